@@ -1,0 +1,216 @@
+/*
+ * outfit_hip.h — C ABI of the MI355X-native batched Gauss IOD engine.
+ *
+ * This is the drop-in boundary for the ONE hot path of FusRoman/Outfit:
+ * `FitIOD::fit_full_iod{,_parallel}`
+ *   (reference: src/initial_orbit_determination/obs_dataset_api.rs:145-207).
+ *
+ * The reference keeps `prepare_iod` (photom error model + OutfitCache,
+ * obs_dataset_api.rs:254-275) on its side; what crosses this boundary is what
+ * `process_traj`/`fit_single_traj`/`estimate_best_orbit` consume
+ * (obs_dataset_api.rs:210-226,277-296; trajectory.rs:429-545):
+ * per-observation (mjd_tt, ra, dec, sigma_ra, sigma_dec) after the error
+ * model, time-sorted per trajectory, plus the two cached observer vectors
+ * (cache/mod.rs:144-174) and, optionally, a legacy-DE Chebyshev table
+ * (jpl_ephem/horizon/horizon_data.rs:810-849).
+ *
+ * Conventions
+ *   - all pointers are caller-owned; inputs are read-only; the library never
+ *     retains them after a call returns (sessions copy what they need);
+ *   - plain `double` / fixed-width integers only, structure-of-arrays;
+ *   - return value 0 = success, negative = whole-call failure
+ *     (outfit_hip_last_error() has the text). Per-trajectory failures are
+ *     DATA (status/cause in outfit_gauss_result_t), never a call failure
+ *     (mirrors obs_dataset_api.rs:63-68,159-171);
+ *   - blocking entry points are re-entrant; a session is owned by one host
+ *     thread at a time.
+ */
+#ifndef OUTFIT_HIP_H
+#define OUTFIT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OUTFIT_HIP_ABI_VERSION 1
+
+/* ---- whole-call return codes --------------------------------------------- */
+#define OUTFIT_OK                 0
+#define OUTFIT_ERR_INVALID_PARAM -1 /* IODParamsBuilder::build rules, mod.rs:544-624 (OutfitError::InvalidIODParameter) */
+#define OUTFIT_ERR_INVALID_BATCH -2 /* malformed offsets / null pointers                                          */
+#define OUTFIT_ERR_NO_DEVICE     -3 /* HIP runtime reports no usable gfx950 device                                */
+#define OUTFIT_ERR_HIP           -4 /* a HIP runtime call failed                                                  */
+#define OUTFIT_ERR_EPHEM_RANGE   -5 /* an epoch lies outside the table (reference panics: horizon_data.rs:722-724)*/
+#define OUTFIT_ERR_BAD_HANDLE    -6
+
+/* ---- per-trajectory status (outfit_gauss_result_t.status) ------------------
+ * mirrors the Err variants `estimate_best_orbit` can return
+ * (trajectory.rs:439-451,491-497,531-544; outfit_errors.rs:195-250). */
+#define OUTFIT_TRAJ_OK                    0 /* FitOrbitResult::IODGauss((GaussResult, rms))            */
+#define OUTFIT_TRAJ_NO_FEASIBLE_TRIPLETS  1 /* OutfitError::NoFeasibleTriplets{span,n_obs,dt_min,dt_max}*/
+#define OUTFIT_TRAJ_NO_VIABLE_ORBIT       2 /* OutfitError::NoViableOrbit{cause,attempts}               */
+#define OUTFIT_TRAJ_INVALID_CONVERSION    3 /* to_equinoctial()? aborted: parabolic band (cometary_element.rs:265-269) */
+#define OUTFIT_TRAJ_INVALID_ORBIT         4 /* to_equinoctial()? aborted: hyperbolic_mean_anomaly e<=1 (cometary_element.rs:225-229) */
+
+/* ---- root cause carried by NoViableOrbit (outfit_gauss_result_t.cause) ----- */
+#define OUTFIT_CAUSE_NONE                         0
+#define OUTFIT_CAUSE_GAUSS_NO_ROOTS_FOUND         1 /* gauss.rs:1133-1135,1201-1205 */
+#define OUTFIT_CAUSE_SINGULAR_DIRECTION_MATRIX    2 /* gauss.rs:544-546             */
+#define OUTFIT_CAUSE_POLYNOMIAL_ROOT_FINDING_FAILED 3 /* gauss.rs:984             */
+#define OUTFIT_CAUSE_NON_FINITE_SCORE             4 /* trajectory.rs:509-511        */
+
+/* ---- GaussResult variant / OrbitalElements variant ------------------------- */
+#define OUTFIT_STAGE_PRELIM    0 /* GaussResult::PrelimOrbit    (gauss_result.rs:99-102) */
+#define OUTFIT_STAGE_CORRECTED 1 /* GaussResult::CorrectedOrbit                          */
+#define OUTFIT_KIND_KEPLERIAN  0 /* (a, e, i, Omega, omega, M)  keplerian_element.rs:145 */
+#define OUTFIT_KIND_COMETARY   1 /* (q, e, i, Omega, omega, nu) cometary_element.rs:180-202 */
+
+/* Mirrors `IODParams` (initial_orbit_determination/mod.rs:225-266), field for
+ * field and in declaration order. Defaults: mod.rs:308-344. */
+typedef struct outfit_iod_params {
+  uint64_t n_noise_realizations;
+  double   noise_scale;
+  double   extf;
+  double   dtmax;
+  double   dt_min;
+  double   dt_max_triplet;
+  double   optimal_interval_time;
+  uint64_t max_obs_for_triplets;
+  uint32_t max_triplets;
+  uint32_t _pad0;
+  double   gap_max;
+  double   max_ecc;
+  double   max_perihelion_au;
+  double   min_rho2_au;
+  uint32_t aberth_max_iter;
+  uint32_t _pad1;
+  double   aberth_eps;
+  double   kepler_eps;
+  uint64_t max_tested_solutions;
+  double   r2_min_au;
+  double   r2_max_au;
+  double   newton_eps;
+  uint64_t newton_max_it;
+  double   root_imag_eps;
+} outfit_iod_params_t;
+
+/* One batch = all trajectories of a prepared dataset (what `process_traj`
+ * iterates over, obs_dataset_api.rs:159-171,191-205). Observations of
+ * trajectory t are rows traj_offset[t] .. traj_offset[t+1]-1 and MUST be
+ * sorted by mjd_tt (fit_single_traj sorts them, obs_dataset_api.rs:222-223). */
+typedef struct outfit_obs_batch {
+  uint64_t        n_traj;
+  const uint64_t *traj_offset;   /* n_traj + 1 entries                                            */
+  const double   *mjd_tt;        /* Observation::mjd_tt()                                          */
+  const double   *ra;            /* equ_coord().ra        [rad]                                    */
+  const double   *dec;           /* equ_coord().dec       [rad]                                    */
+  const double   *sigma_ra;      /* equ_coord().ra_error  [rad] (after error model)                */
+  const double   *sigma_dec;     /* equ_coord().dec_error [rad]                                    */
+  const double   *obs_helio_equ; /* 3/obs, AU, equatorial J2000 = cache.get_helio_position         */
+  const double   *obs_geo_ecl;   /* 3/obs, AU, ecliptic J2000 = get_observer_geocentric_position;
+                                    NULL => the RMS stage uses obs_helio_equ directly              */
+  const double   *noise_z;       /* NULL or, per trajectory, max_triplets*n_noise*6 standard
+                                    normals in (triplet, realisation, ra0 ra1 ra2 dec0 dec1 dec2)
+                                    order (gauss.rs:341-386); required when n_noise_realizations>0 */
+} outfit_obs_batch_t;
+
+/* Legacy-DE ("horizon") Chebyshev table, restricted to what
+ * `HorizonData::ephemeris(Earth, Sun, ..)` reads (horizon_data.rs:810-849):
+ * body 0 = Earth-Moon barycentre (IPT row 2), 1 = Moon (row 9), 2 = Sun (row 10).
+ * Per block the coefficients are packed as
+ *   for body b: for sub-interval s: for axis (x,y,z): ncoef[b] doubles
+ * i.e. the order of the DE record itself (horizon_records.rs:132-171),
+ * in km (the reference divides by AU afterwards, interpolation_result.rs:82). */
+typedef struct outfit_ephem {
+  double   jd_start;     /* header.start_period   */
+  double   jd_end;       /* header.end_period     */
+  double   block_days;   /* header.period_lenght (32 for DE440) */
+  double   emrat;        /* header.earth_moon_mass_ratio */
+  uint32_t ncoef[3];     /* DE440: 13, 13, 11 (horizon_data.rs:869-885) */
+  uint32_t nsub[3];      /* DE440:  2,  8,  2 */
+  uint64_t n_blocks;
+  const double *coef;    /* n_blocks * sum_b(3*ncoef[b]*nsub[b]) doubles */
+} outfit_ephem_t;
+
+/* What the host needs to rebuild
+ *   Result<FitOrbitResult::IODGauss((GaussResult, IODRMS)), OutfitError>
+ * for one trajectory (constants.rs:134-137,195). 96 bytes. */
+typedef struct outfit_gauss_result {
+  int32_t  status;           /* OUTFIT_TRAJ_*                                   */
+  int32_t  cause;            /* OUTFIT_CAUSE_* (NoViableOrbit only)             */
+  int32_t  stage;            /* OUTFIT_STAGE_*                                  */
+  int32_t  kind;             /* OUTFIT_KIND_*                                   */
+  uint32_t attempts;         /* n_attempts (trajectory.rs:463,478)              */
+  uint32_t best_triplet;     /* index into the weight-sorted triplet list       */
+  uint32_t best_realization; /* 0 = noise-free original (gauss.rs:342-346)      */
+  uint32_t n_triplets;       /* triplets generated for this trajectory          */
+  double   epoch;            /* reference_epoch (MJD TT, light-time corrected)  */
+  double   elem[6];          /* see OUTFIT_KIND_*                               */
+  double   rms;              /* IODRMS                                          */
+} outfit_gauss_result_t;
+
+/* ---- parameters ------------------------------------------------------------ */
+/* IODParams::default() (mod.rs:308-344). */
+void outfit_hip_iod_params_default(outfit_iod_params_t *p);
+/* IODParamsBuilder::build validation (mod.rs:544-624); 0 or OUTFIT_ERR_INVALID_PARAM. */
+int  outfit_hip_iod_params_validate(const outfit_iod_params_t *p);
+
+/* ---- blocking drop-in entry point ------------------------------------------
+ * Replaces the body of fit_full_iod / fit_full_iod_parallel after prepare_iod
+ * (obs_dataset_api.rs:159-171,191-205): trajectories are sharded over
+ * `n_devices` GPUs of this process (0 = all visible), results are written to
+ * out[0..n_traj) in trajectory order. */
+int outfit_hip_fit_full_iod(const outfit_iod_params_t *params,
+                            const outfit_obs_batch_t  *batch,
+                            const outfit_ephem_t      *ephem /* nullable */,
+                            int n_devices,
+                            outfit_gauss_result_t     *out);
+
+/* ---- resident-session API (one device) --------------------------------------
+ * Same computation with inputs kept in HBM between runs; what the blocking
+ * call uses internally per device and what bench.py / a long-lived host uses.
+ * `stream` is a hipStream_t (NULL = the session's own stream). */
+typedef struct outfit_hip_session outfit_hip_session_t;
+
+int outfit_hip_session_create(const outfit_iod_params_t *params,
+                              const outfit_obs_batch_t  *batch,
+                              const outfit_ephem_t      *ephem /* nullable */,
+                              int device,
+                              outfit_hip_session_t     **out_session);
+/* Enqueue every kernel of the path; d_out (device memory, n_traj records) may be
+ * NULL to use the session's own result buffer. Asynchronous w.r.t. the host. */
+int outfit_hip_session_run(outfit_hip_session_t *s, void *stream, void *d_out);
+/* Wait for the last run and copy the session's result buffer to host memory. */
+int outfit_hip_session_results(outfit_hip_session_t *s, outfit_gauss_result_t *out);
+/* Device pointer of the session's own result buffer (n_traj records). */
+void *outfit_hip_session_device_results(outfit_hip_session_t *s);
+/* Per-kernel durations of the most recent run, measured with HIP events on the
+ * run's stream (ms). names[i] are static strings; returns the kernel count. */
+int outfit_hip_session_kernel_times(outfit_hip_session_t *s, int max_n,
+                                    const char **names, float *ms);
+/* Enable/disable the per-kernel HIP-event timing above (default off). */
+int outfit_hip_session_set_profiling(outfit_hip_session_t *s, int enabled);
+void outfit_hip_session_destroy(outfit_hip_session_t *s);
+
+/* ---- kepler::propagate_universal (kepler/propagation.rs:114-174) -------------
+ * Batched over n states; solver kind NewtonRaphson (kepler/params.rs:66-73)
+ * with `convergency`; out is 11 doubles per state:
+ *   r1[3], v1[3], f, g, f_dot, g_dot, psi.
+ * status[i]: 0 ok, 1 DegenerateState (initial radius), 2 solver did not
+ * converge (NewtonRaphsonKeplerConvergence), 3 DegenerateState (propagated). */
+int outfit_hip_propagate_universal(uint64_t n, const double *r0v0 /* 6n */,
+                                   const double *t0, const double *t1,
+                                   double convergency,
+                                   double *out /* 11n */, int32_t *status /* n */);
+
+/* ---- diagnostics ------------------------------------------------------------ */
+const char *outfit_hip_last_error(void); /* thread-local, never NULL */
+int         outfit_hip_abi_version(void);
+int         outfit_hip_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OUTFIT_HIP_H */

@@ -1,0 +1,171 @@
+/*
+ * oracle.h — CPU restatement of Outfit's Gauss-IOD hot path (plain C, fp64).
+ *
+ * TEST INFRASTRUCTURE ONLY. Nothing under oracle/ is part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * liboutfit_oracle.so, and only as the checker / CPU baseline. The product
+ * path (outfit_amd/csrc, liboutfit_hip.so) neither links nor calls this code.
+ *
+ * Parity pin: the reference is pure Rust and cannot be built here (no
+ * cargo/rustc, crates not vendored) — see DESIGN.md. This restatement follows
+ * the reference source function by function (file:line cited at each
+ * function) and is pinned by the reference's own self-contained known-answer
+ * tests, committed as data under tests/golden/.
+ * Arithmetic that lives in third-party crates absent from /root/reference is
+ * restated from their published algorithm:
+ *   aberth 0.4.1 (Cargo.lock) — Aberth–Ehrlich iteration, pinned by
+ *                               gauss.rs:1543-1570 (values AND order);
+ *   roots 0.0.8               — find_root_newton_raphson + SimpleConvergency,
+ *                               pinned by equinoctial_element.rs:1267-1315;
+ *   nalgebra 0.34.2           — 3x3 try_inverse / dot / norm / gemv operation
+ *                               order, pinned by gauss.rs:1470-1487.
+ *
+ * Build: -O2 -ffp-contract=off -fno-fast-math (Rust never contracts a*b+c).
+ */
+#ifndef OUTFIT_ORACLE_H
+#define OUTFIT_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "../include/outfit_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* constants.rs */
+#define ORC_DPI 6.283185307179586476925286766559 /* constants.rs:31  2*PI (rounds to 2.0*f64 PI) */
+#define ORC_PI 3.14159265358979323846
+#define ORC_EPS 2.220446049250313e-16 /* f64::EPSILON */
+#define ORC_GAUSS_GRAV 0.01720209895  /* constants.rs:70 */
+#define ORC_AU 149597870.7            /* constants.rs:37 */
+#define ORC_VLIGHT 2.99792458e5       /* constants.rs:76 */
+#define ORC_SECONDS_PER_DAY 86400.0   /* constants.rs:34 */
+
+/* ---- kepler/ --------------------------------------------------------------- */
+typedef struct {
+  double dt, r0, sig0, mu, alpha, e0;
+  double convergency;          /* SolverParams.convergency   (params.rs:26)  */
+  int has_guess;               /* SolverParams.psi_guess     (params.rs:28)  */
+  double psi_guess;
+  int max_iter_prelim_kepuni;  /* params.rs:30, default 20                    */
+  int kind;                    /* 0 NewtonRaphson, 1 BrentDecker, 2 Auto      */
+} orc_kepler_params;
+
+typedef struct { double psi, s0, s1, s2, s3; } orc_kepler_solution;
+
+void   orc_s_funct(double psi, double alpha, double s[4]);
+double orc_principal_angle(double a);
+double orc_prelim_elliptic(const orc_kepler_params *p);
+double orc_prelim_hyperbolic(const orc_kepler_params *p);
+double orc_prelim_parabolic(const orc_kepler_params *p);
+double orc_prelim_kepuni(const orc_kepler_params *p);
+int    orc_solve_kepuni_with_guess(const orc_kepler_params *p, orc_kepler_solution *sol);
+int    orc_solve_kepuni_brent_dekker(const orc_kepler_params *p, orc_kepler_solution *sol);
+int    orc_kepler_solve(const orc_kepler_params *p, orc_kepler_solution *sol);
+/* returns 0 ok, nonzero Err(VelocityCorrectionError / Kepler convergence) */
+int    orc_velocity_correction_with_guess(const double x1[3], const double x2[3], const double v2[3],
+                                          double dt, double peri_max, double ecc_max, int has_guess,
+                                          double chi_guess, double eps, double v_out[3], double *f,
+                                          double *g, double *chi);
+/* out: r1[3] v1[3] f g fdot gdot psi ; returns status as outfit_hip_propagate_universal */
+int    orc_propagate_universal(const double r[3], const double v[3], double t0, double t1,
+                               double convergency, int kind, double out[11]);
+
+/* ---- orb_elem.rs / orbit_type/ ----------------------------------------------- */
+/* returns 0 if None (zero angular momentum) else 1; out = accepted, ecc, peri, energy */
+int orc_eccentricity_control(const double r[3], const double v[3], double peri_max, double ecc_max,
+                             int *accepted, double *ecc, double *peri, double *energy);
+typedef struct {
+  int kind;        /* OUTFIT_KIND_* */
+  double epoch;
+  double e[6];     /* Keplerian (a,e,i,Om,om,M) or Cometary (q,e,i,Om,om,nu) */
+} orc_elements;
+void orc_ccek1(const double pos[3], const double vel[3], double epoch, orc_elements *out);
+typedef struct { double epoch, a, h, k, p, q, lambda; } orc_equinoctial;
+/* 0 ok, OUTFIT_TRAJ_INVALID_CONVERSION, OUTFIT_TRAJ_INVALID_ORBIT */
+int orc_to_equinoctial(const orc_elements *el, orc_equinoctial *eq);
+/* roots::find_root_newton_raphson restatement; 0 ok, 1 Err */
+int orc_solve_kepler_equation(const orc_equinoctial *eq, double lambda1, double varpi, double *F);
+int orc_propagate_twobody(const orc_equinoctial *eq, double t0, double t1, double pos[3],
+                          double vel[3]);
+
+/* ---- aberth crate ------------------------------------------------------------ */
+#define ORC_ABERTH_CONVERGED 0
+#define ORC_ABERTH_MAXITER 1
+#define ORC_ABERTH_FAILED 2
+int orc_aberth9(const double poly[9], uint32_t max_iter, double eps, double re[8], double im[8],
+                uint32_t *iterations);
+
+/* ---- gauss.rs ---------------------------------------------------------------- */
+typedef struct {
+  uint32_t idx[3];
+  double ra[3], dec[3], t[3];
+  double obs[3][3]; /* obs[row][col]: row = x,y,z ; col = epoch (Matrix3 columns = epochs) */
+} orc_gauss_obs;
+
+typedef struct {
+  double tau1, tau3;
+  double S[3][3], Sinv[3][3]; /* [row][col] */
+  double a[3], b[3];
+} orc_gauss_prelim;
+
+int  orc_gauss_prelim_fn(const orc_gauss_obs *g, orc_gauss_prelim *out); /* 0 ok, 1 singular */
+void orc_coeff_eight_poly(const orc_gauss_obs *g, const orc_gauss_prelim *p, double *c6, double *c3,
+                          double *c0);
+uint32_t orc_descartes_upper_bound(double c0, double c3, double c6, double zero_eps);
+int  orc_solve_8poly(const double poly[9], uint32_t max_iter, double aberth_eps, double root_eps,
+                     double roots[8], int *n_roots);
+int  orc_position_vector_and_reference_epoch(const orc_gauss_obs *g, const outfit_iod_params_t *ip,
+                                             const double S[3][3], const double Sinv[3][3],
+                                             const double c[3], double pos[3][3], double *epoch);
+void orc_gibbs_correction(const double pos[3][3], double tau1, double tau3, double vel[3]);
+int  orc_accept_root(const orc_gauss_obs *g, const outfit_iod_params_t *ip, double root,
+                     const orc_gauss_prelim *p, double pos[3][3], double vel[3], double *epoch);
+int  orc_pos_and_vel_correction(const orc_gauss_obs *g, const outfit_iod_params_t *ip,
+                                const double pos_in[3][3], const double vel_in[3],
+                                const double S[3][3], const double Sinv[3][3], double peri_max,
+                                double ecc_max, double err_max, uint64_t itmax, double pos[3][3],
+                                double vel[3], double *epoch);
+typedef struct {
+  int stage; /* OUTFIT_STAGE_* */
+  orc_elements el;
+} orc_gauss_result;
+/* returns 0 ok else OUTFIT_CAUSE_* ; n_out <= 8 (at most 8 roots) */
+int orc_prelim_orbit_all(const orc_gauss_obs *g, const outfit_iod_params_t *ip,
+                         orc_gauss_result out[8], int *n_out);
+int orc_prelim_orbit(const orc_gauss_obs *g, const outfit_iod_params_t *ip, orc_gauss_result *out);
+
+/* ---- triplet_generation/ ------------------------------------------------------- */
+/* returns number of triplets written (<= max_triplets); idx = 3 per triplet; w = weights */
+size_t orc_generate_triplet_indices(const double *mjd, size_t n_obs, const outfit_iod_params_t *ip,
+                                    uint32_t *idx, double *w);
+size_t orc_downsample_uniform_with_edges(size_t n, size_t max_keep, size_t *keep);
+
+/* ---- jpl_ephem/horizon + ephemeris/ ---------------------------------------------- */
+/* Earth wrt Sun, equatorial J2000, AU. 0 ok / OUTFIT_ERR_EPHEM_RANGE */
+int  orc_earth_ephemeris(const outfit_ephem_t *eph, double mjd_tt, double pos[3]);
+void orc_observer_position_equ(const outfit_ephem_t *eph, double mjd_tt, const double geo_ecl[3],
+                               double out[3], int *err);
+void orc_topocentric_radec(const double ast_pos[3], const double ast_vel[3], const double obs_pos[3],
+                           double *ra, double *dec);
+/* ephemeris_error ; 0 ok, 1 Err */
+int orc_ephemeris_error(const orc_equinoctial *eq, double mjd, double ra, double dec, double sra,
+                        double sdec, const double obs_pos_equ[3], double *term);
+
+/* ---- trajectory.rs / obs_dataset_api.rs ------------------------------------------- */
+void orc_select_rms_interval(const double *mjd, size_t n_obs, const uint32_t idx[3],
+                             const outfit_iod_params_t *ip, size_t *i_start, size_t *i_end);
+int  orc_fit_full_iod(const outfit_iod_params_t *params, const outfit_obs_batch_t *batch,
+                      const outfit_ephem_t *ephem, int n_threads, int hoist_ephem,
+                      outfit_gauss_result_t *out);
+void orc_estimate_best_orbit(const outfit_iod_params_t *ip, const outfit_obs_batch_t *b,
+                             const outfit_ephem_t *eph, uint64_t traj, int hoist_ephem,
+                             outfit_gauss_result_t *out);
+void orc_iod_params_default(outfit_iod_params_t *p);
+int  orc_iod_params_validate(const outfit_iod_params_t *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

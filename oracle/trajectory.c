@@ -1,0 +1,275 @@
+/*
+ * trajectory.c — oracle restatement of src/trajectory.rs (estimate_best_orbit,
+ * rms_orbit_error, select_rms_interval), the batch driver of
+ * src/initial_orbit_determination/obs_dataset_api.rs and the IODParams
+ * defaults/validation of src/initial_orbit_determination/mod.rs.
+ * TEST INFRASTRUCTURE ONLY (see oracle.h).
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include "oracle.h"
+
+/* mod.rs:308-344 */
+void orc_iod_params_default(outfit_iod_params_t *p) {
+  memset(p, 0, sizeof *p);
+  p->n_noise_realizations = 20;
+  p->noise_scale = 1.0;
+  p->extf = -1.0;
+  p->dtmax = 30.0;
+  p->dt_min = 0.03;
+  p->dt_max_triplet = 150.0;
+  p->optimal_interval_time = 20.0;
+  p->max_obs_for_triplets = 100;
+  p->max_triplets = 10;
+  p->gap_max = 8.0 / 24.0;
+  p->max_ecc = 5.0;
+  p->max_perihelion_au = 1.0e3;
+  p->min_rho2_au = 0.01;
+  p->aberth_max_iter = 50;
+  p->aberth_eps = 1.0e-6;
+  p->kepler_eps = 1e3 * ORC_EPS;
+  p->max_tested_solutions = 3;
+  p->r2_min_au = 0.05;
+  p->r2_max_au = 200.0;
+  p->newton_eps = 1.0e-10;
+  p->newton_max_it = 50;
+  p->root_imag_eps = 1.0e-6;
+}
+
+/* mod.rs:466-480,544-624 : partial_cmp based, so NaN is invalid and +inf is accepted */
+static int gt0(double x) { return x > 0.0; }
+static int ge0(double x) { return x >= 0.0; }
+int orc_iod_params_validate(const outfit_iod_params_t *p) {
+  if (!ge0(p->noise_scale)) return OUTFIT_ERR_INVALID_PARAM;
+  if (!ge0(p->dt_min) || !ge0(p->dt_max_triplet) || !ge0(p->dtmax)) return OUTFIT_ERR_INVALID_PARAM;
+  if (!ge0(p->max_ecc)) return OUTFIT_ERR_INVALID_PARAM;
+  if (!ge0(p->root_imag_eps)) return OUTFIT_ERR_INVALID_PARAM;
+  if (!gt0(p->max_perihelion_au)) return OUTFIT_ERR_INVALID_PARAM;
+  if (!gt0(p->min_rho2_au)) return OUTFIT_ERR_INVALID_PARAM;
+  if (!gt0(p->aberth_eps)) return OUTFIT_ERR_INVALID_PARAM;
+  if (!gt0(p->kepler_eps)) return OUTFIT_ERR_INVALID_PARAM;
+  if (!gt0(p->newton_eps)) return OUTFIT_ERR_INVALID_PARAM;
+  if (p->newton_max_it == 0) return OUTFIT_ERR_INVALID_PARAM;
+  if (p->aberth_max_iter == 0) return OUTFIT_ERR_INVALID_PARAM;
+  if (p->max_tested_solutions < 1) return OUTFIT_ERR_INVALID_PARAM;
+  if (!(gt0(p->r2_min_au) && gt0(p->r2_max_au) && p->r2_min_au <= p->r2_max_au))
+    return OUTFIT_ERR_INVALID_PARAM;
+  return 0;
+}
+
+/* trajectory.rs:294-350 (indices always valid here: idx < n_obs) */
+void orc_select_rms_interval(const double *mjd, size_t n_obs, const uint32_t idx[3],
+                             const outfit_iod_params_t *ip, size_t *i_start, size_t *i_end) {
+  size_t i1 = idx[0], i3 = idx[2];
+  double t1 = mjd[i1], t3 = mjd[i3];
+  double dt = (ip->extf >= 0.0) ? (t3 - t1) * ip->extf : 10.0 * (mjd[n_obs - 1] - mjd[0]);
+  if (ip->dtmax >= 0.0) dt = fmax(dt, ip->dtmax); /* f64::max: NaN-ignoring, like fmax */
+  size_t s = 0;
+  for (size_t i = i1 + 1; i-- > 0;) {
+    if (t1 - mjd[i] > dt) break;
+    s = i;
+  }
+  size_t e = n_obs - 1;
+  for (size_t i = i3; i < n_obs; ++i) {
+    if (mjd[i] - t3 > dt) break;
+    e = i;
+  }
+  *i_start = s;
+  *i_end = e;
+}
+
+typedef struct {
+  const outfit_iod_params_t *ip;
+  const outfit_obs_batch_t *b;
+  const outfit_ephem_t *eph;
+  int hoist;
+} ctx_t;
+
+/* observer position used by the residual of observation `o` (global row) */
+static int observer_pos(const ctx_t *c, uint64_t o, const double *hoisted, double out[3]) {
+  if (hoisted) { out[0] = hoisted[0]; out[1] = hoisted[1]; out[2] = hoisted[2]; return 0; }
+  if (c->eph && c->b->obs_geo_ecl) {
+    int err;
+    orc_observer_position_equ(c->eph, c->b->mjd_tt[o], c->b->obs_geo_ecl + 3 * o, out, &err);
+    return err;
+  }
+  out[0] = c->b->obs_helio_equ[3 * o];
+  out[1] = c->b->obs_helio_equ[3 * o + 1];
+  out[2] = c->b->obs_helio_equ[3 * o + 2];
+  return 0;
+}
+
+/* trajectory.rs:352-427 with prune_if_rms_ge = Some(best_rms) */
+static double rms_orbit_error(const ctx_t *c, uint64_t base, size_t n_obs, const orc_gauss_obs *g,
+                              const orc_equinoctial *eq, double prune, const double *hoist_buf) {
+  const outfit_obs_batch_t *b = c->b;
+  size_t s, e;
+  orc_select_rms_interval(b->mjd_tt + base, n_obs, g->idx, c->ip, &s, &e);
+  double denom = 2.0 * (double)(e - s + 1);
+  double cutoff = isfinite(prune) ? prune * prune * denom : INFINITY;
+  double acc = 0.0;
+  for (size_t i = s; i <= e; ++i) {
+    uint64_t o = base + i;
+    double op[3], term;
+    if (observer_pos(c, o, hoist_buf ? hoist_buf + 3 * i : NULL, op)) return prune;
+    if (orc_ephemeris_error(eq, b->mjd_tt[o], b->ra[o], b->dec[o], b->sigma_ra[o], b->sigma_dec[o],
+                            op, &term))
+      return prune; /* Err(_) => Break(prune) */
+    double ns = acc + term;
+    if (ns >= cutoff) return prune;
+    acc = ns;
+  }
+  return sqrt(acc / denom);
+}
+
+/* trajectory.rs:429-545 + obs_dataset_api.rs:210-226 (observations already time-sorted) */
+void orc_estimate_best_orbit(const outfit_iod_params_t *ip, const outfit_obs_batch_t *b,
+                             const outfit_ephem_t *eph, uint64_t traj, int hoist_ephem,
+                             outfit_gauss_result_t *out) {
+  ctx_t c = {ip, b, eph, hoist_ephem};
+  uint64_t base = b->traj_offset[traj];
+  size_t n_obs = (size_t)(b->traj_offset[traj + 1] - base);
+  memset(out, 0, sizeof *out);
+
+  size_t cap = ip->max_triplets ? ip->max_triplets : 1;
+  uint32_t *tidx = (uint32_t *)malloc(sizeof(uint32_t) * 3 * cap);
+  size_t nt = orc_generate_triplet_indices(b->mjd_tt + base, n_obs, ip, tidx, NULL);
+  out->n_triplets = (uint32_t)nt;
+  if (nt == 0) {
+    out->status = OUTFIT_TRAJ_NO_FEASIBLE_TRIPLETS;
+    free(tidx);
+    return;
+  }
+  double *hoist_buf = NULL;
+  if (hoist_ephem && eph && b->obs_geo_ecl) {
+    hoist_buf = (double *)malloc(sizeof(double) * 3 * n_obs);
+    for (size_t i = 0; i < n_obs; ++i) {
+      int err;
+      orc_observer_position_equ(eph, b->mjd_tt[base + i], b->obs_geo_ecl + 3 * (base + i),
+                                hoist_buf + 3 * i, &err);
+    }
+  }
+
+  double best_rms = INFINITY;
+  int have_best = 0, last_error = 0;
+  orc_gauss_result best;
+  uint32_t attempts = 0, best_t = 0, best_r = 0;
+  size_t R = 1 + (size_t)ip->n_noise_realizations;
+  int aborted = 0;
+
+  for (size_t t = 0; t < nt && !aborted; ++t) {
+    orc_gauss_obs g0;
+    for (int k = 0; k < 3; ++k) {
+      uint32_t i = tidx[3 * t + k];
+      uint64_t o = base + i;
+      g0.idx[k] = i;
+      g0.ra[k] = b->ra[o];
+      g0.dec[k] = b->dec[o];
+      g0.t[k] = b->mjd_tt[o];
+      for (int r = 0; r < 3; ++r) g0.obs[r][k] = b->obs_helio_equ[3 * o + r];
+    }
+    /* extract_errors + realizations_iter (gauss.rs:323-387) */
+    double sra[3], sdec[3];
+    for (int k = 0; k < 3; ++k) {
+      sra[k] = b->sigma_ra[base + g0.idx[k]] * ip->noise_scale;
+      sdec[k] = b->sigma_dec[base + g0.idx[k]] * ip->noise_scale;
+    }
+    for (size_t r = 0; r < R; ++r) {
+      orc_gauss_obs g = g0;
+      if (r > 0) {
+        const double *z = b->noise_z +
+                          ((traj * (uint64_t)ip->max_triplets + t) * ip->n_noise_realizations + (r - 1)) * 6;
+        for (int k = 0; k < 3; ++k) {
+          g.ra[k] = g0.ra[k] + z[k] * sra[k];
+          g.dec[k] = g0.dec[k] + z[3 + k] * sdec[k];
+        }
+      }
+      attempts += 1;
+      orc_gauss_result res;
+      int rc = orc_prelim_orbit(&g, ip, &res);
+      if (rc) { last_error = rc; continue; }
+      orc_equinoctial eq;
+      int ec = orc_to_equinoctial(&res.el, &eq);
+      if (ec) { /* `?` aborts the whole trajectory (quirk Q2) */
+        out->status = ec;
+        out->attempts = attempts;
+        aborted = 1;
+        break;
+      }
+      double rms = rms_orbit_error(&c, base, n_obs, &g, &eq, best_rms, hoist_buf);
+      if (!isfinite(rms)) { last_error = OUTFIT_CAUSE_NON_FINITE_SCORE; continue; }
+      if (rms < best_rms) {
+        best_rms = rms;
+        best = res;
+        have_best = 1;
+        best_t = (uint32_t)t;
+        best_r = (uint32_t)r;
+      }
+    }
+  }
+  if (!aborted) {
+    out->attempts = attempts;
+    if (have_best) {
+      out->status = OUTFIT_TRAJ_OK;
+      out->stage = best.stage;
+      out->kind = best.el.kind;
+      out->best_triplet = best_t;
+      out->best_realization = best_r;
+      out->epoch = best.el.epoch;
+      memcpy(out->elem, best.el.e, sizeof(double) * 6);
+      out->rms = best_rms;
+    } else {
+      out->status = OUTFIT_TRAJ_NO_VIABLE_ORBIT;
+      out->cause = last_error;
+    }
+  }
+  free(hoist_buf);
+  free(tidx);
+}
+
+typedef struct {
+  const outfit_iod_params_t *ip;
+  const outfit_obs_batch_t *b;
+  const outfit_ephem_t *eph;
+  int hoist;
+  volatile uint64_t *next;
+  outfit_gauss_result_t *out;
+} work_t;
+
+static void *worker(void *arg) {
+  work_t *w = (work_t *)arg;
+  for (;;) {
+    /* dynamic scheduling, one task per trajectory = par_iter_traj_id (obs_dataset_api.rs:191-197) */
+    uint64_t t = __atomic_fetch_add(w->next, 16, __ATOMIC_RELAXED);
+    if (t >= w->b->n_traj) break;
+    uint64_t hi = t + 16 < w->b->n_traj ? t + 16 : w->b->n_traj;
+    for (uint64_t i = t; i < hi; ++i) orc_estimate_best_orbit(w->ip, w->b, w->eph, i, w->hoist, &w->out[i]);
+  }
+  return NULL;
+}
+
+int orc_fit_full_iod(const outfit_iod_params_t *params, const outfit_obs_batch_t *batch,
+                     const outfit_ephem_t *ephem, int n_threads, int hoist_ephem,
+                     outfit_gauss_result_t *out) {
+  int rc = orc_iod_params_validate(params);
+  if (rc) return rc;
+  if (!batch || !batch->traj_offset || !out) return OUTFIT_ERR_INVALID_BATCH;
+  if (params->n_noise_realizations > 0 && !batch->noise_z) return OUTFIT_ERR_INVALID_BATCH;
+  if (ephem && batch->obs_geo_ecl) {
+    uint64_t n = batch->traj_offset[batch->n_traj];
+    for (uint64_t o = 0; o < n; ++o) {
+      double p[3];
+      if (orc_earth_ephemeris(ephem, batch->mjd_tt[o], p)) return OUTFIT_ERR_EPHEM_RANGE;
+    }
+  }
+  volatile uint64_t next = 0;
+  work_t w = {params, batch, ephem, hoist_ephem, &next, out};
+  if (n_threads <= 1) { worker(&w); return 0; }
+  pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
+  for (int i = 0; i < n_threads; ++i) pthread_create(&th[i], NULL, worker, &w);
+  for (int i = 0; i < n_threads; ++i) pthread_join(th[i], NULL);
+  free(th);
+  return 0;
+}

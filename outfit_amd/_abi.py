@@ -1,0 +1,121 @@
+"""ctypes mirror of ``include/outfit_hip.h`` (the C-ABI drop-in boundary).
+
+Field order and types follow the header exactly; the header cites the
+reference interface each struct replaces (``IODParams``:
+src/initial_orbit_determination/mod.rs:225-266, ``FitIOD`` inputs:
+src/initial_orbit_determination/obs_dataset_api.rs:145-296).
+"""
+import ctypes as C
+
+ABI_VERSION = 1
+
+OUTFIT_OK = 0
+OUTFIT_ERR_INVALID_PARAM = -1
+OUTFIT_ERR_INVALID_BATCH = -2
+OUTFIT_ERR_NO_DEVICE = -3
+OUTFIT_ERR_HIP = -4
+OUTFIT_ERR_EPHEM_RANGE = -5
+OUTFIT_ERR_BAD_HANDLE = -6
+
+TRAJ_OK = 0
+TRAJ_NO_FEASIBLE_TRIPLETS = 1
+TRAJ_NO_VIABLE_ORBIT = 2
+TRAJ_INVALID_CONVERSION = 3
+TRAJ_INVALID_ORBIT = 4
+
+CAUSE_NONE = 0
+CAUSE_GAUSS_NO_ROOTS_FOUND = 1
+CAUSE_SINGULAR_DIRECTION_MATRIX = 2
+CAUSE_POLYNOMIAL_ROOT_FINDING_FAILED = 3
+CAUSE_NON_FINITE_SCORE = 4
+
+STAGE_PRELIM = 0
+STAGE_CORRECTED = 1
+KIND_KEPLERIAN = 0
+KIND_COMETARY = 1
+
+_dp = C.POINTER(C.c_double)
+
+
+class IODParamsC(C.Structure):
+    _fields_ = [
+        ("n_noise_realizations", C.c_uint64),
+        ("noise_scale", C.c_double),
+        ("extf", C.c_double),
+        ("dtmax", C.c_double),
+        ("dt_min", C.c_double),
+        ("dt_max_triplet", C.c_double),
+        ("optimal_interval_time", C.c_double),
+        ("max_obs_for_triplets", C.c_uint64),
+        ("max_triplets", C.c_uint32),
+        ("_pad0", C.c_uint32),
+        ("gap_max", C.c_double),
+        ("max_ecc", C.c_double),
+        ("max_perihelion_au", C.c_double),
+        ("min_rho2_au", C.c_double),
+        ("aberth_max_iter", C.c_uint32),
+        ("_pad1", C.c_uint32),
+        ("aberth_eps", C.c_double),
+        ("kepler_eps", C.c_double),
+        ("max_tested_solutions", C.c_uint64),
+        ("r2_min_au", C.c_double),
+        ("r2_max_au", C.c_double),
+        ("newton_eps", C.c_double),
+        ("newton_max_it", C.c_uint64),
+        ("root_imag_eps", C.c_double),
+    ]
+
+
+class ObsBatchC(C.Structure):
+    _fields_ = [
+        ("n_traj", C.c_uint64),
+        ("traj_offset", C.POINTER(C.c_uint64)),
+        ("mjd_tt", _dp),
+        ("ra", _dp),
+        ("dec", _dp),
+        ("sigma_ra", _dp),
+        ("sigma_dec", _dp),
+        ("obs_helio_equ", _dp),
+        ("obs_geo_ecl", _dp),
+        ("noise_z", _dp),
+    ]
+
+
+class EphemC(C.Structure):
+    _fields_ = [
+        ("jd_start", C.c_double),
+        ("jd_end", C.c_double),
+        ("block_days", C.c_double),
+        ("emrat", C.c_double),
+        ("ncoef", C.c_uint32 * 3),
+        ("nsub", C.c_uint32 * 3),
+        ("n_blocks", C.c_uint64),
+        ("coef", _dp),
+    ]
+
+
+class GaussResultC(C.Structure):
+    _fields_ = [
+        ("status", C.c_int32),
+        ("cause", C.c_int32),
+        ("stage", C.c_int32),
+        ("kind", C.c_int32),
+        ("attempts", C.c_uint32),
+        ("best_triplet", C.c_uint32),
+        ("best_realization", C.c_uint32),
+        ("n_triplets", C.c_uint32),
+        ("epoch", C.c_double),
+        ("elem", C.c_double * 6),
+        ("rms", C.c_double),
+    ]
+
+
+assert C.sizeof(GaussResultC) == 96
+assert C.sizeof(IODParamsC) == 176
+
+# numpy view of outfit_gauss_result_t (same 96-byte layout)
+RESULT_DTYPE = [
+    ("status", "<i4"), ("cause", "<i4"), ("stage", "<i4"), ("kind", "<i4"),
+    ("attempts", "<u4"), ("best_triplet", "<u4"), ("best_realization", "<u4"),
+    ("n_triplets", "<u4"), ("epoch", "<f8"), ("elem", "<f8", (6,)), ("rms", "<f8"),
+]
