@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""bench.py — objects/s through the full Gauss IOD path on N MI355X (one process per GPU).
+
+A "step" is one pass of the whole hot path (triplet selection, observer pre-pass,
+Gauss candidates, best-orbit selection) over this rank's batch of synthetic
+objects, inputs already resident in HBM, followed — for N > 1 — by the path's only
+exchange step, an RCCL all_gather of the 96-byte result records.
+
+    python bench.py                      # N = 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (see the contract in DESIGN.md §Measurement).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+BYTES_PER_OBS_IN = 64          # t, ra, dec, sigma_ra, sigma_dec, obs_helio_equ[3]   
+BYTES_PER_OBS_GEO = 24         # obs_geo_ecl[3] when the Earth is evaluated on device
+BYTES_PER_RESULT = 96          # outfit_gauss_result_t
+
+
+def cpu_baseline(batch, ephem, params, n_obj_max, budget_s=15.0):
+    """The CPU oracle (a restatement of the reference's Rayon path: one task per trajectory,
+    dynamic scheduling) timed on the host cores, on a bounded prefix of the same workload."""
+    import oracle_lib as O
+    cores = os.cpu_count() or 1
+    n0 = min(n_obj_max, 64 * cores)
+    sub = batch.slice(0, n0)
+    t = time.perf_counter()
+    rc, _ = O.fit_full_iod(params.as_c(), sub.as_c(), ephem.as_c(), n_threads=cores, hoist=0)
+    dt0 = time.perf_counter() - t
+    assert rc == 0
+    n1 = int(min(n_obj_max, max(n0, n0 * budget_s / max(dt0, 1e-3))))
+    sub = batch.slice(0, n1)
+    t = time.perf_counter()
+    rc, _ = O.fit_full_iod(params.as_c(), sub.as_c(), ephem.as_c(), n_threads=cores, hoist=0)
+    dt1 = time.perf_counter() - t
+    assert rc == 0
+    return {"value": n1 / dt1, "unit": "objects/s", "cores": cores, "kind": "port",
+            "sample": f"first {n1} objects of the same synthetic batch, {dt1:.1f} s, Earth re-interpolated "
+                      "per (candidate, observation) as the reference does"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--objects", type=int, default=100000, help="objects per GPU (weak scaling)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import outfit_amd
+    from outfit_amd import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    # ---- this rank's shard of the synthetic dataset (weak scaling: fixed objects per GPU) ----
+    n_obj = args.objects
+    ephem_d = synth.make_ephemeris()
+    ds = synth.make_dataset(n_obj, seed=synth.DEFAULT_SEED + rank, ephem=ephem_d)
+    batch = outfit_amd.ObsBatch.from_dict(ds)
+    ephem = outfit_amd.Ephemeris.from_dict(ephem_d)
+    params = synth.bench_params(outfit_amd.IODParams())
+    n_obs = int(batch.traj_offset[-1])
+
+    session = outfit_amd.IODSession(batch, ephem, params, device=local_rank)
+    out_local = torch.empty((n_obj, BYTES_PER_RESULT), dtype=torch.uint8, device="cuda")
+    out_all = torch.empty((world * n_obj, BYTES_PER_RESULT), dtype=torch.uint8, device="cuda") if world > 1 else None
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        session.run(stream=stream, d_out=out_local.data_ptr())
+        if world > 1:
+            dist.all_gather_into_tensor(out_all, out_local)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    session.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ktimes = session.kernel_times()      # HIP events on the run's stream, summed over the LAST step
+    session.set_profiling(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity: the timed work produced orbits
+    res = np.frombuffer(out_local.cpu().numpy().tobytes(), dtype=outfit_amd._abi.RESULT_DTYPE)
+    n_ok = int((res["status"] == 0).sum())
+
+    if rank == 0:
+        total_objects = world * n_obj
+        value = total_objects * args.steps / elapsed
+        # dominant kernel and its roofline (algorithmic bytes, SURVEY §8d / DESIGN.md)
+        dom = max(ktimes, key=ktimes.get) if ktimes else None
+        n_chunks = max(1, -(-n_obj // 131072))
+        launches = n_chunks
+        bytes_per_obj = (n_obs / n_obj) * (BYTES_PER_OBS_IN + BYTES_PER_OBS_GEO) + BYTES_PER_RESULT
+        roof = None
+        if dom:
+            avg_ms = ktimes[dom] / launches
+            units = n_obj / launches
+            achieved = units * bytes_per_obj / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "avg_launch_ms": avg_ms, "units_per_launch": units, "algorithmic_bytes_per_object": bytes_per_obj,
+                    "all_kernels_ms_last_step": ktimes}
+        line = {
+            "metric": "objects/s full Gauss IOD (20 obs, 100 triplets/obj)",
+            "value": value, "unit": "objects/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{n_obj} synthetic objects per GPU x 20 obs, 100 triplets each "
+                                   "(BASELINE configs[2] shape; synthetic DE440-layout table resident in HBM)",
+                       "objects_per_gpu": n_obj, "obs_per_object": n_obs / n_obj, "triplets_per_object": 100,
+                       "n_noise_realizations": 0, "orbits_found_rank0": n_ok,
+                       "parallelism": f"objects sharded over {world} GPU(s); RCCL all_gather of 96-B results"},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(batch, ephem, params, n_obj)
+        print(json.dumps(line), flush=True)
+    session.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

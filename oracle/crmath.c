@@ -1,0 +1,199 @@
+/*
+ * crmath.c — correctly-rounded sin / cos / acos for the oracle.
+ *
+ * The reference calls f64::sin/cos/acos, i.e. the platform libm (glibc on the
+ * machines its KATs were recorded on), whose results are correctly rounded for
+ * all but ~0.1 % of arguments. The Gauss correction loop is chaotically
+ * sensitive to a 1-ulp change of the direction cosines or of the Kepler start
+ * value, so a libm-dependent oracle could not be compared
+ * bit for bit with a GPU that has a different libm (ROCm ocml). The oracle
+ * therefore restates these three functions as CORRECTLY ROUNDED — the value an
+ * ideal libm returns — using double-double arithmetic; the device code does
+ * the same (outfit_amd/csrc/device/crmath.hpp, written independently against
+ * the same constants from tools/gen_crmath_constants.py). The reference's
+ * bit-exact KATs still pass with them (tests/test_oracle_kats.py).
+ * TEST INFRASTRUCTURE ONLY (see oracle.h).
+ */
+#include <math.h>
+#include "oracle.h"
+
+int orc_use_libm = 0; /* 1 = plain libm sin/cos/acos (platform-dependent), 0 = correctly rounded */
+
+#define CRM_PIO2_P1 1.5707963267341256     /* 0x1.921fb54400000p+0  */
+#define CRM_PIO2_P2 6.077100506303966e-11  /* 0x1.0b4611a600000p-34 */
+#define CRM_PIO2_P3 2.0222662487111665e-21 /* 0x1.3198a2e000000p-69 */
+#define CRM_PIO2_P4 8.4784276603689e-32    /* 0x1.b839a252049c1p-104 */
+#define CRM_TWO_OVER_PI 0.6366197723675814
+#define CRM_PI_HI 3.141592653589793
+
+static const double CRM_INV_FACT[32][2] = {
+  {1.0, 0.0},
+  {1.0, 0.0},
+  {0.5, 0.0},
+  {0.16666666666666666, 9.25185853854297e-18},
+  {0.041666666666666664, 2.3129646346357427e-18},
+  {0.008333333333333333, 1.1564823173178714e-19},
+  {0.001388888888888889, -5.300543954373577e-20},
+  {0.0001984126984126984, 1.7209558293420705e-22},
+  {2.48015873015873e-05, 2.1511947866775882e-23},
+  {2.7557319223985893e-06, -1.858393274046472e-22},
+  {2.755731922398589e-07, 2.3767714622250297e-23},
+  {2.505210838544172e-08, -1.448814070935912e-24},
+  {2.08767569878681e-09, -1.20734505911326e-25},
+  {1.6059043836821613e-10, 1.2585294588752098e-26},
+  {1.1470745597729725e-11, 2.0655512752830745e-28},
+  {7.647163731819816e-13, 7.03872877733453e-30},
+  {4.779477332387385e-14, 4.399205485834081e-31},
+  {2.8114572543455206e-15, 1.6508842730861433e-31},
+  {1.5619206968586225e-16, 1.1910679660273754e-32},
+  {8.22063524662433e-18, 2.2141894119604265e-34},
+  {4.110317623312165e-19, 1.4412973378659527e-36},
+  {1.9572941063391263e-20, -1.3643503830087908e-36},
+  {8.896791392450574e-22, -7.911402614872376e-38},
+  {3.868170170630684e-23, -8.843177655482344e-40},
+  {1.6117375710961184e-24, -3.6846573564509766e-41},
+  {6.446950284384474e-26, -1.9330404233703465e-42},
+  {2.4795962632247976e-27, -1.2953730964765229e-43},
+  {9.183689863795546e-29, 1.4303150396787322e-45},
+  {3.279889237069838e-30, 1.5117542744029879e-46},
+  {1.1309962886447716e-31, 1.0498015412959506e-47},
+  {3.7699876288159054e-33, 2.5870347832750324e-49},
+  {1.216125041553518e-34, 5.586290567888806e-51},
+};
+
+/* theta_k = fma(2pi/8, k, (pi/2)/8): (cos, sin), correctly rounded */
+const double orc_aberth_cos_sin[8][2] = {
+  {0.9807852804032304, 0.19509032201612825},
+  {0.5555702330196023, 0.8314696123025452},
+  {-0.1950903220161282, 0.9807852804032304},
+  {-0.8314696123025453, 0.5555702330196022},
+  {-0.9807852804032304, -0.19509032201612836},
+  {-0.5555702330196022, -0.8314696123025452},
+  {0.1950903220161283, -0.9807852804032304},
+  {0.8314696123025452, -0.5555702330196022},
+};
+
+typedef struct { double hi, lo; } dd;
+
+static inline dd two_sum(double a, double b) {
+  double s = a + b, bb = s - a;
+  return (dd){s, (a - (s - bb)) + (b - bb)};
+}
+static inline dd fast_two_sum(double a, double b) { /* |a| >= |b| */
+  double s = a + b;
+  return (dd){s, b - (s - a)};
+}
+static inline dd two_prod(double a, double b) {
+  double p = a * b;
+  return (dd){p, fma(a, b, -p)};
+}
+static inline dd dd_add(dd a, dd b) {
+  dd s = two_sum(a.hi, b.hi), t = two_sum(a.lo, b.lo);
+  s.lo += t.hi;
+  s = fast_two_sum(s.hi, s.lo);
+  s.lo += t.lo;
+  return fast_two_sum(s.hi, s.lo);
+}
+static inline dd dd_add_d(dd a, double b) {
+  dd s = two_sum(a.hi, b);
+  s.lo += a.lo;
+  return fast_two_sum(s.hi, s.lo);
+}
+static inline dd dd_mul(dd a, dd b) {
+  dd p = two_prod(a.hi, b.hi);
+  p.lo += a.hi * b.lo + a.lo * b.hi;
+  return fast_two_sum(p.hi, p.lo);
+}
+static inline dd dd_neg(dd a) { return (dd){-a.hi, -a.lo}; }
+static inline dd dd_div(dd a, dd b) {
+  double q1 = a.hi / b.hi;
+  dd r = dd_add(a, dd_neg(dd_mul(b, (dd){q1, 0.0})));
+  double q2 = r.hi / b.hi;
+  r = dd_add(r, dd_neg(dd_mul(b, (dd){q2, 0.0})));
+  double q3 = r.hi / b.hi;
+  dd q = fast_two_sum(q1, q2);
+  return dd_add_d(q, q3);
+}
+
+/* r = x - k*pi/2 as a double-double, |r| <= pi/4 (+ tiny); valid for |x| < 2^20 */
+static dd reduce_pio2(double x, int *quadrant) {
+  double k = nearbyint(x * CRM_TWO_OVER_PI);
+  *quadrant = (int)((long long)k & 3);
+  if (k == 0.0) return (dd){x, 0.0};
+  double t = x - k * CRM_PIO2_P1;          /* exact: k*P1 is exact (33+20 bits) and cancels */
+  dd a = two_sum(t, -(k * CRM_PIO2_P2));   /* k*P2 exact */
+  dd b = two_sum(a.hi, -(k * CRM_PIO2_P3)); /* k*P3 exact */
+  double lo = (a.lo + b.lo) - k * CRM_PIO2_P4;
+  return two_sum(b.hi, lo);
+}
+
+/* sin and cos of a reduced double-double argument, |r| <= pi/4: Taylor series, the
+ * tail (terms below 2^-53 of the sum) in double, the head in double-double */
+static void sincos_kernel(dd r, dd *s, dd *c) {
+  dd z = dd_mul(r, r);
+  double zh = z.hi;
+  /* sin: r * sum_{j=0}^{14} (-1)^j z^j / (2j+1)! */
+  double ts = 0.0;
+  for (int j = 14; j >= 8; --j) {
+    double cj = CRM_INV_FACT[2 * j + 1][0];
+    ts = ts * zh + ((j & 1) ? -cj : cj);
+  }
+  dd p = {ts, 0.0};
+  for (int j = 7; j >= 0; --j) {
+    dd cj = {CRM_INV_FACT[2 * j + 1][0], CRM_INV_FACT[2 * j + 1][1]};
+    if (j & 1) cj = dd_neg(cj);
+    p = dd_add(dd_mul(p, z), cj);
+  }
+  *s = dd_mul(r, p);
+  /* cos: sum_{j=0}^{15} (-1)^j z^j / (2j)! */
+  double tc = 0.0;
+  for (int j = 15; j >= 9; --j) {
+    double cj = CRM_INV_FACT[2 * j][0];
+    tc = tc * zh + ((j & 1) ? -cj : cj);
+  }
+  dd q = {tc, 0.0};
+  for (int j = 8; j >= 0; --j) {
+    dd cj = {CRM_INV_FACT[2 * j][0], CRM_INV_FACT[2 * j][1]};
+    if (j & 1) cj = dd_neg(cj);
+    q = dd_add(dd_mul(q, z), cj);
+  }
+  *c = q;
+}
+
+static void sincos_dd(double x, dd *s, dd *c) {
+  int q;
+  dd r = reduce_pio2(x, &q);
+  dd sr, cr;
+  sincos_kernel(r, &sr, &cr);
+  switch (q) {
+    case 0: *s = sr; *c = cr; break;
+    case 1: *s = cr; *c = dd_neg(sr); break;
+    case 2: *s = dd_neg(sr); *c = dd_neg(cr); break;
+    default: *s = dd_neg(cr); *c = sr; break;
+  }
+}
+
+void orc_sincos(double x, double *s, double *c) {
+  if (orc_use_libm || !(fabs(x) < 1048576.0)) { *s = sin(x); *c = cos(x); return; }
+  if (x == 0.0) { *s = x; *c = 1.0; return; }
+  dd sd, cd;
+  sincos_dd(x, &sd, &cd);
+  *s = sd.hi;
+  *c = cd.hi;
+}
+double orc_sin(double x) { double s, c; orc_sincos(x, &s, &c); return s; }
+double orc_cos(double x) { double s, c; orc_sincos(x, &s, &c); return c; }
+
+/* acos by one Newton step in double-double from the libm seed: y1 = y0 + (cos y0 - x)/sin y0 */
+double orc_acos(double x) {
+  if (orc_use_libm || !(fabs(x) <= 1.0)) return acos(x);
+  if (x == 1.0) return 0.0;
+  if (x == -1.0) return CRM_PI_HI;
+  double y0 = acos(x);
+  dd sd, cd;
+  sincos_dd(y0, &sd, &cd);
+  dd num = dd_add_d(cd, -x);
+  dd q = dd_div(num, sd);
+  dd y1 = dd_add_d(q, y0);
+  return y1.hi;
+}

@@ -57,10 +57,12 @@ int orc_gauss_prelim_fn(const orc_gauss_obs *g, orc_gauss_prelim *o) {
   o->b[1] = 0.0;
   o->b[2] = o->a[2] * (tau13 * tau13 - tau1 * tau1) / 6.0;
   for (int c = 0; c < 3; ++c) {
-    double cd = cos(g->dec[c]);
-    o->S[0][c] = cos(g->ra[c]) * cd;
-    o->S[1][c] = sin(g->ra[c]) * cd;
-    o->S[2][c] = sin(g->dec[c]);
+    double sr, cr, sd, cd;
+    orc_sincos(g->ra[c], &sr, &cr);
+    orc_sincos(g->dec[c], &sd, &cd);
+    o->S[0][c] = cr * cd;
+    o->S[1][c] = sr * cd;
+    o->S[2][c] = sd;
   }
   return inv3(o->S, o->Sinv) ? 0 : 1;
 }

@@ -92,7 +92,7 @@ void orc_s_funct(double psi, double alpha, double s[4]) {
 static double initial_ecc_anomaly(double r0, double a0, double e0, double sig0) {
   double c = (1.0 - r0 / a0) / e0;
   double u;
-  if (fabs(c) <= 1.0) u = acos(c);
+  if (fabs(c) <= 1.0) u = orc_acos(c);
   else if (c >= 1.0) u = 0.0;
   else u = ORC_PI;
   if (sig0 < 0.0) u = -u;
@@ -106,12 +106,14 @@ double orc_prelim_elliptic(const orc_kepler_params *p) {
   double n = sqrt(p->mu) * sqrt(-powi3(p->alpha));
   if (p->e0 < contr) return n * p->dt / sqrt(-p->alpha);
   double u0 = initial_ecc_anomaly(p->r0, a0, p->e0, p->sig0);
-  double m0 = orc_principal_angle(u0 - p->e0 * sin(u0));
+  double m0 = orc_principal_angle(u0 - p->e0 * orc_sin(u0));
   double m = m0 + n * p->dt;
   double u = m;
   for (int i = 0; i < p->max_iter_prelim_kepuni; ++i) {
-    double res = u - p->e0 * sin(u) - m;
-    double der = 1.0 - p->e0 * cos(u);
+    double su, cu;
+    orc_sincos(u, &su, &cu);
+    double res = u - p->e0 * su - m;
+    double der = 1.0 - p->e0 * cu;
     double step = -res / der;
     u += step;
     if (fabs(step) < contr * 1e3) break;

@@ -42,6 +42,14 @@ extern "C" {
 #define ORC_VLIGHT 2.99792458e5       /* constants.rs:76 */
 #define ORC_SECONDS_PER_DAY 86400.0   /* constants.rs:34 */
 
+/* ---- crmath.c: correctly-rounded sin/cos/acos (see the header of that file) ---- */
+extern int orc_use_libm; /* 1 = platform libm instead (results then depend on the libm) */
+extern const double orc_aberth_cos_sin[8][2];
+void   orc_sincos(double x, double *s, double *c);
+double orc_sin(double x);
+double orc_cos(double x);
+double orc_acos(double x);
+
 /* ---- kepler/ --------------------------------------------------------------- */
 typedef struct {
   double dt, r0, sig0, mu, alpha, e0;

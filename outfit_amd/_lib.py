@@ -1,0 +1,83 @@
+"""Loader of the native library ``outfit_amd/csrc/_build/liboutfit_hip.so``.
+
+The product path has no CPU fallback: if the HIP library is missing (or cannot
+be loaded) every operation fails loudly with the build instruction.
+"""
+import ctypes as C
+import os
+import subprocess
+
+from ._abi import ABI_VERSION, EphemC, GaussResultC, IODParamsC, ObsBatchC
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "_build", "liboutfit_hip.so")
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def build_native(verbose=False):
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded C ABI; raises NativeLibraryError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} is missing: build it with `make -C {CSRC}` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. libamdhip64 not found
+        raise NativeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    vp = C.c_void_p
+    L.outfit_hip_abi_version.restype = C.c_int
+    if L.outfit_hip_abi_version() != ABI_VERSION:
+        raise NativeLibraryError("liboutfit_hip.so ABI version mismatch: rebuild it")
+    L.outfit_hip_last_error.restype = C.c_char_p
+    L.outfit_hip_device_count.restype = C.c_int
+    L.outfit_hip_iod_params_default.argtypes = [C.POINTER(IODParamsC)]
+    L.outfit_hip_iod_params_default.restype = None
+    L.outfit_hip_iod_params_validate.argtypes = [C.POINTER(IODParamsC)]
+    L.outfit_hip_fit_full_iod.argtypes = [C.POINTER(IODParamsC), C.POINTER(ObsBatchC), C.POINTER(EphemC),
+                                          C.c_int, C.POINTER(GaussResultC)]
+    L.outfit_hip_session_create.argtypes = [C.POINTER(IODParamsC), C.POINTER(ObsBatchC), C.POINTER(EphemC),
+                                            C.c_int, C.POINTER(vp)]
+    L.outfit_hip_session_run.argtypes = [vp, vp, vp]
+    L.outfit_hip_session_results.argtypes = [vp, C.POINTER(GaussResultC)]
+    L.outfit_hip_session_device_results.argtypes = [vp]
+    L.outfit_hip_session_device_results.restype = vp
+    L.outfit_hip_session_kernel_times.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float)]
+    L.outfit_hip_session_set_profiling.argtypes = [vp, C.c_int]
+    L.outfit_hip_session_destroy.argtypes = [vp]
+    L.outfit_hip_session_destroy.restype = None
+    L.outfit_hip_propagate_universal.argtypes = [
+        C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double,
+        C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = [
+    "outfit_hip_iod_params_default", "outfit_hip_iod_params_validate", "outfit_hip_fit_full_iod",
+    "outfit_hip_session_create", "outfit_hip_session_run", "outfit_hip_session_results",
+    "outfit_hip_session_device_results", "outfit_hip_session_kernel_times",
+    "outfit_hip_session_set_profiling", "outfit_hip_session_destroy", "outfit_hip_propagate_universal",
+    "outfit_hip_last_error", "outfit_hip_abi_version", "outfit_hip_device_count",
+]
+
+
+def last_error():
+    return lib().outfit_hip_last_error().decode()

@@ -1,0 +1,375 @@
+"""Host-side mirror of the reference's `FitIOD` surface, on top of the C ABI.
+
+The names follow the reference so that tests read like its own:
+``IODParams`` / ``IODParams.builder()`` (src/initial_orbit_determination/mod.rs:225-630),
+``fit_full_iod`` (obs_dataset_api.rs:145-207), ``GaussResult`` (gauss_result.rs:99-102),
+``FitOrbitResult.IODGauss`` / ``FullOrbitResult`` (constants.rs:134-195) and the
+``OutfitError`` variants the path can return (outfit_errors.rs:195-250).
+
+What stays on the caller's side of the boundary (as in the reference, where it is
+`prepare_iod`, obs_dataset_api.rs:254-275): the astrometric error model and the
+observer-position cache; their outputs are the columns of :class:`ObsBatch`.
+All computation happens in liboutfit_hip.so on the GPU; there is no CPU fallback.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _abi
+from ._abi import EphemC, GaussResultC, IODParamsC, ObsBatchC, RESULT_DTYPE
+from ._lib import NativeLibraryError, last_error, lib
+
+_dp = C.POINTER(C.c_double)
+
+
+# ----------------------------------------------------------------------------- errors
+class OutfitError(Exception):
+    """Base of the error variants of outfit_errors.rs that this path can produce."""
+
+
+class InvalidIODParameter(OutfitError):
+    pass
+
+
+class InvalidBatch(OutfitError):
+    pass
+
+
+class EphemerisRange(OutfitError):
+    """The reference panics here (horizon_data.rs:722-724); the ABI reports it."""
+
+
+class HipRuntimeError(OutfitError):
+    pass
+
+
+@dataclass
+class NoFeasibleTriplets(OutfitError):
+    span: float
+    n_obs: int
+    dt_min: float
+    dt_max: float
+
+
+@dataclass
+class NoViableOrbit(OutfitError):
+    cause: str
+    attempts: int
+
+
+class InvalidConversion(OutfitError):
+    pass
+
+
+class InvalidOrbit(OutfitError):
+    pass
+
+
+_CAUSES = {
+    _abi.CAUSE_GAUSS_NO_ROOTS_FOUND: "GaussNoRootsFound",
+    _abi.CAUSE_SINGULAR_DIRECTION_MATRIX: "SingularDirectionMatrix",
+    _abi.CAUSE_POLYNOMIAL_ROOT_FINDING_FAILED: "PolynomialRootFindingFailed",
+    _abi.CAUSE_NON_FINITE_SCORE: "NonFiniteScore",
+}
+
+
+def _raise_rc(rc):
+    msg = last_error()
+    if rc == _abi.OUTFIT_ERR_INVALID_PARAM:
+        raise InvalidIODParameter(msg)
+    if rc == _abi.OUTFIT_ERR_INVALID_BATCH:
+        raise InvalidBatch(msg)
+    if rc == _abi.OUTFIT_ERR_EPHEM_RANGE:
+        raise EphemerisRange(msg)
+    if rc == _abi.OUTFIT_ERR_NO_DEVICE:
+        raise NativeLibraryError(msg)
+    raise HipRuntimeError(f"rc={rc}: {msg}")
+
+
+# ----------------------------------------------------------------------------- params
+_PARAM_FIELDS = [n for n, _ in IODParamsC._fields_ if not n.startswith("_")]
+
+
+class IODParams:
+    """`IODParams` (mod.rs:225-266). Defaults = `IODParams::default()` (mod.rs:308-344)."""
+
+    def __init__(self, **kw):
+        c = IODParamsC()
+        lib().outfit_hip_iod_params_default(C.byref(c))
+        for n in _PARAM_FIELDS:
+            setattr(self, n, getattr(c, n))
+        for k, v in kw.items():
+            if k not in _PARAM_FIELDS:
+                raise TypeError(f"unknown IODParams field {k!r}")
+            setattr(self, k, v)
+
+    @staticmethod
+    def builder():
+        return IODParamsBuilder()
+
+    def as_c(self):
+        c = IODParamsC()
+        for n in _PARAM_FIELDS:
+            setattr(c, n, getattr(self, n))
+        return c
+
+    def __repr__(self):
+        return "IODParams(" + ", ".join(f"{n}={getattr(self, n)!r}" for n in _PARAM_FIELDS) + ")"
+
+
+class IODParamsBuilder:
+    """`IODParamsBuilder` (mod.rs:348-630): fluent setters + validated `build()`."""
+
+    def __init__(self):
+        self._p = IODParams()
+
+    def __getattr__(self, name):
+        if name in _PARAM_FIELDS:
+            def setter(v):
+                setattr(self._p, name, v)
+                return self
+            return setter
+        raise AttributeError(name)
+
+    def build(self):
+        c = self._p.as_c()
+        rc = lib().outfit_hip_iod_params_validate(C.byref(c))
+        if rc != 0:
+            raise InvalidIODParameter(last_error())
+        return self._p
+
+
+# ----------------------------------------------------------------------------- inputs
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Ephemeris:
+    """Legacy-DE Chebyshev subset (EMB, Moon, Sun) = `outfit_ephem_t`."""
+
+    def __init__(self, jd_start, jd_end, block_days, emrat, ncoef, nsub, n_blocks, coef):
+        self.jd_start, self.jd_end, self.block_days, self.emrat = jd_start, jd_end, block_days, emrat
+        self.ncoef, self.nsub, self.n_blocks = tuple(ncoef), tuple(nsub), int(n_blocks)
+        self.coef = _f64(coef)
+
+    @classmethod
+    def from_dict(cls, d):
+        return cls(d["jd_start"], d["jd_end"], d["block_days"], d["emrat"], d["ncoef"], d["nsub"],
+                   d["n_blocks"], d["coef"])
+
+    def as_c(self):
+        e = EphemC()
+        e.jd_start, e.jd_end, e.block_days, e.emrat = self.jd_start, self.jd_end, self.block_days, self.emrat
+        for i in range(3):
+            e.ncoef[i] = self.ncoef[i]
+            e.nsub[i] = self.nsub[i]
+        e.n_blocks = self.n_blocks
+        e.coef = self.coef.ctypes.data_as(_dp)
+        return e
+
+
+class ObsBatch:
+    """All trajectories of a prepared dataset = `outfit_obs_batch_t` (SoA, time-sorted per trajectory).
+
+    `traj_ids` are the caller's trajectory identifiers (the keys of `FullOrbitResult`)."""
+
+    def __init__(self, traj_offset, mjd_tt, ra, dec, sigma_ra, sigma_dec, obs_helio_equ,
+                 obs_geo_ecl=None, noise_z=None, traj_ids=None):
+        self.traj_offset = np.ascontiguousarray(traj_offset, dtype=np.uint64)
+        self.mjd_tt, self.ra, self.dec = _f64(mjd_tt), _f64(ra), _f64(dec)
+        self.sigma_ra, self.sigma_dec = _f64(sigma_ra), _f64(sigma_dec)
+        self.obs_helio_equ = _f64(obs_helio_equ)
+        self.obs_geo_ecl = None if obs_geo_ecl is None else _f64(obs_geo_ecl)
+        self.noise_z = None if noise_z is None else _f64(noise_z)
+        self.n_traj = len(self.traj_offset) - 1
+        self.traj_ids = list(range(self.n_traj)) if traj_ids is None else list(traj_ids)
+
+    @classmethod
+    def from_dict(cls, d, with_geo=True):
+        return cls(d["traj_offset"], d["mjd_tt"], d["ra"], d["dec"], d["sigma_ra"], d["sigma_dec"],
+                   d["obs_helio_equ"], d.get("obs_geo_ecl") if with_geo else None, d.get("noise_z"))
+
+    def slice(self, t0, t1):
+        """Trajectories [t0, t1) as an independent batch (used to shard over ranks)."""
+        o0, o1 = int(self.traj_offset[t0]), int(self.traj_offset[t1])
+        geo = None if self.obs_geo_ecl is None else self.obs_geo_ecl[3 * o0:3 * o1]
+        return ObsBatch(self.traj_offset[t0:t1 + 1] - np.uint64(o0), self.mjd_tt[o0:o1], self.ra[o0:o1],
+                        self.dec[o0:o1], self.sigma_ra[o0:o1], self.sigma_dec[o0:o1],
+                        self.obs_helio_equ[3 * o0:3 * o1], geo, None, self.traj_ids[t0:t1])
+
+    def as_c(self):
+        b = ObsBatchC()
+        b.n_traj = self.n_traj
+        b.traj_offset = self.traj_offset.ctypes.data_as(C.POINTER(C.c_uint64))
+        for k in ("mjd_tt", "ra", "dec", "sigma_ra", "sigma_dec", "obs_helio_equ"):
+            setattr(b, k, getattr(self, k).ctypes.data_as(_dp))
+        if self.obs_geo_ecl is not None:
+            b.obs_geo_ecl = self.obs_geo_ecl.ctypes.data_as(_dp)
+        if self.noise_z is not None:
+            b.noise_z = self.noise_z.ctypes.data_as(_dp)
+        return b
+
+
+# ----------------------------------------------------------------------------- results
+@dataclass
+class OrbitalElements:
+    """`OrbitalElements::{Keplerian, Cometary}` (orbit_type/mod.rs:221-237)."""
+    kind: str            # "Keplerian" (a,e,i,Omega,omega,M) | "Cometary" (q,e,i,Omega,omega,nu)
+    reference_epoch: float
+    elements: tuple
+
+
+@dataclass
+class GaussResult:
+    """`GaussResult::{PrelimOrbit, CorrectedOrbit}` (gauss_result.rs:99-102)."""
+    stage: str           # "PrelimOrbit" | "CorrectedOrbit"
+    orbit: OrbitalElements
+
+    def get_orbit(self):
+        return self.orbit
+
+
+@dataclass
+class IODGauss:
+    """`FitOrbitResult::IODGauss((GaussResult, IODRMS))` (constants.rs:134-137)."""
+    gauss_result: GaussResult
+    rms: float
+    best_triplet: int = 0
+    best_realization: int = 0
+    n_triplets: int = 0
+    attempts: int = 0
+
+    def orbital_elements(self):
+        return self.gauss_result.orbit
+
+    def orbit_quality(self):
+        return self.rms
+
+
+def record_to_result(rec, batch=None, traj_index=None, params=None):
+    """One `outfit_gauss_result_t` -> FitOrbitResult or an OutfitError instance (not raised)."""
+    st = int(rec["status"])
+    if st == _abi.TRAJ_OK:
+        kind = "Keplerian" if int(rec["kind"]) == _abi.KIND_KEPLERIAN else "Cometary"
+        stage = "CorrectedOrbit" if int(rec["stage"]) == _abi.STAGE_CORRECTED else "PrelimOrbit"
+        orb = OrbitalElements(kind, float(rec["epoch"]), tuple(float(x) for x in rec["elem"]))
+        return IODGauss(GaussResult(stage, orb), float(rec["rms"]), int(rec["best_triplet"]),
+                        int(rec["best_realization"]), int(rec["n_triplets"]), int(rec["attempts"]))
+    if st == _abi.TRAJ_NO_FEASIBLE_TRIPLETS:
+        span, n_obs = 0.0, 0
+        if batch is not None and traj_index is not None:
+            o0, o1 = int(batch.traj_offset[traj_index]), int(batch.traj_offset[traj_index + 1])
+            n_obs = o1 - o0
+            span = float(batch.mjd_tt[o1 - 1] - batch.mjd_tt[o0]) if n_obs else 0.0
+        return NoFeasibleTriplets(span, n_obs, params.dt_min if params else float("nan"),
+                                  params.dt_max_triplet if params else float("nan"))
+    if st == _abi.TRAJ_NO_VIABLE_ORBIT:
+        return NoViableOrbit(_CAUSES.get(int(rec["cause"]), "Unknown"), int(rec["attempts"]))
+    if st == _abi.TRAJ_INVALID_CONVERSION:
+        return InvalidConversion("Parabolic orbit cannot be represented with finite a")
+    if st == _abi.TRAJ_INVALID_ORBIT:
+        return InvalidOrbit("eccentricity must be > 1 for hyperbolic orbits")
+    return OutfitError(f"unknown status {st}")
+
+
+# ----------------------------------------------------------------------------- entry points
+def fit_full_iod_records(batch, ephem, params, n_devices=0):
+    """The blocking C-ABI call; returns the raw records (numpy structured array)."""
+    L = lib()
+    pc, bc = params.as_c(), batch.as_c()
+    ec = ephem.as_c() if ephem is not None else None
+    out = (GaussResultC * max(batch.n_traj, 1))()
+    rc = L.outfit_hip_fit_full_iod(C.byref(pc), C.byref(bc), C.byref(ec) if ec is not None else None,
+                                   n_devices, out)
+    if rc != 0:
+        _raise_rc(rc)
+    return np.frombuffer(out, dtype=RESULT_DTYPE)[:batch.n_traj].copy()
+
+
+def fit_full_iod(batch, ephem, params, n_devices=0):
+    """`FitIOD::fit_full_iod` after `prepare_iod`: {traj_id: FitOrbitResult | OutfitError}
+    (`FullOrbitResult`, constants.rs:195). Per-trajectory failures are values, not raises."""
+    recs = fit_full_iod_records(batch, ephem, params, n_devices)
+    return {tid: record_to_result(recs[i], batch, i, params) for i, tid in enumerate(batch.traj_ids)}
+
+
+def fit_iod(batch, traj_id, ephem, params):
+    """`FitIOD::fit_iod` for a single trajectory (obs_dataset_api.rs:130-143); raises on error."""
+    i = batch.traj_ids.index(traj_id)
+    sub = batch.slice(i, i + 1)
+    if batch.noise_z is not None:
+        stride = params.max_triplets * params.n_noise_realizations * 6
+        sub.noise_z = batch.noise_z[i * stride:(i + 1) * stride]
+    res = record_to_result(fit_full_iod_records(sub, ephem, params, 1)[0], sub, 0, params)
+    if isinstance(res, OutfitError):
+        raise res
+    return res
+
+
+class IODSession:
+    """Inputs resident in HBM; `run()` enqueues the kernels of the whole path on a stream."""
+
+    def __init__(self, batch, ephem, params, device=0):
+        self._L = lib()
+        self.n_traj = batch.n_traj
+        self._keep = (batch, ephem)
+        pc, bc = params.as_c(), batch.as_c()
+        ec = ephem.as_c() if ephem is not None else None
+        h = C.c_void_p()
+        rc = self._L.outfit_hip_session_create(C.byref(pc), C.byref(bc),
+                                               C.byref(ec) if ec is not None else None, device, C.byref(h))
+        if rc != 0:
+            _raise_rc(rc)
+        self._h = h
+
+    def run(self, stream=None, d_out=None):
+        rc = self._L.outfit_hip_session_run(self._h, C.c_void_p(stream or 0), C.c_void_p(d_out or 0))
+        if rc != 0:
+            _raise_rc(rc)
+
+    def results(self):
+        out = (GaussResultC * max(self.n_traj, 1))()
+        rc = self._L.outfit_hip_session_results(self._h, out)
+        if rc != 0:
+            _raise_rc(rc)
+        return np.frombuffer(out, dtype=RESULT_DTYPE)[:self.n_traj].copy()
+
+    def set_profiling(self, on):
+        self._L.outfit_hip_session_set_profiling(self._h, 1 if on else 0)
+
+    def kernel_times(self):
+        names = (C.c_char_p * 8)()
+        ms = (C.c_float * 8)()
+        n = self._L.outfit_hip_session_kernel_times(self._h, 8, names, ms)
+        if n < 0:
+            _raise_rc(n)
+        return {names[i].decode(): float(ms[i]) for i in range(n)}
+
+    def close(self):
+        if self._h:
+            self._L.outfit_hip_session_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def propagate_universal(r, v, t0, t1, convergency=100 * 2.220446049250313e-16):
+    """Batched `kepler::propagate_universal` (kepler/propagation.rs:114-174), NewtonRaphson solver.
+    Returns (out[n,11] = r1,v1,f,g,fdot,gdot,psi ; status[n])."""
+    r, v = _f64(r).reshape(-1, 3), _f64(v).reshape(-1, 3)
+    n = r.shape[0]
+    rv = np.ascontiguousarray(np.concatenate([r, v], axis=1))
+    t0a, t1a = _f64(np.broadcast_to(t0, (n,))), _f64(np.broadcast_to(t1, (n,)))
+    out = np.empty((n, 11))
+    st = np.empty(n, dtype=np.int32)
+    rc = lib().outfit_hip_propagate_universal(n, rv.ctypes.data_as(_dp), t0a.ctypes.data_as(_dp),
+                                              t1a.ctypes.data_as(_dp), convergency, out.ctypes.data_as(_dp),
+                                              st.ctypes.data_as(C.POINTER(C.c_int32)))
+    if rc != 0:
+        _raise_rc(rc)
+    return out, st

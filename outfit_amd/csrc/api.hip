@@ -1,0 +1,523 @@
+// api.hip — host side of the C ABI declared in include/outfit_hip.h.
+//
+// Mirrors what the reference does per call of FitIOD::fit_full_iod after
+// prepare_iod (src/initial_orbit_determination/obs_dataset_api.rs:145-207):
+// every trajectory is an independent task (process_traj :277-296); here the
+// tasks of one device are batched into four kernels per chunk of trajectories.
+// There is no CPU fallback: without a usable HIP device every entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/outfit_hip.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e__ = (expr);                                                                  \
+    if (e__ != hipSuccess)                                                                    \
+      return fail(OUTFIT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));        \
+  } while (0)
+
+// IODParamsBuilder::build (mod.rs:544-624); partial_cmp semantics: NaN invalid, +inf allowed
+const char* validate_params(const outfit_iod_params_t* p) {
+  auto gt0 = [](double x) { return x > 0.0; };
+  auto ge0 = [](double x) { return x >= 0.0; };
+  if (!ge0(p->noise_scale)) return "noise_scale must be non-negative";
+  if (!ge0(p->dt_min) || !ge0(p->dt_max_triplet) || !ge0(p->dtmax)) return "time parameters must be non-negative";
+  if (!ge0(p->max_ecc)) return "max_ecc must be >= 0";
+  if (!ge0(p->root_imag_eps)) return "root_imag_eps must be >= 0";
+  if (!gt0(p->max_perihelion_au)) return "max_perihelion_au must be > 0";
+  if (!gt0(p->min_rho2_au)) return "min_rho2_au must be > 0";
+  if (!gt0(p->aberth_eps)) return "aberth_eps must be > 0";
+  if (!gt0(p->kepler_eps)) return "kepler_eps must be > 0";
+  if (!gt0(p->newton_eps)) return "newton_eps must be > 0";
+  if (p->newton_max_it == 0) return "newton_max_it must be >= 1";
+  if (p->aberth_max_iter == 0) return "aberth_max_iter must be >= 1";
+  if (p->max_tested_solutions < 1) return "max_tested_solutions must be >= 1";
+  if (!(gt0(p->r2_min_au) && gt0(p->r2_max_au) && p->r2_min_au <= p->r2_max_au))
+    return "require 0 < r2_min_au <= r2_max_au";
+  return nullptr;
+}
+
+unsigned saturate_u32(uint64_t v) {
+  return v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)v;
+}
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  hipError_t alloc(size_t count) {
+    n = count;
+    if (count == 0) { p = nullptr; return hipSuccess; }
+    return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+
+enum KernelId { K_TRIPLETS = 0, K_PREPASS = 1, K_CANDIDATE = 2, K_SELECT = 3, K_COUNT = 4 };
+const char* const kKernelNames[K_COUNT] = {"k_triplet_select", "k_observer_prepass", "k_gauss_candidate",
+                                           "k_select_best"};
+
+}  // namespace
+
+struct outfit_hip_session {
+  int device = 0;
+  outfit_iod_params_t params{};
+  uint64_t n_traj = 0, n_obs = 0;
+  bool has_ephem = false, has_geo = false;
+  unsigned n_real = 1, k_cap = 0, cand_per_traj = 0;
+  uint64_t chunk = 0;
+
+  DevBuf<unsigned long long> traj_offset;
+  DevBuf<double> mjd, ra, dec, sra, sdec, helio, geo, obs_pos, noise, coef;
+  DevBuf<double> heap_w, sum, el_epoch, el;
+  DevBuf<unsigned long long> heap_id, triplets;
+  DevBuf<unsigned> n_triplets, flags, n_win;
+  DevBuf<outfit::GaussResultRec> results;
+  DevBuf<int> error_flag;
+  outfit::EphemTable table{};
+  outfit::GaussParams gp{};
+  outfit::TripletParams tp{};
+
+  hipStream_t own_stream = nullptr;
+  hipStream_t last_stream = nullptr;
+  bool profiling = false;
+  struct Timed { int id; hipEvent_t a, b; };
+  std::vector<Timed> timed;
+  float kernel_ms[K_COUNT] = {0, 0, 0, 0};
+  int kernel_launches[K_COUNT] = {0, 0, 0, 0};
+
+  void free_all() {
+    traj_offset.release(); mjd.release(); ra.release(); dec.release(); sra.release(); sdec.release();
+    helio.release(); geo.release(); obs_pos.release(); noise.release(); coef.release();
+    heap_w.release(); sum.release(); el_epoch.release(); el.release(); heap_id.release();
+    triplets.release(); n_triplets.release(); flags.release(); n_win.release(); results.release();
+    error_flag.release();
+    for (auto& t : timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    timed.clear();
+    if (own_stream) (void)hipStreamDestroy(own_stream);
+    own_stream = nullptr;
+  }
+};
+
+namespace {
+
+int check_batch(const outfit_iod_params_t* params, const outfit_obs_batch_t* b, const outfit_ephem_t* eph) {
+  if (!b) return fail(OUTFIT_ERR_INVALID_BATCH, "batch is NULL");
+  if (b->n_traj > 0 && !b->traj_offset) return fail(OUTFIT_ERR_INVALID_BATCH, "traj_offset is NULL");
+  if (b->n_traj == 0) return OUTFIT_OK;
+  const uint64_t o0 = b->traj_offset[0];
+  for (uint64_t t = 0; t < b->n_traj; ++t) {
+    if (b->traj_offset[t + 1] < b->traj_offset[t])
+      return fail(OUTFIT_ERR_INVALID_BATCH, "traj_offset must be non-decreasing");
+    if (b->traj_offset[t + 1] - b->traj_offset[t] >= (1ull << 21))
+      return fail(OUTFIT_ERR_INVALID_BATCH, "a trajectory has 2^21 or more observations");
+  }
+  const uint64_t n_obs = b->traj_offset[b->n_traj] - o0;
+  if (n_obs > 0 && (!b->mjd_tt || !b->ra || !b->dec || !b->sigma_ra || !b->sigma_dec || !b->obs_helio_equ))
+    return fail(OUTFIT_ERR_INVALID_BATCH, "an observation array is NULL");
+  if (params->n_noise_realizations > 0 && !b->noise_z)
+    return fail(OUTFIT_ERR_INVALID_BATCH, "noise_z is required when n_noise_realizations > 0");
+  const uint64_t cpt = (uint64_t)params->max_triplets * (1 + params->n_noise_realizations);
+  if (params->n_noise_realizations >= (1ull << 31) || cpt >= (1ull << 31))
+    return fail(OUTFIT_ERR_INVALID_PARAM, "max_triplets * (1 + n_noise_realizations) must be < 2^31");
+  if (eph) {
+    if (!eph->coef || eph->n_blocks == 0) return fail(OUTFIT_ERR_INVALID_BATCH, "ephemeris table is empty");
+    for (int k = 0; k < 3; ++k)
+      if (eph->ncoef[k] < 2 || eph->ncoef[k] > 32 || eph->nsub[k] < 1)
+        return fail(OUTFIT_ERR_INVALID_BATCH, "ephemeris ncoef must be in [2,32] and nsub >= 1");
+    if (!(eph->block_days > 0.0)) return fail(OUTFIT_ERR_INVALID_BATCH, "ephemeris block_days must be > 0");
+  }
+  return OUTFIT_OK;
+}
+
+template <typename T>
+int upload(DevBuf<T>& d, const T* src, size_t n) {
+  HIP_TRY(d.alloc(n));
+  if (n) HIP_TRY(hipMemcpy(d.p, src, n * sizeof(T), hipMemcpyHostToDevice));
+  return OUTFIT_OK;
+}
+
+#define TRY_RC(expr)              \
+  do {                            \
+    int rc__ = (expr);            \
+    if (rc__ != OUTFIT_OK) return rc__; \
+  } while (0)
+
+int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, const outfit_obs_batch_t* b,
+                  const outfit_ephem_t* eph) {
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+  s->params = *params;
+  s->n_traj = b->n_traj;
+  const uint64_t o0 = b->n_traj ? b->traj_offset[0] : 0;
+  s->n_obs = b->n_traj ? b->traj_offset[b->n_traj] - o0 : 0;
+  s->n_real = (unsigned)(1 + params->n_noise_realizations);
+  s->k_cap = params->max_triplets;
+  s->cand_per_traj = s->k_cap * s->n_real;
+  s->has_ephem = eph != nullptr;
+  s->has_geo = b->obs_geo_ecl != nullptr;
+
+  // rebased offsets
+  std::vector<unsigned long long> off(s->n_traj + 1, 0ull);
+  for (uint64_t t = 0; t <= s->n_traj && s->n_traj; ++t) off[t] = b->traj_offset[t] - o0;
+  TRY_RC(upload(s->traj_offset, off.data(), off.size()));
+  const size_t n = (size_t)s->n_obs;
+  TRY_RC(upload(s->mjd, n ? b->mjd_tt + o0 : nullptr, n));
+  TRY_RC(upload(s->ra, n ? b->ra + o0 : nullptr, n));
+  TRY_RC(upload(s->dec, n ? b->dec + o0 : nullptr, n));
+  TRY_RC(upload(s->sra, n ? b->sigma_ra + o0 : nullptr, n));
+  TRY_RC(upload(s->sdec, n ? b->sigma_dec + o0 : nullptr, n));
+  TRY_RC(upload(s->helio, n ? b->obs_helio_equ + 3 * o0 : nullptr, 3 * n));
+  if (s->has_ephem && s->has_geo) {
+    TRY_RC(upload(s->geo, n ? b->obs_geo_ecl + 3 * o0 : nullptr, 3 * n));
+    HIP_TRY(s->obs_pos.alloc(3 * n));
+    unsigned per_block = 0;
+    for (int k = 0; k < 3; ++k) {
+      s->table.ncoef[k] = eph->ncoef[k];
+      s->table.nsub[k] = eph->nsub[k];
+      s->table.off[k] = per_block;
+      per_block += 3u * eph->ncoef[k] * eph->nsub[k];
+    }
+    s->table.per_block = per_block;
+    s->table.jd_start = eph->jd_start; s->table.jd_end = eph->jd_end;
+    s->table.block_days = eph->block_days; s->table.emrat = eph->emrat;
+    s->table.n_blocks = eph->n_blocks;
+    TRY_RC(upload(s->coef, eph->coef, (size_t)eph->n_blocks * per_block));
+    s->table.coef = s->coef.p;
+  }
+  if (params->n_noise_realizations > 0)
+    TRY_RC(upload(s->noise, b->noise_z,
+                  (size_t)s->n_traj * s->k_cap * (size_t)params->n_noise_realizations * 6));
+  HIP_TRY(s->results.alloc((size_t)s->n_traj));
+  HIP_TRY(s->error_flag.alloc(1));
+  HIP_TRY(hipMemset(s->error_flag.p, 0, sizeof(int)));
+
+  // chunking: bound the candidate scratch (72 B per candidate) and the heap scratch
+  uint64_t chunk = 131072;
+  if (s->cand_per_traj) chunk = std::min<uint64_t>(chunk, std::max<uint64_t>(1, (16ull << 20) / s->cand_per_traj));
+  chunk = std::max<uint64_t>(1, std::min<uint64_t>(chunk, s->n_traj));
+  s->chunk = chunk;
+  const size_t n_cand = (size_t)chunk * s->cand_per_traj;
+  const size_t heap_stride = (size_t)((chunk + 63) / 64 * 64);
+  HIP_TRY(s->heap_w.alloc(heap_stride * s->k_cap));
+  HIP_TRY(s->heap_id.alloc(heap_stride * s->k_cap));
+  HIP_TRY(s->triplets.alloc((size_t)chunk * s->k_cap));
+  HIP_TRY(s->n_triplets.alloc((size_t)chunk));
+  HIP_TRY(s->flags.alloc(n_cand));
+  HIP_TRY(s->n_win.alloc(n_cand));
+  HIP_TRY(s->sum.alloc(n_cand));
+  HIP_TRY(s->el_epoch.alloc(n_cand));
+  HIP_TRY(s->el.alloc(6 * n_cand));
+
+  s->gp.max_ecc = params->max_ecc;
+  s->gp.max_perihelion_au = params->max_perihelion_au;
+  s->gp.min_rho2_au = params->min_rho2_au;
+  s->gp.aberth_eps = params->aberth_eps;
+  s->gp.kepler_eps = params->kepler_eps;
+  s->gp.r2_min_au = params->r2_min_au;
+  s->gp.r2_max_au = params->r2_max_au;
+  s->gp.newton_eps = params->newton_eps;
+  s->gp.root_imag_eps = params->root_imag_eps;
+  s->gp.aberth_max_iter = params->aberth_max_iter;
+  s->gp.max_tested_solutions = saturate_u32(params->max_tested_solutions);
+  s->gp.newton_max_it = saturate_u32(params->newton_max_it);
+  s->tp.dt_min = params->dt_min;
+  s->tp.dt_max = params->dt_max_triplet;
+  s->tp.inv_dtw = 1.0 / params->optimal_interval_time;  // f64::recip (mod.rs:347)
+  s->tp.max_keep = params->max_obs_for_triplets;
+  s->tp.k_cap = params->max_triplets;
+  return OUTFIT_OK;
+}
+
+struct Stamp {
+  outfit_hip_session* s;
+  hipStream_t st;
+  int id;
+  hipEvent_t a = nullptr, b = nullptr;
+  Stamp(outfit_hip_session* s_, hipStream_t st_, int id_) : s(s_), st(st_), id(id_) {
+    if (s->profiling) {
+      (void)hipEventCreate(&a);
+      (void)hipEventCreate(&b);
+      (void)hipEventRecord(a, st);
+    }
+  }
+  ~Stamp() {
+    if (s->profiling) {
+      (void)hipEventRecord(b, st);
+      s->timed.push_back({id, a, b});
+    }
+  }
+};
+
+int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d_out) {
+  HIP_TRY(hipSetDevice(s->device));
+  for (auto& t : s->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+  s->timed.clear();
+  s->last_stream = st;
+  if (s->n_traj == 0) return OUTFIT_OK;
+
+  const double* obs_pos = s->helio.p;
+  if (s->has_ephem && s->has_geo) {
+    outfit::PrepassArgs pa{};
+    pa.n_obs = s->n_obs; pa.mjd = s->mjd.p; pa.geo_ecl = s->geo.p; pa.obs_pos = s->obs_pos.p;
+    pa.T = s->table; pa.error_flag = s->error_flag.p;
+    Stamp stamp(s, st, K_PREPASS);
+    HIP_TRY(outfit::launch_observer_prepass(pa, st));
+    obs_pos = s->obs_pos.p;
+  }
+  for (uint64_t t0 = 0; t0 < s->n_traj; t0 += s->chunk) {
+    const uint64_t nt = std::min<uint64_t>(s->chunk, s->n_traj - t0);
+    const unsigned long long n_cand = (unsigned long long)nt * s->cand_per_traj;
+    outfit::TripletArgs ta{};
+    ta.n_traj = nt; ta.traj0 = t0; ta.traj_offset = s->traj_offset.p; ta.mjd = s->mjd.p; ta.P = s->tp;
+    ta.heap_w = s->heap_w.p; ta.heap_id = s->heap_id.p;
+    ta.heap_stride = (unsigned long long)((s->chunk + 63) / 64 * 64);
+    ta.n_triplets = s->n_triplets.p; ta.triplets = s->triplets.p;
+    {
+      Stamp stamp(s, st, K_TRIPLETS);
+      HIP_TRY(outfit::launch_triplet_select(ta, st));
+    }
+    outfit::CandidateArgs ca{};
+    ca.n_cand = n_cand; ca.traj0 = t0; ca.cand_per_traj = s->cand_per_traj; ca.n_real = s->n_real;
+    ca.k_cap = s->k_cap; ca.traj_offset = s->traj_offset.p;
+    ca.mjd = s->mjd.p; ca.ra = s->ra.p; ca.dec = s->dec.p; ca.sra = s->sra.p; ca.sdec = s->sdec.p;
+    ca.helio = s->helio.p; ca.obs_pos = obs_pos; ca.noise_z = s->noise.p;
+    ca.n_triplets = s->n_triplets.p; ca.triplets = s->triplets.p; ca.P = s->gp;
+    ca.extf = s->params.extf; ca.dtmax = s->params.dtmax; ca.noise_scale = s->params.noise_scale;
+    ca.flags = s->flags.p; ca.n_win = s->n_win.p; ca.sum = s->sum.p; ca.el_epoch = s->el_epoch.p;
+    ca.el = s->el.p;
+    {
+      Stamp stamp(s, st, K_CANDIDATE);
+      HIP_TRY(outfit::launch_gauss_candidate(ca, st));
+    }
+    outfit::SelectArgs sa{};
+    sa.n_traj = nt; sa.traj0 = t0; sa.n_cand = n_cand; sa.cand_per_traj = s->cand_per_traj;
+    sa.n_real = s->n_real; sa.n_triplets = s->n_triplets.p; sa.flags = s->flags.p; sa.n_win = s->n_win.p;
+    sa.sum = s->sum.p; sa.el_epoch = s->el_epoch.p; sa.el = s->el.p;
+    sa.out = d_out ? d_out : s->results.p;
+    {
+      Stamp stamp(s, st, K_SELECT);
+      HIP_TRY(outfit::launch_select_best(sa, st));
+    }
+  }
+  return OUTFIT_OK;
+}
+
+int collect_times(outfit_hip_session* s) {
+  for (int k = 0; k < K_COUNT; ++k) { s->kernel_ms[k] = 0.f; s->kernel_launches[k] = 0; }
+  for (auto& t : s->timed) {
+    HIP_TRY(hipEventSynchronize(t.b));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b));
+    s->kernel_ms[t.id] += ms;
+    s->kernel_launches[t.id] += 1;
+  }
+  return OUTFIT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void outfit_hip_iod_params_default(outfit_iod_params_t* p) {
+  std::memset(p, 0, sizeof *p);
+  p->n_noise_realizations = 20; p->noise_scale = 1.0; p->extf = -1.0; p->dtmax = 30.0;
+  p->dt_min = 0.03; p->dt_max_triplet = 150.0; p->optimal_interval_time = 20.0;
+  p->max_obs_for_triplets = 100; p->max_triplets = 10; p->gap_max = 8.0 / 24.0;
+  p->max_ecc = 5.0; p->max_perihelion_au = 1.0e3; p->min_rho2_au = 0.01;
+  p->aberth_max_iter = 50; p->aberth_eps = 1.0e-6;
+  p->kepler_eps = 1e3 * std::numeric_limits<double>::epsilon();
+  p->max_tested_solutions = 3; p->r2_min_au = 0.05; p->r2_max_au = 200.0;
+  p->newton_eps = 1.0e-10; p->newton_max_it = 50; p->root_imag_eps = 1.0e-6;
+}
+
+int outfit_hip_iod_params_validate(const outfit_iod_params_t* p) {
+  if (!p) return fail(OUTFIT_ERR_INVALID_PARAM, "params is NULL");
+  if (const char* m = validate_params(p)) return fail(OUTFIT_ERR_INVALID_PARAM, m);
+  return OUTFIT_OK;
+}
+
+const char* outfit_hip_last_error(void) { return g_last_error.c_str(); }
+int outfit_hip_abi_version(void) { return OUTFIT_HIP_ABI_VERSION; }
+
+int outfit_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int outfit_hip_session_create(const outfit_iod_params_t* params, const outfit_obs_batch_t* batch,
+                              const outfit_ephem_t* ephem, int device, outfit_hip_session_t** out) {
+  if (!out) return fail(OUTFIT_ERR_BAD_HANDLE, "out_session is NULL");
+  *out = nullptr;
+  TRY_RC(outfit_hip_iod_params_validate(params));
+  TRY_RC(check_batch(params, batch, ephem));
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+    return fail(OUTFIT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+  if (device < 0 || device >= n_dev) return fail(OUTFIT_ERR_NO_DEVICE, "device index out of range");
+  auto* s = new outfit_hip_session();
+  s->device = device;
+  const int rc = session_build(s, params, batch, ephem);
+  if (rc != OUTFIT_OK) {
+    s->free_all();
+    delete s;
+    return rc;
+  }
+  *out = s;
+  return OUTFIT_OK;
+}
+
+int outfit_hip_session_run(outfit_hip_session_t* s, void* stream, void* d_out) {
+  if (!s) return fail(OUTFIT_ERR_BAD_HANDLE, "session is NULL");
+  hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : s->own_stream;
+  return session_run(s, st, reinterpret_cast<outfit::GaussResultRec*>(d_out));
+}
+
+int outfit_hip_session_results(outfit_hip_session_t* s, outfit_gauss_result_t* out) {
+  if (!s || !out) return fail(OUTFIT_ERR_BAD_HANDLE, "session or out is NULL");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->last_stream ? s->last_stream : s->own_stream));
+  int flag = 0;
+  HIP_TRY(hipMemcpy(&flag, s->error_flag.p, sizeof(int), hipMemcpyDeviceToHost));
+  if (flag) return fail(OUTFIT_ERR_EPHEM_RANGE, "an observation epoch lies outside the ephemeris table");
+  if (s->n_traj)
+    HIP_TRY(hipMemcpy(out, s->results.p, (size_t)s->n_traj * sizeof(outfit_gauss_result_t),
+                      hipMemcpyDeviceToHost));
+  return OUTFIT_OK;
+}
+
+void* outfit_hip_session_device_results(outfit_hip_session_t* s) { return s ? s->results.p : nullptr; }
+
+int outfit_hip_session_set_profiling(outfit_hip_session_t* s, int enabled) {
+  if (!s) return fail(OUTFIT_ERR_BAD_HANDLE, "session is NULL");
+  s->profiling = enabled != 0;
+  return OUTFIT_OK;
+}
+
+int outfit_hip_session_kernel_times(outfit_hip_session_t* s, int max_n, const char** names, float* ms) {
+  if (!s) return fail(OUTFIT_ERR_BAD_HANDLE, "session is NULL");
+  if (collect_times(s) != OUTFIT_OK) return OUTFIT_ERR_HIP;
+  int n = 0;
+  for (int k = 0; k < K_COUNT && n < max_n; ++k) {
+    if (s->kernel_launches[k] == 0) continue;
+    if (names) names[n] = kKernelNames[k];
+    if (ms) ms[n] = s->kernel_ms[k];
+    ++n;
+  }
+  return n;
+}
+
+void outfit_hip_session_destroy(outfit_hip_session_t* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  s->free_all();
+  delete s;
+}
+
+int outfit_hip_fit_full_iod(const outfit_iod_params_t* params, const outfit_obs_batch_t* batch,
+                            const outfit_ephem_t* ephem, int n_devices, outfit_gauss_result_t* out) {
+  TRY_RC(outfit_hip_iod_params_validate(params));
+  TRY_RC(check_batch(params, batch, ephem));
+  if (!out && batch->n_traj) return fail(OUTFIT_ERR_INVALID_BATCH, "out is NULL");
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+    return fail(OUTFIT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+  if (n_devices <= 0 || n_devices > n_dev) n_devices = n_dev;
+  if (batch->n_traj == 0) return OUTFIT_OK;
+  n_devices = (int)std::min<uint64_t>((uint64_t)n_devices, batch->n_traj);
+
+  // contiguous ranges balanced by observation count (all tasks are independent:
+  // obs_dataset_api.rs:277-296), one host thread per device, no exchange step.
+  const uint64_t o0 = batch->traj_offset[0], total = batch->traj_offset[batch->n_traj] - o0;
+  std::vector<uint64_t> cut(n_devices + 1, batch->n_traj);
+  cut[0] = 0;
+  for (int d = 1; d < n_devices; ++d) {
+    const uint64_t target = o0 + total * (uint64_t)d / (uint64_t)n_devices;
+    const uint64_t* lo = std::lower_bound(batch->traj_offset, batch->traj_offset + batch->n_traj, target);
+    cut[d] = std::max<uint64_t>(cut[d - 1], (uint64_t)(lo - batch->traj_offset));
+  }
+  std::vector<int> rc(n_devices, OUTFIT_OK);
+  std::vector<std::string> msg(n_devices);
+  auto work = [&](int d) {
+    const uint64_t t0 = cut[d], t1 = cut[d + 1];
+    if (t1 <= t0) return;
+    outfit_obs_batch_t sub = *batch;
+    sub.n_traj = t1 - t0;
+    sub.traj_offset = batch->traj_offset + t0;
+    if (batch->noise_z)
+      sub.noise_z = batch->noise_z + (size_t)t0 * params->max_triplets * (size_t)params->n_noise_realizations * 6;
+    outfit_hip_session_t* s = nullptr;
+    int r = outfit_hip_session_create(params, &sub, ephem, d, &s);
+    if (r == OUTFIT_OK) r = outfit_hip_session_run(s, nullptr, nullptr);
+    if (r == OUTFIT_OK) r = outfit_hip_session_results(s, out + t0);
+    if (r != OUTFIT_OK) msg[d] = g_last_error;
+    outfit_hip_session_destroy(s);
+    rc[d] = r;
+  };
+  if (n_devices == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int d = 0; d < n_devices; ++d) th.emplace_back(work, d);
+    for (auto& t : th) t.join();
+  }
+  for (int d = 0; d < n_devices; ++d)
+    if (rc[d] != OUTFIT_OK) return fail(rc[d], msg[d]);
+  return OUTFIT_OK;
+}
+
+int outfit_hip_propagate_universal(uint64_t n, const double* r0v0, const double* t0, const double* t1,
+                                   double convergency, double* out, int32_t* status) {
+  if (n == 0) return OUTFIT_OK;
+  if (!r0v0 || !t0 || !t1 || !out || !status) return fail(OUTFIT_ERR_INVALID_BATCH, "NULL argument");
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+    return fail(OUTFIT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+  DevBuf<double> d_rv, d_t0, d_t1, d_out;
+  DevBuf<int> d_st;
+  auto cleanup = [&]() { d_rv.release(); d_t0.release(); d_t1.release(); d_out.release(); d_st.release(); };
+  int rc = OUTFIT_OK;
+  do {
+    if ((rc = upload(d_rv, r0v0, (size_t)6 * n)) != OUTFIT_OK) break;
+    if ((rc = upload(d_t0, t0, (size_t)n)) != OUTFIT_OK) break;
+    if ((rc = upload(d_t1, t1, (size_t)n)) != OUTFIT_OK) break;
+    if (d_out.alloc((size_t)11 * n) != hipSuccess || d_st.alloc((size_t)n) != hipSuccess) {
+      rc = fail(OUTFIT_ERR_HIP, "hipMalloc failed");
+      break;
+    }
+    hipError_t e = outfit::launch_propagate_universal(n, d_rv.p, d_t0.p, d_t1.p, convergency, d_out.p, d_st.p,
+                                                      nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out, d_out.p, (size_t)11 * n * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(status, d_st.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(OUTFIT_ERR_HIP, hipGetErrorString(e));
+  } while (false);
+  cleanup();
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,347 @@
+// kepler.hpp — device-side universal-variable two-body routines (gfx950, fp64).
+//
+// Replaces, on the GPU, the reference's src/kepler/ as used by the Gauss
+// correction loop (gauss.rs:1325-1344 -> velocity.rs:94-211 -> params.rs:130 ->
+// newton_solver.rs:151-352 -> stumpff.rs:78-297) and by
+// kepler::propagate_universal (propagation.rs:114-207).
+//
+// Everything lives in registers: one lane owns one Kepler problem. The
+// arithmetic keeps the reference's operation order and the translation unit is
+// compiled with -ffp-contract=off, so apart from libm-vs-ocml transcendentals
+// the results follow the Rust code to the last bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "crmath.hpp"
+
+namespace outfit {
+
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kTwoPi = 6.283185307179586476925286766559;  // constants.rs:31
+constexpr double kEps = 2.220446049250313e-16;                // f64::EPSILON
+constexpr double kGaussGrav = 0.01720209895;                  // constants.rs:70
+constexpr double kMu = kGaussGrav * kGaussGrav;               // constants.rs:73
+constexpr double kAU = 149597870.7;                           // constants.rs:37
+constexpr double kVlightAU = 2.99792458e5 / kAU * 86400.0;    // constants.rs:79
+
+struct Vec3 {
+  double x, y, z;
+};
+
+__device__ __forceinline__ double dot(const Vec3& a, const Vec3& b) {
+  // nalgebra 3-vector dot: (a0*b0 + a1*b1) + a2*b2
+  return (a.x * b.x + a.y * b.y) + a.z * b.z;
+}
+__device__ __forceinline__ double norm(const Vec3& a) { return sqrt(dot(a, a)); }
+__device__ __forceinline__ Vec3 cross(const Vec3& a, const Vec3& b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ double clampd(double x, double lo, double hi) {
+  return x < lo ? lo : (x > hi ? hi : x);  // f64::clamp (NaN passes through)
+}
+
+// f64::rem_euclid(2*pi)   (kepler/angles.rs:10-12)
+__device__ __forceinline__ double principal_angle(double a) {
+  double r = fmod(a, kTwoPi);
+  return r < 0.0 ? r + kTwoPi : r;
+}
+
+struct Stumpff {
+  double s0, s1, s2, s3;
+};
+
+// kepler/stumpff.rs:78-297. Power series while |alpha psi^2| < 100, otherwise
+// halve psi, expand s0/s1 and apply the duplication formulas.
+__device__ __forceinline__ Stumpff s_funct(double psi, double alpha) {
+  constexpr double tol = 100.0 * kEps, ovf = 1.0 / kEps;
+  if (psi == 0.0) return {1.0, 0.0, 0.0, 0.0};
+  const double psi2 = psi * psi;
+  const double beta = alpha * psi2;
+  if (fabs(beta) < 100.0) {
+    double s2 = 0.5 * psi2, t2 = s2;
+    double s3 = (s2 * psi) / 3.0, t3 = s3;
+    double d2l = 3.0, d2h = 4.0, d3l = 4.0, d3h = 5.0;
+    for (int j = 1; j <= 70; ++j) {
+      t2 *= beta / (d2l * d2h);
+      s2 += t2;
+      t3 *= beta / (d3l * d3h);
+      s3 += t3;
+      const double a2 = fabs(t2), a3 = fabs(t3);
+      if ((a2 < tol && a3 < tol) || a2 > ovf || a3 > ovf) break;
+      d2l += 2.0; d2h += 2.0; d3l += 2.0; d3h += 2.0;
+    }
+    return {1.0 + alpha * s2, psi + alpha * s3, s2, s3};
+  }
+  double rp = psi, rb = beta;
+  int nh = 0;
+  while (fabs(rb) >= 100.0 && nh < 30) { rp *= 0.5; rb *= 0.25; ++nh; }
+  double s0 = 1.0, s1 = rp, t0 = 1.0, t1 = rp;
+  for (int j = 1; j <= 70; ++j) {
+    t0 *= rb / ((double)(2 * j - 1) * (double)(2 * j));
+    s0 += t0;
+    if (fabs(t0) < tol || fabs(t0) > ovf) break;
+  }
+  for (int j = 1; j <= 70; ++j) {
+    t1 *= rb / ((double)(2 * j) * (double)(2 * j + 1));
+    s1 += t1;
+    if (fabs(t1) < tol || fabs(t1) > ovf) break;
+  }
+  for (int i = 0; i < nh; ++i) {
+    const double c = s0, s = s1;
+    s0 = 2.0 * c * c - 1.0;
+    s1 = 2.0 * c * s;
+  }
+  return {s0, s1, (s0 - 1.0) / alpha, (s1 - psi) / alpha};
+}
+
+struct KeplerProblem {
+  double dt, r0, sig0, alpha, e0, convergency;
+};
+
+// kepler/prelim_kepler/prelim_elliptic.rs:9-134
+__device__ __forceinline__ double prelim_elliptic(const KeplerProblem& p) {
+  const double contr = p.convergency;
+  const double a0 = -1.0 / p.alpha;
+  const double n = sqrt(kMu) * sqrt(-(p.alpha * p.alpha * p.alpha));
+  if (p.e0 < contr) return n * p.dt / sqrt(-p.alpha);
+  const double c = (1.0 - p.r0 / a0) / p.e0;
+  double u0;
+  if (fabs(c) <= 1.0) u0 = crm::acos(c);  // correctly rounded: see crmath.hpp
+  else if (c >= 1.0) u0 = 0.0;
+  else u0 = kPi;
+  if (p.sig0 < 0.0) u0 = -u0;
+  u0 = principal_angle(u0);
+  double su0, cu0;
+  crm::sincos(u0, su0, cu0);
+  const double m0 = principal_angle(u0 - p.e0 * su0);
+  const double m = m0 + n * p.dt;
+  double u = m;
+  for (int i = 0; i < 20; ++i) {
+    double su, cu;
+    crm::sincos(u, su, cu);
+    const double res = u - p.e0 * su - m;
+    const double der = 1.0 - p.e0 * cu;
+    const double step = -res / der;
+    u += step;
+    if (fabs(step) < contr * 1e3) break;
+  }
+  return (u - u0) / sqrt(-p.alpha);
+}
+
+// kepler/prelim_kepler/prelim_hyperbolic.rs:45-141 (loop exit tests |F|, quirk Q5)
+__device__ __forceinline__ double prelim_hyperbolic(const KeplerProblem& p) {
+  const double a0 = -1.0 / p.alpha;
+  const double n = sqrt(kMu) * sqrt(p.alpha * p.alpha * p.alpha);
+  const double c = (1.0 - p.r0 / a0) / p.e0;
+  double f0 = (c > 1.0) ? log(c + sqrt(c * c - 1.0)) : 0.0;
+  if (p.sig0 < 0.0) f0 = -f0;
+  const double m = (p.e0 * sinh(f0) - f0) + n * p.dt;
+  double f = 0.0;
+  for (int i = 0; i < 20; ++i) {
+    if (fabs(f) < 15.0) {
+      const double res = p.e0 * sinh(f) - f - m;
+      const double der = p.e0 * cosh(f) - 1.0;
+      const double cand = f + (-res / der);
+      f = (f * cand < 0.0) ? f / 2.0 : cand;
+    } else {
+      f /= 2.0;
+    }
+    if (fabs(f) < p.convergency * 1e3) break;
+  }
+  return (f - f0) / sqrt(p.alpha);
+}
+
+__device__ __forceinline__ void cubic_res_der(double psi, double r0, double sig0, double smdt,
+                                              double& res, double& der) {
+  res = (psi * psi * psi) / 6.0 + sig0 / 2.0 * (psi * psi) + r0 * psi - smdt;
+  der = (psi * psi) / 2.0 + sig0 * psi + r0;
+}
+
+// kepler/prelim_kepler/prelim_parabolic.rs:264-477 (Cardano; reached only for alpha == 0)
+__device__ __forceinline__ double prelim_parabolic(const KeplerProblem& p) {
+  const double r0 = p.r0, sig0 = p.sig0;
+  const double smdt = sqrt(kMu) * p.dt;
+  if (p.dt == 0.0) return 0.0;
+  const double lead = 1.0 / 6.0;
+  const double qc = (sig0 / 2.0) / lead, lc = r0 / lead, cc = -smdt / lead;
+  const double shift = qc / 3.0;
+  const double dl = lc - qc * shift;
+  const double dc = 2.0 * (shift * shift * shift) - lc * shift + cc;
+  const double half = dc / 2.0;
+  const double third = dl / 3.0;
+  const double disc = half * half + third * third * third;
+  double c0, c1 = 0.0, c2 = 0.0;
+  int nc = 1;
+  if (disc > 0.0) {
+    const double sq = sqrt(disc);
+    c0 = (cbrt(-half + sq) + cbrt(-half - sq)) - shift;
+  } else {
+    const double arg = clampd((3.0 * dc) / (2.0 * dl) * sqrt(-3.0 / dl), -1.0, 1.0);
+    const double base = acos(arg) / 3.0;
+    const double amp = 2.0 * sqrt(-dl / 3.0);
+    c0 = amp * cos(base) - shift;
+    c1 = amp * cos(base - 2.0 * kPi / 3.0) - shift;
+    c2 = amp * cos(base - 4.0 * kPi / 3.0) - shift;
+    nc = 3;
+  }
+  // select_physical_root: derivative >= 0 first, then closest to smdt/r0 (first minimum wins)
+  const double lin = smdt / r0;
+  double res, d0, d1 = -1.0, d2 = -1.0;
+  cubic_res_der(c0, r0, sig0, smdt, res, d0);
+  if (nc == 3) {
+    cubic_res_der(c1, r0, sig0, smdt, res, d1);
+    cubic_res_der(c2, r0, sig0, smdt, res, d2);
+  }
+  const bool any_mono = (d0 >= 0.0) || (nc == 3 && (d1 >= 0.0 || d2 >= 0.0));
+  double sel = 0.0;
+  bool have = false;
+  auto consider = [&](double cand, double der) {
+    if (any_mono && !(der >= 0.0)) return;
+    if (!have || fabs(cand - lin) < fabs(sel - lin)) { sel = cand; have = true; }
+  };
+  consider(c0, d0);
+  if (nc == 3) { consider(c1, d1); consider(c2, d2); }
+  double psi = sel;
+  for (int i = 0; i < 2; ++i) {
+    double der;
+    cubic_res_der(psi, r0, sig0, smdt, res, der);
+    if (der == 0.0 || !isfinite(der)) break;
+    psi -= res / der;
+  }
+  return psi;
+}
+
+// kepler/params.rs:185-191
+__device__ __forceinline__ double prelim_kepuni(const KeplerProblem& p) {
+  if (p.alpha < 0.0) return prelim_elliptic(p);
+  if (p.alpha > 0.0) return prelim_hyperbolic(p);
+  return prelim_parabolic(p);
+}
+
+struct KeplerSolution {
+  double psi;
+  Stumpff s;
+  bool ok;
+};
+
+// kepler/newton_solver.rs:151-161,240-352 (SolverKind::NewtonRaphson)
+__device__ __forceinline__ KeplerSolution solve_kepuni(const KeplerProblem& p, bool has_guess, double guess) {
+  const double sqrt_mu = sqrt(kMu);
+  const double res_tol = 10.0 * kEps * (1.0 + fabs(sqrt_mu * p.dt));
+  double psi = has_guess ? guess : prelim_kepuni(p);
+  KeplerSolution out;
+  out.ok = false;
+  out.psi = psi;
+  out.s = {1.0, 0.0, 0.0, 0.0};
+  for (int it = 0; it < 50; ++it) {
+    if (!isfinite(psi)) { psi = 0.5; continue; }
+    const Stumpff s = s_funct(psi, p.alpha);
+    const double residual = p.r0 * s.s1 + p.sig0 * s.s2 + s.s3 - sqrt_mu * p.dt;
+    const double derivative = p.r0 * s.s0 + p.sig0 * s.s1 + s.s2;
+    if (fabs(residual) <= res_tol) { out.psi = psi; out.s = s; out.ok = true; break; }
+    if (!isfinite(derivative) || fabs(derivative) < 10.0 * kEps) { psi *= 0.5; continue; }
+    const double mx = 2.0 * (1.0 + fabs(psi));
+    const double step = clampd(-residual / derivative, -mx, mx);
+    const double cand = psi + step;
+    psi = (cand * psi < 0.0) ? 0.5 * psi : cand;
+    const double sa = fabs(step);
+    if (sa <= p.convergency) {  // quirk Q3: new psi with the previous Stumpff values
+      out.psi = psi; out.s = s; out.ok = true; break;
+    }
+    if (sa <= p.convergency * (1.0 + fabs(psi))) {
+      out.psi = psi; out.s = s_funct(psi, p.alpha); out.ok = true; break;
+    }
+  }
+  return out;
+}
+
+struct EccControl {
+  bool some;      // false = None (zero angular momentum)
+  bool accepted;
+  double ecc, peri, energy;
+};
+
+// orb_elem.rs:257-301
+__device__ __forceinline__ EccControl eccentricity_control(const Vec3& r, const Vec3& v, double peri_max,
+                                                  double ecc_max) {
+  EccControl o;
+  const double v2 = dot(v, v);
+  const double dist = norm(r);
+  const Vec3 h = cross(r, v);
+  const double h2 = dot(h, h);
+  o.some = !(sqrt(h2) == 0.0);
+  const Vec3 vxh = cross(v, h);
+  const double inv_mu = 1.0 / kMu, inv_d = 1.0 / dist;
+  const Vec3 lenz = {vxh.x * inv_mu - r.x * inv_d, vxh.y * inv_mu - r.y * inv_d,
+                     vxh.z * inv_mu - r.z * inv_d};
+  o.ecc = norm(lenz);
+  o.peri = h2 / (kMu * (1.0 + o.ecc));
+  o.energy = v2 / 2.0 - kMu / dist;
+  o.accepted = (o.ecc < ecc_max) && (o.peri < peri_max);
+  return o;
+}
+
+struct VelCorr {
+  bool ok;
+  Vec3 v;
+  double f, g, chi;
+};
+
+// kepler/velocity.rs:94-211. Quirk Q7: only the None of eccentricity_control fails.
+__device__ __forceinline__ VelCorr velocity_correction(const Vec3& x1, const Vec3& x2, const Vec3& v2, double dt,
+                                              double peri_max, double ecc_max, bool has_guess,
+                                              double chi_guess, double eps) {
+  VelCorr o;
+  o.ok = false;
+  const double r2 = norm(x2);
+  const double sig0 = dot(x2, v2) / sqrt(kMu);
+  const double hn = norm(cross(x2, v2));
+  if (!isfinite(hn) || hn <= 1e6 * kEps) return o;
+  const EccControl ec = eccentricity_control(x2, v2, peri_max, ecc_max);
+  if (!ec.some) return o;
+  KeplerProblem p;
+  p.dt = dt; p.r0 = r2; p.sig0 = sig0;
+  p.alpha = 2.0 * ec.energy / kMu;
+  p.e0 = ec.ecc;
+  p.convergency = eps;
+  const KeplerSolution sol = solve_kepuni(p, has_guess, chi_guess);
+  if (!sol.ok) return o;
+  const double f = 1.0 - sol.s.s2 / r2;
+  const double g = dt - sol.s.s3 / sqrt(kMu);
+  const double ga = fabs(g);
+  if (!isfinite(ga) || ga < 100.0 * kEps * (1.0 + fabs(dt))) return o;
+  o.v = {((-f) * x2.x + x1.x) / g, ((-f) * x2.y + x1.y) / g, ((-f) * x2.z + x1.z) / g};
+  o.f = f; o.g = g; o.chi = sol.psi;
+  o.ok = true;
+  return o;
+}
+
+// kepler/propagation.rs:114-207 ; out = r1[3] v1[3] f g fdot gdot psi ; returns the status code
+// documented at outfit_hip_propagate_universal (include/outfit_hip.h).
+__device__ __forceinline__ int propagate_universal(const Vec3& r, const Vec3& v, double t0, double t1,
+                                          double convergency, double* out) {
+  const double r0 = norm(r);
+  if (r0 < kEps) return 1;
+  const double v2 = dot(v, v);
+  const double sqrt_mu = sqrt(kMu);
+  KeplerProblem p;
+  p.sig0 = dot(r, v) / sqrt_mu;
+  p.alpha = (v2 - 2.0 * kMu / r0) / kMu;
+  const Vec3 h = cross(r, v);
+  double e = sqrt(1.0 + p.alpha * dot(h, h) / kMu);
+  if (!(e >= 0.0)) e = 0.0;  // f64::max(NaN, 0.0) == 0.0
+  p.e0 = e; p.r0 = r0; p.dt = t1 - t0; p.convergency = convergency;
+  const KeplerSolution s = solve_kepuni(p, false, 0.0);
+  if (!s.ok) return 2;
+  const double r1 = r0 * s.s.s0 + p.sig0 * s.s.s1 + s.s.s2;
+  if (r1 < kEps) return 3;
+  const double f = 1.0 - s.s.s2 / r0;
+  const double g = (r0 * s.s.s1 + p.sig0 * s.s.s2) / sqrt_mu;
+  const double fd = -(sqrt_mu / (r0 * r1)) * s.s.s1;
+  const double gd = 1.0 - s.s.s2 / r1;
+  out[0] = f * r.x + g * v.x; out[1] = f * r.y + g * v.y; out[2] = f * r.z + g * v.z;
+  out[3] = fd * r.x + gd * v.x; out[4] = fd * r.y + gd * v.y; out[5] = fd * r.z + gd * v.z;
+  out[6] = f; out[7] = g; out[8] = fd; out[9] = gd; out[10] = s.psi;
+  return 0;
+}
+
+}  // namespace outfit

@@ -1,0 +1,244 @@
+// orbit.hpp — device-side state -> elements conversion and the per-observation
+// astrometric residual, one lane per candidate.
+//
+// Replaces: compute_orbit_from_state (gauss.rs:906-923) -> ccek1
+// (orb_elem.rs:58-226); OrbitalElements::to_equinoctial (orbit_type/mod.rs:399-443,
+// equinoctial_element.rs:285-313, cometary_element.rs:224-289);
+// EquinoctialElements::propagate_twobody (equinoctial_element.rs:809-867) with the
+// `roots` 0.0.8 Newton–Raphson (equinoctial_element.rs:326-348);
+// Observation::ephemeris_error (observation_ephemeris.rs:388-416) with
+// topocentric_radec_and_partials :222-275 and correct_aberration_first_order
+// (aberration.rs:139-145).
+#pragma once
+#include "kepler.hpp"
+
+namespace outfit {
+
+constexpr double kCosEps = 9.174820620691818e-1;  // constants.rs:93-127
+constexpr double kSinEps = 3.977771559319137e-1;
+
+// ROT_EQUMJ2000_TO_ECLMJ2000 * v with nalgebra's gemv order (zero terms kept)
+__device__ __forceinline__ Vec3 equ_to_ecl(const Vec3& v) {
+  return {(1.0 * v.x + 0.0 * v.y) + 0.0 * v.z,
+          (0.0 * v.x + kCosEps * v.y) + kSinEps * v.z,
+          (0.0 * v.x + (-kSinEps) * v.y) + kCosEps * v.z};
+}
+__device__ __forceinline__ Vec3 ecl_to_equ(const Vec3& v) {
+  return {(1.0 * v.x + 0.0 * v.y) + 0.0 * v.z,
+          (0.0 * v.x + kCosEps * v.y) + (-kSinEps) * v.z,
+          (0.0 * v.x + kSinEps * v.y) + kCosEps * v.z};
+}
+
+struct Elements {
+  int kind;      // 0 Keplerian (a,e,i,Om,om,M) ; 1 Cometary (q,e,i,Om,om,nu)
+  double epoch;
+  double e[6];
+};
+
+// orb_elem.rs:58-226 (input already rotated to the ecliptic frame)
+__device__ __forceinline__ Elements ccek1(const Vec3& pos, const Vec3& vel, double epoch) {
+  constexpr double EPS_EQ = 1e-15, EPS_PARAB = 1e-12, EPS_E = 5e-15;
+  Elements out;
+  out.epoch = epoch;
+  const Vec3 h = cross(pos, vel);
+  const double h2 = dot(h, h);
+  const double hn = sqrt(h2);
+  const Vec3 hu = {h.x / hn, h.y / hn, h.z / hn};
+  const double sin_i = sqrt(hu.x * hu.x + hu.y * hu.y);
+  double inc = principal_angle(atan2(sin_i, hu.z));
+  double node;
+  if (sin_i <= EPS_EQ) { inc = 0.0; node = 0.0; }
+  else node = principal_angle(atan2(hu.x, -hu.y));
+  double si, ci, sn, cn;
+  sincos(inc, &si, &ci);
+  sincos(node, &sn, &cn);
+  // rotmt(i,0)^T * rotmt(Om,2)^T: every entry is a single product (ref_system.rs:453-462)
+  const double m10 = ci * (-sn), m11 = ci * cn, m20 = (-si) * (-sn), m21 = (-si) * cn;
+  const Vec3 po = {(cn * pos.x + sn * pos.y) + 0.0 * pos.z, (m10 * pos.x + m11 * pos.y) + si * pos.z,
+                   (m20 * pos.x + m21 * pos.y) + ci * pos.z};
+  const Vec3 vo = {(cn * vel.x + sn * vel.y) + 0.0 * vel.z, (m10 * vel.x + m11 * vel.y) + si * vel.z,
+                   (m20 * vel.x + m21 * vel.y) + ci * vel.z};
+  const double rv = po.x * vo.x + po.y * vo.y;
+  const double rad = sqrt(po.x * po.x + po.y * po.y);
+  const double vsq = vo.x * vo.x + vo.y * vo.y;
+  const double inv_a = 2.0 / rad - vsq / kMu;
+  bool parabolic = false;
+  if (inv_a > EPS_PARAB) {
+    const double a = 1.0 / inv_a;
+    const double n = sqrt(kMu / (a * a * a));
+    const double esin = rv / (n * a * a);
+    const double ecos = vsq * rad / kMu - 1.0;
+    const double e = sqrt(esin * esin + ecos * ecos);
+    if (fabs(e - 1.0) < EPS_E) {
+      parabolic = true;
+    } else {
+      const double ea = atan2(esin, ecos);
+      double sea, cea;
+      sincos(ea, &sea, &cea);
+      const double ma = principal_angle(ea - e * sea);
+      const double x1 = cea - e;
+      const double x2 = sqrt(1.0 - e * e) * sea;
+      const double nm = sqrt(x1 * x1 + x2 * x2);
+      const double x1n = x1 / nm, x2n = x2 / nm;
+      const double sp = x1n * po.y - x2n * po.x;
+      const double cp = x1n * po.x + x2n * po.y;
+      out.kind = 0;
+      out.e[0] = a; out.e[1] = e; out.e[2] = inc; out.e[3] = node;
+      out.e[4] = principal_angle(atan2(sp, cp));
+      out.e[5] = ma;
+      return out;
+    }
+  } else if (fabs(inv_a) <= EPS_PARAB) {
+    parabolic = true;
+  } else {
+    const double p = h2 / kMu;
+    const double ecos = p / rad - 1.0;
+    const double esin = rv * p / (hn * rad);
+    const double nu = atan2(esin, ecos);
+    const double e = sqrt(ecos * ecos + esin * esin);
+    if (fabs(e - 1.0) < EPS_E) {
+      parabolic = true;
+    } else {
+      out.kind = 1;
+      out.e[0] = p / (1.0 + e); out.e[1] = e; out.e[2] = inc; out.e[3] = node;
+      out.e[4] = principal_angle(atan2(po.y, po.x) - nu);
+      out.e[5] = nu;
+      return out;
+    }
+  }
+  // parabolic_solution (orb_elem.rs:122-145)
+  (void)parabolic;
+  const double p = h2 / kMu;
+  const double cnu = p / rad - 1.0;
+  const double snu = rv * p / (rad * hn);
+  const double nu = atan2(snu, cnu);
+  out.kind = 1;
+  out.e[0] = p / 2.0; out.e[1] = 1.0; out.e[2] = inc; out.e[3] = node;
+  out.e[4] = principal_angle(atan2(po.y, po.x) - nu);
+  out.e[5] = nu;
+  return out;
+}
+
+struct Equinoctial {
+  double epoch, a, h, k, p, q, lambda;
+};
+
+// equinoctial_element.rs:285-313
+__device__ __forceinline__ Equinoctial from_kepler(double epoch, double a, double e, double inc, double node,
+                                          double argp, double ma) {
+  Equinoctial q;
+  const double dig = node + argp;
+  double sd, cd, sn, cn;
+  sincos(dig, &sd, &cd);
+  sincos(node, &sn, &cn);
+  q.h = e * sd;
+  q.k = e * cd;
+  const double t = tan(inc / 2.0);
+  q.p = t * sn;
+  q.q = t * cn;
+  q.lambda = principal_angle(dig + ma);
+  q.epoch = epoch;
+  q.a = a;
+  return q;
+}
+
+// orbit_type/mod.rs:399-443 ; returns 0, 3 (InvalidConversion) or 4 (InvalidOrbit) =
+// OUTFIT_TRAJ_* of include/outfit_hip.h
+__device__ __forceinline__ int to_equinoctial(const Elements& el, Equinoctial& eq) {
+  if (el.kind == 0) {
+    eq = from_kepler(el.epoch, el.e[0], el.e[1], el.e[2], el.e[3], el.e[4], el.e[5]);
+    return 0;
+  }
+  const double e = el.e[1];
+  if (fabs(e - 1.0) < 1e-12) return 3;
+  const double p = el.e[0] * (1.0 + e);
+  const double a = -p / (e * e - 1.0);
+  if (e <= 1.0) return 4;
+  const double s = sqrt((e - 1.0) / (e + 1.0));
+  const double x = clampd(s * tan(0.5 * el.e[5]), -1.0 + 1e-15, 1.0 - 1e-15);
+  const double hh = 2.0 * atanh(x);
+  eq = from_kepler(el.epoch, a, e, el.e[2], el.e[3], el.e[4], e * sinh(hh) - hh);
+  return 0;
+}
+
+// Candidate-constant part of propagate_twobody, hoisted out of the observation loop.
+struct TwoBodyFrame {
+  double n, e2, varpi, beta, bet, one_bh2, one_bk2;
+  Vec3 f, g;
+};
+
+__device__ __forceinline__ TwoBodyFrame twobody_frame(const Equinoctial& q) {
+  TwoBodyFrame F;
+  F.n = sqrt(kMu / (q.a * q.a * q.a));
+  F.e2 = q.h * q.h + q.k * q.k;
+  F.varpi = 0.0;
+  if (F.e2 > kEps * 1e2) F.varpi = principal_angle(atan2(q.h, q.k));
+  F.beta = 1.0 / (1.0 + sqrt(1.0 - F.e2));
+  F.bet = F.beta * q.h * q.k;
+  F.one_bh2 = 1.0 - F.beta * (q.h * q.h);
+  F.one_bk2 = 1.0 - F.beta * (q.k * q.k);
+  const double u = 1.0 + q.p * q.p + q.q * q.q;
+  const double inv_u = 1.0 / u;
+  const double cc = 2.0 * q.p * q.q * inv_u;
+  F.f = {(1.0 - q.p * q.p + q.q * q.q) * inv_u, cc, -2.0 * q.p * inv_u};
+  F.g = {cc, (1.0 + q.p * q.p - q.q * q.q) * inv_u, 2.0 * q.q * inv_u};
+  return F;
+}
+
+// equinoctial_element.rs:809-867 with t0 = 0, t1 = dt ; false = Err(RootFindingError)
+__device__ __forceinline__ bool propagate_twobody(const Equinoctial& q, const TwoBodyFrame& F, double dt,
+                                         Vec3& pos, Vec3& vel) {
+  double lam = principal_angle(q.lambda + F.n * (dt - 0.0));
+  if (lam < F.varpi) lam += kTwoPi;
+  // roots::find_root_newton_raphson, SimpleConvergency{eps: 100*EPSILON, max_iter: 25}
+  constexpr double eps = kEps * 1e2;
+  double x = kPi + F.varpi;
+  double sx, cx;
+  int iter = 0;
+  for (;;) {
+    sincos(x, &sx, &cx);
+    const double f = x - q.k * sx + q.h * cx - lam;
+    const double d = 1.0 - q.k * cx - q.h * sx;
+    if (fabs(f) < eps) break;
+    if (fabs(d) < eps) {
+      if (iter == 0) { x = x + 1.0; iter = 1; continue; }
+      return false;
+    }
+    const double x1 = x - f / d;
+    if (fabs(x - x1) < eps) { x = x1; sincos(x, &sx, &cx); break; }
+    x = x1;
+    iter = iter + 1;
+    if (iter >= 25) return false;
+  }
+  const double xe = q.a * (F.one_bh2 * cx + F.bet * sx - q.k);
+  const double ye = q.a * (F.one_bk2 * sx + F.bet * cx - q.h);
+  pos = {xe * F.f.x + ye * F.g.x, xe * F.f.y + ye * F.g.y, xe * F.f.z + ye * F.g.z};
+  const double vc = F.n * (q.a * q.a) / sqrt(xe * xe + ye * ye);
+  const double vxe = vc * (F.bet * cx - F.one_bh2 * sx);
+  const double vye = vc * (F.one_bk2 * cx - F.bet * sx);
+  vel = {vxe * F.f.x + vye * F.g.x, vxe * F.f.y + vye * F.g.y, vxe * F.f.z + vye * F.g.z};
+  return true;
+}
+
+// observation_ephemeris.rs:369-416 for one observation; false = Err(_)
+__device__ __forceinline__ bool ephemeris_error(const Equinoctial& q, const TwoBodyFrame& F, double mjd, double ra,
+                                       double dec, double sra, double sdec, const Vec3& obs_pos_equ,
+                                       double& term) {
+  Vec3 pe, ve;
+  if (!propagate_twobody(q, F, mjd - q.epoch, pe, ve)) return false;
+  const Vec3 pq = ecl_to_equ(pe), vq = ecl_to_equ(ve);
+  const Vec3 rel = {pq.x - obs_pos_equ.x, pq.y - obs_pos_equ.y, pq.z - obs_pos_equ.z};
+  const double lt = norm(rel) / kVlightAU;
+  const Vec3 cor = {rel.x - lt * vq.x, rel.y - lt * vq.y, rel.z - lt * vq.z};
+  const double delta = atan2(cor.z, hypot(cor.x, cor.y));
+  double alpha = fmod(atan2(cor.y, cor.x), kTwoPi);
+  if (alpha < 0.0) alpha += kTwoPi;
+  double da = fmod(ra - alpha, kTwoPi);  // sign of the dividend is kept (quirk Q6)
+  if (da > kPi) da -= kTwoPi;
+  const double t1 = cos(dec) * (da / sra);
+  const double t2 = (dec - delta) / sdec;
+  term = t1 * t1 + t2 * t2;
+  return true;
+}
+
+}  // namespace outfit

@@ -1,0 +1,168 @@
+// triplets.hpp — device-side triplet enumeration and best-K selection, one lane
+// per trajectory.
+//
+// Replaces generate_triplets (reference
+// src/initial_orbit_determination/triplet_generation/mod.rs:328-408) with its
+// lazy index stream (index_generator.rs:133-271), the down-sampling rule
+// (index_generator.rs:66-75) and the weight (mod.rs:229-274).
+//
+// The reference keeps the K best triplets in a std BinaryHeap (max-heap on the
+// weight) and sorts the survivors by weight. Which of several EQUAL weights
+// survives depends on the heap's sift order, so the heap is emulated operation
+// for operation; the heap lives in a per-lane slice of a global scratch buffer
+// ([slot][lane] interleaved so that a wave touches 64 consecutive words).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace outfit {
+
+struct TripletParams {
+  double dt_min, dt_max, inv_dtw;
+  unsigned long long max_keep;  // IODParams::max_obs_for_triplets
+  unsigned k_cap;               // IODParams::max_triplets
+};
+
+__device__ __forceinline__ unsigned long long pack_triplet(unsigned i, unsigned j, unsigned k) {
+  return ((unsigned long long)i << 42) | ((unsigned long long)j << 21) | (unsigned long long)k;
+}
+__device__ __forceinline__ void unpack_triplet(unsigned long long p, unsigned& i, unsigned& j, unsigned& k) {
+  i = (unsigned)(p >> 42) & 0x1FFFFFu;
+  j = (unsigned)(p >> 21) & 0x1FFFFFu;
+  k = (unsigned)p & 0x1FFFFFu;
+}
+
+// Per-lane view of the heap: slot s of this lane is at [s * stride].
+struct HeapView {
+  double* w;
+  unsigned long long* id;
+  unsigned long long stride;
+  __device__ __forceinline__ double W(unsigned s) const { return w[s * stride]; }
+  __device__ __forceinline__ unsigned long long I(unsigned s) const { return id[s * stride]; }
+  __device__ __forceinline__ void set(unsigned s, double ww, unsigned long long ii) const {
+    w[s * stride] = ww;
+    id[s * stride] = ii;
+  }
+  __device__ __forceinline__ void move(unsigned dst, unsigned src) const {
+    w[dst * stride] = w[src * stride];
+    id[dst * stride] = id[src * stride];
+  }
+};
+
+// WeightedTriplet::cmp (mod.rs:135-146): weight first; indices only when a weight is NaN.
+// Weights here are finite (non-finite ones are skipped, mod.rs:382-384), so `a <= b` is wa <= wb.
+__device__ __forceinline__ bool wt_le(double wa, double wb) { return wa <= wb; }
+
+// std::collections::BinaryHeap::sift_up(start, pos) with the element held out of the array
+__device__ __forceinline__ unsigned heap_sift_up(const HeapView& h, unsigned start, unsigned pos, double ew,
+                                        unsigned long long ei) {
+  while (pos > start) {
+    const unsigned parent = (pos - 1) / 2;
+    if (wt_le(ew, h.W(parent))) break;
+    h.move(pos, parent);
+    pos = parent;
+  }
+  h.set(pos, ew, ei);
+  return pos;
+}
+
+// BinaryHeap::pop(): swap the last element into the root, sift_down_to_bottom(0), sift_up
+__device__ __forceinline__ void heap_pop(const HeapView& h, unsigned& len) {
+  const double lw = h.W(len - 1);
+  const unsigned long long li = h.I(len - 1);
+  --len;
+  if (len == 0) return;
+  const unsigned end = len;
+  unsigned pos = 0, child = 1;
+  while (end >= 2 && child <= end - 2) {
+    if (wt_le(h.W(child), h.W(child + 1))) child += 1;
+    h.move(pos, child);
+    pos = child;
+    child = 2 * pos + 1;
+  }
+  if (child == end - 1) { h.move(pos, child); pos = child; }
+  heap_sift_up(h, 0, pos, lw, li);
+}
+
+// index_generator.rs:66-75 — reduced index -> original index
+__device__ __forceinline__ unsigned long long keep_index(unsigned long long i, unsigned long long n,
+                                                         unsigned long long max_keep) {
+  if (max_keep >= n) return i;
+  if (max_keep <= 3) return i == 0 ? 0 : (i == 1 ? n / 2 : n - 1);
+  return i * (n - 1) / (max_keep - 1);
+}
+__device__ __forceinline__ unsigned long long reduced_len(unsigned long long n, unsigned long long max_keep) {
+  if (n == 0) return 0;
+  if (max_keep >= n) return n;
+  if (max_keep <= 3) return 3;
+  return max_keep;
+}
+
+// mod.rs:265-274
+__device__ __forceinline__ double s_gap(double dt, double inv_dtw) {
+  const double r = dt * inv_dtw;
+  return (r <= 1.0) ? 1.0 / r : 1.0 + r;
+}
+
+// Enumerate, keep the best K, sort by weight (stable on the heap's vector order).
+// Returns the number of triplets; slot s of the heap then holds triplet s.
+__device__ __forceinline__ unsigned select_triplets(const double* mjd /* this trajectory */, unsigned long long n_obs,
+                                           const TripletParams& P, const HeapView& h) {
+  if (P.k_cap == 0 || n_obs < 3) return 0;
+  const unsigned long long n = reduced_len(n_obs, P.max_keep);
+  auto ep = [&](unsigned long long i) { return mjd[keep_index(i, n_obs, P.max_keep)]; };
+  auto window = [&](unsigned long long anchor, unsigned long long& lo, unsigned long long& hi) {
+    const double t0 = ep(anchor);
+    lo = anchor + 2;
+    while (lo < n && ep(lo) - t0 < P.dt_min) ++lo;
+    hi = lo - 1;  // lo >= 2
+    if (hi < anchor + 1) hi = anchor + 1;
+    while (hi + 1 < n && ep(hi + 1) - t0 <= P.dt_max) ++hi;
+  };
+  unsigned len = 0;
+  unsigned long long lo, hi;
+  if (n >= 3) window(0, lo, hi); else { lo = n; hi = 0; }
+  unsigned long long anchor = 0, middle = 1, last = lo > 2 ? lo : 2;
+  for (;;) {
+    if (anchor + 2 >= n) break;
+    const bool empty = lo >= n || lo > hi || hi <= anchor + 1;
+    if (empty || middle >= hi) {
+      anchor += 1;
+      if (anchor + 2 >= n) break;
+      window(anchor, lo, hi);
+      middle = anchor + 1;
+      last = lo > middle + 1 ? lo : middle + 1;
+      continue;
+    }
+    if (last <= middle) last = lo > middle + 1 ? lo : middle + 1;
+    if (last > hi) {
+      middle += 1;
+      last = lo > middle + 1 ? lo : middle + 1;
+      continue;
+    }
+    const unsigned long long f = anchor, m = middle, l = last;
+    last += 1;
+    const double tm = ep(m);
+    const double w = s_gap(tm - ep(f), P.inv_dtw) + s_gap(ep(l) - tm, P.inv_dtw);
+    if (!isfinite(w)) continue;
+    const unsigned long long id = pack_triplet((unsigned)f, (unsigned)m, (unsigned)l);
+    if (len < P.k_cap) {
+      heap_sift_up(h, 0, len, w, id);
+      ++len;
+    } else if (w < h.W(0)) {
+      heap_pop(h, len);
+      heap_sift_up(h, 0, len, w, id);
+      ++len;
+    }
+  }
+  // sort_unstable_by(weight) restated as a stable insertion sort (equal weights keep heap order)
+  for (unsigned i = 1; i < len; ++i) {
+    const double xw = h.W(i);
+    const unsigned long long xi = h.I(i);
+    unsigned j = i;
+    while (j > 0 && h.W(j - 1) > xw) { h.move(j, j - 1); --j; }
+    h.set(j, xw, xi);
+  }
+  return len;
+}
+
+}  // namespace outfit
