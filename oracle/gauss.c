@@ -23,6 +23,9 @@ static inline double colnorm(const double A[3][3], int c) {
   return sqrt((A[0][c] * A[0][c] + A[1][c] * A[1][c]) + A[2][c] * A[2][c]);
 }
 
+/* debug statistics (single-threaded use only): iterations run by the last correction loop */
+int orc_dbg_corr_iters = 0;
+
 /* nalgebra 0.34 try_inverse, 3x3 branch (adjugate / determinant) — pinned
  * bit-exactly by gauss.rs:1470-1487. */
 static int inv3(const double m[3][3], double o[3][3]) {
@@ -171,6 +174,7 @@ int orc_pos_and_vel_correction(const orc_gauss_obs *g, const outfit_iod_params_t
   if (fabs(dt01) <= ORC_EPS || fabs(dt21) <= ORC_EPS) return 0;
 
   for (uint64_t it = 0; it < itmax; ++it) {
+    orc_dbg_corr_iters = (int)it + 1;
     double r1[3] = {pos[0][0], pos[1][0], pos[2][0]};
     double r2[3] = {pos[0][1], pos[1][1], pos[2][1]};
     double r3[3] = {pos[0][2], pos[1][2], pos[2][2]};
@@ -214,6 +218,7 @@ int orc_pos_and_vel_correction(const orc_gauss_obs *g, const outfit_iod_params_t
   *epoch_out = epoch;
   return 1;
 }
+
 
 /* gauss.rs:906-923 (ROT_EQUMJ2000_TO_ECLMJ2000, constants.rs:93-103) + orbit_type/mod.rs:281-287 */
 static void orbit_from_state(const double pos[3][3], const double vel[3], double epoch,

@@ -76,9 +76,9 @@ struct DevBuf {
   }
 };
 
-enum KernelId { K_TRIPLETS = 0, K_PREPASS = 1, K_CANDIDATE = 2, K_SELECT = 3, K_COUNT = 4 };
-const char* const kKernelNames[K_COUNT] = {"k_triplet_select", "k_observer_prepass", "k_gauss_candidate",
-                                           "k_select_best"};
+enum KernelId { K_TRIPLETS = 0, K_PREPASS = 1, K_ROOTS = 2, K_CORRECT = 3, K_RMS = 4, K_SELECT = 5, K_COUNT = 6 };
+const char* const kKernelNames[K_COUNT] = {"k_triplet_select", "k_observer_prepass", "k_gauss_roots",
+                                           "k_gauss_correct",  "k_orbit_rms",        "k_select_best"};
 
 }  // namespace
 
@@ -92,9 +92,10 @@ struct outfit_hip_session {
 
   DevBuf<unsigned long long> traj_offset;
   DevBuf<double> mjd, ra, dec, sra, sdec, helio, geo, obs_pos, noise, coef;
-  DevBuf<double> heap_w, sum, el_epoch, el;
-  DevBuf<unsigned long long> heap_id, triplets;
+  DevBuf<double> heap_w, sum, el, dirS, roots, state;
+  DevBuf<unsigned long long> heap_id, triplets, queue;
   DevBuf<unsigned> n_triplets, flags, n_win;
+  unsigned n_cu = 256;
   DevBuf<outfit::GaussResultRec> results;
   DevBuf<int> error_flag;
   outfit::EphemTable table{};
@@ -106,15 +107,15 @@ struct outfit_hip_session {
   bool profiling = false;
   struct Timed { int id; hipEvent_t a, b; };
   std::vector<Timed> timed;
-  float kernel_ms[K_COUNT] = {0, 0, 0, 0};
-  int kernel_launches[K_COUNT] = {0, 0, 0, 0};
+  float kernel_ms[K_COUNT] = {0, 0, 0, 0, 0, 0};
+  int kernel_launches[K_COUNT] = {0, 0, 0, 0, 0, 0};
 
   void free_all() {
     traj_offset.release(); mjd.release(); ra.release(); dec.release(); sra.release(); sdec.release();
     helio.release(); geo.release(); obs_pos.release(); noise.release(); coef.release();
-    heap_w.release(); sum.release(); el_epoch.release(); el.release(); heap_id.release();
-    triplets.release(); n_triplets.release(); flags.release(); n_win.release(); results.release();
-    error_flag.release();
+    heap_w.release(); sum.release(); el.release(); dirS.release(); roots.release(); state.release();
+    heap_id.release(); triplets.release(); queue.release(); n_triplets.release(); flags.release();
+    n_win.release(); results.release(); error_flag.release();
     for (auto& t : timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     timed.clear();
     if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -215,9 +216,9 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
   HIP_TRY(s->error_flag.alloc(1));
   HIP_TRY(hipMemset(s->error_flag.p, 0, sizeof(int)));
 
-  // chunking: bound the candidate scratch (72 B per candidate) and the heap scratch
+  // chunking: bound the candidate scratch (256 B per candidate) and the heap scratch
   uint64_t chunk = 131072;
-  if (s->cand_per_traj) chunk = std::min<uint64_t>(chunk, std::max<uint64_t>(1, (16ull << 20) / s->cand_per_traj));
+  if (s->cand_per_traj) chunk = std::min<uint64_t>(chunk, std::max<uint64_t>(1, (12ull << 20) / s->cand_per_traj));
   chunk = std::max<uint64_t>(1, std::min<uint64_t>(chunk, s->n_traj));
   s->chunk = chunk;
   const size_t n_cand = (size_t)chunk * s->cand_per_traj;
@@ -229,8 +230,14 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
   HIP_TRY(s->flags.alloc(n_cand));
   HIP_TRY(s->n_win.alloc(n_cand));
   HIP_TRY(s->sum.alloc(n_cand));
-  HIP_TRY(s->el_epoch.alloc(n_cand));
   HIP_TRY(s->el.alloc(6 * n_cand));
+  HIP_TRY(s->dirS.alloc(9 * n_cand));
+  HIP_TRY(s->roots.alloc((size_t)outfit::kRootSlots * n_cand));
+  HIP_TRY(s->state.alloc(7 * n_cand));
+  HIP_TRY(s->queue.alloc(1));
+  int n_cu = 0;
+  HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, s->device));
+  s->n_cu = n_cu > 0 ? (unsigned)n_cu : 256u;
 
   s->gp.max_ecc = params->max_ecc;
   s->gp.max_perihelion_au = params->max_perihelion_au;
@@ -300,23 +307,33 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
       Stamp stamp(s, st, K_TRIPLETS);
       HIP_TRY(outfit::launch_triplet_select(ta, st));
     }
-    outfit::CandidateArgs ca{};
-    ca.n_cand = n_cand; ca.traj0 = t0; ca.cand_per_traj = s->cand_per_traj; ca.n_real = s->n_real;
-    ca.k_cap = s->k_cap; ca.traj_offset = s->traj_offset.p;
-    ca.mjd = s->mjd.p; ca.ra = s->ra.p; ca.dec = s->dec.p; ca.sra = s->sra.p; ca.sdec = s->sdec.p;
-    ca.helio = s->helio.p; ca.obs_pos = obs_pos; ca.noise_z = s->noise.p;
-    ca.n_triplets = s->n_triplets.p; ca.triplets = s->triplets.p; ca.P = s->gp;
-    ca.extf = s->params.extf; ca.dtmax = s->params.dtmax; ca.noise_scale = s->params.noise_scale;
-    ca.flags = s->flags.p; ca.n_win = s->n_win.p; ca.sum = s->sum.p; ca.el_epoch = s->el_epoch.p;
-    ca.el = s->el.p;
+    outfit::CandidateIndex ci{};
+    ci.n_cand = n_cand; ci.traj0 = t0; ci.cand_per_traj = s->cand_per_traj; ci.n_real = s->n_real;
+    ci.k_cap = s->k_cap; ci.traj_offset = s->traj_offset.p;
+    ci.n_triplets = s->n_triplets.p; ci.triplets = s->triplets.p;
+    ci.mjd = s->mjd.p; ci.ra = s->ra.p; ci.dec = s->dec.p; ci.sra = s->sra.p; ci.sdec = s->sdec.p;
+    ci.helio = s->helio.p; ci.noise_z = s->noise.p; ci.noise_scale = s->params.noise_scale;
+    outfit::CandidateScratch w{};
+    w.flags = s->flags.p; w.S = s->dirS.p; w.roots = s->roots.p; w.state = s->state.p; w.el = s->el.p;
+    w.sum = s->sum.p; w.n_win = s->n_win.p;
     {
-      Stamp stamp(s, st, K_CANDIDATE);
-      HIP_TRY(outfit::launch_gauss_candidate(ca, st));
+      outfit::RootsArgs ra{ci, w, s->gp};
+      Stamp stamp(s, st, K_ROOTS);
+      HIP_TRY(outfit::launch_gauss_roots(ra, st));
+    }
+    {
+      outfit::CorrectArgs ca{ci, w, s->gp, s->queue.p};
+      Stamp stamp(s, st, K_CORRECT);
+      HIP_TRY(outfit::launch_gauss_correct(ca, s->n_cu, st));
+    }
+    {
+      outfit::RmsArgs ra{ci, w, obs_pos, s->params.extf, s->params.dtmax};
+      Stamp stamp(s, st, K_RMS);
+      HIP_TRY(outfit::launch_orbit_rms(ra, st));
     }
     outfit::SelectArgs sa{};
     sa.n_traj = nt; sa.traj0 = t0; sa.n_cand = n_cand; sa.cand_per_traj = s->cand_per_traj;
-    sa.n_real = s->n_real; sa.n_triplets = s->n_triplets.p; sa.flags = s->flags.p; sa.n_win = s->n_win.p;
-    sa.sum = s->sum.p; sa.el_epoch = s->el_epoch.p; sa.el = s->el.p;
+    sa.n_real = s->n_real; sa.n_triplets = s->n_triplets.p; sa.W = w;
     sa.out = d_out ? d_out : s->results.p;
     {
       Stamp stamp(s, st, K_SELECT);

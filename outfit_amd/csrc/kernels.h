@@ -8,15 +8,18 @@
 
 namespace outfit {
 
-constexpr unsigned kCandBlock = 256;  // lanes per workgroup of the candidate kernel
+constexpr unsigned kRootSlots = 8;       // a degree-8 polynomial has at most 8 roots
+constexpr unsigned kCorrectBlock = 256;  // lanes per workgroup of the correction kernel
+constexpr unsigned kCorrectLdsDoubles = 34;  // per lane: S, S^-1, observer matrix (27) + prelim state (7)
 
-// per-candidate flag word written by K2 and replayed by K3
+// per-candidate flag word (phase A writes it, phase B/C update it, K3 replays it)
 constexpr unsigned kFlagEmpty = 0x80000000u;  // slot beyond n_triplets (never read by K3)
 constexpr unsigned kFlagOk = 0x10u;           // prelim_orbit returned Ok; low nibble = cause otherwise
 constexpr unsigned kFlagCorrected = 0x20u;    // GaussResult::CorrectedOrbit
 constexpr unsigned kFlagCometary = 0x40u;     // OrbitalElements::Cometary
 constexpr unsigned kFlagRmsErr = 0x80u;       // an ephemeris_error returned Err
 constexpr unsigned kFlagConvShift = 8;        // 3 bits: to_equinoctial error (3 / 4)
+constexpr unsigned kFlagRootsShift = 12;      // 4 bits: number of filtered roots (phase A -> B)
 
 // same 96-byte layout as outfit_gauss_result_t (include/outfit_hip.h)
 struct GaussResultRec {
@@ -47,37 +50,61 @@ struct PrepassArgs {
   int* error_flag;
 };
 
-struct CandidateArgs {
+// Inputs every candidate-level kernel needs to find its triplet
+struct CandidateIndex {
   unsigned long long n_cand, traj0;
   unsigned cand_per_traj, n_real, k_cap;
   const unsigned long long* traj_offset;
-  const double *mjd, *ra, *dec, *sra, *sdec, *helio, *obs_pos, *noise_z;
   const unsigned* n_triplets;
   const unsigned long long* triplets;
+  const double *mjd, *ra, *dec, *sra, *sdec, *helio, *noise_z;
+  double noise_scale;
+};
+
+// candidate-level scratch, structure-of-arrays over the candidates of one chunk
+struct CandidateScratch {
+  unsigned* flags;   // [n_cand]
+  double* S;         // [9][n_cand]   direction matrix, m[r][c] at (3r+c)
+  double* roots;     // [kRootSlots][n_cand] filtered roots in solver order
+  double* state;     // [7][n_cand]   r2[3], v2[3], epoch (equatorial J2000)
+  double* el;        // [6][n_cand]
+  double* sum;       // [n_cand]
+  unsigned* n_win;   // [n_cand]
+};
+
+struct RootsArgs {
+  CandidateIndex I;
+  CandidateScratch W;
   GaussParams P;
-  double extf, dtmax, noise_scale;
-  unsigned* flags;
-  unsigned* n_win;
-  double* sum;
-  double* el_epoch;
-  double* el;  // [6][n_cand]
+};
+
+struct CorrectArgs {
+  CandidateIndex I;
+  CandidateScratch W;
+  GaussParams P;
+  unsigned long long* queue;  // work-queue head (zeroed before every launch)
+};
+
+struct RmsArgs {
+  CandidateIndex I;
+  CandidateScratch W;
+  const double* obs_pos;
+  double extf, dtmax;
 };
 
 struct SelectArgs {
   unsigned long long n_traj, traj0, n_cand;
   unsigned cand_per_traj, n_real;
   const unsigned* n_triplets;
-  const unsigned* flags;
-  const unsigned* n_win;
-  const double* sum;
-  const double* el_epoch;
-  const double* el;
+  CandidateScratch W;
   GaussResultRec* out;  // indexed by absolute trajectory
 };
 
 hipError_t launch_triplet_select(const TripletArgs& a, hipStream_t s);
 hipError_t launch_observer_prepass(const PrepassArgs& a, hipStream_t s);
-hipError_t launch_gauss_candidate(const CandidateArgs& a, hipStream_t s);
+hipError_t launch_gauss_roots(const RootsArgs& a, hipStream_t s);
+hipError_t launch_gauss_correct(const CorrectArgs& a, unsigned n_cu, hipStream_t s);
+hipError_t launch_orbit_rms(const RmsArgs& a, hipStream_t s);
 hipError_t launch_select_best(const SelectArgs& a, hipStream_t s);
 hipError_t launch_propagate_universal(unsigned long long n, const double* rv, const double* t0,
                                       const double* t1, double convergency, double* out, int* status,
