@@ -206,6 +206,11 @@ int outfit_hip_propagate_universal(uint64_t n, const double *r0v0 /* 6n */,
                                    double *out /* 11n */, int32_t *status /* n */);
 
 /* ---- diagnostics ------------------------------------------------------------ */
+/* Device self-test: the kernels replace some fp64 divisions by cheaper sequences that
+ * must give the SAME bits as IEEE division (outfit_amd/csrc/device/fastdiv.hpp); this
+ * compares them with `/` on n_pairs pseudo-random operand pairs and returns the number
+ * of differing results (must be 0). No counterpart in the reference. */
+int outfit_hip_selftest_division(uint64_t n_pairs, uint64_t seed, uint64_t *mismatches);
 const char *outfit_hip_last_error(void); /* thread-local, never NULL */
 int         outfit_hip_abi_version(void);
 int         outfit_hip_device_count(void);

@@ -66,6 +66,7 @@ def lib():
     L.outfit_hip_propagate_universal.argtypes = [
         C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double,
         C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    L.outfit_hip_selftest_division.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
     _lib = L
     return L
 
@@ -76,6 +77,7 @@ EXPORTED_SYMBOLS = [
     "outfit_hip_session_device_results", "outfit_hip_session_kernel_times",
     "outfit_hip_session_set_profiling", "outfit_hip_session_destroy", "outfit_hip_propagate_universal",
     "outfit_hip_last_error", "outfit_hip_abi_version", "outfit_hip_device_count",
+    "outfit_hip_selftest_division",
 ]
 
 

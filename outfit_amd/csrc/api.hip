@@ -76,9 +76,10 @@ struct DevBuf {
   }
 };
 
-enum KernelId { K_TRIPLETS = 0, K_PREPASS = 1, K_ROOTS = 2, K_CORRECT = 3, K_RMS = 4, K_SELECT = 5, K_COUNT = 6 };
-const char* const kKernelNames[K_COUNT] = {"k_triplet_select", "k_observer_prepass", "k_gauss_roots",
-                                           "k_gauss_correct",  "k_orbit_rms",        "k_select_best"};
+enum KernelId { K_TRIPLETS = 0, K_PREPASS, K_ROOTS, K_PRELIM, K_CORRECT_FAST, K_CORRECT, K_RMS, K_SELECT, K_COUNT };
+const char* const kKernelNames[K_COUNT] = {"k_triplet_select", "k_observer_prepass",   "k_gauss_roots",
+                                           "k_gauss_prelim",   "k_gauss_correct_fast", "k_gauss_correct",
+                                           "k_orbit_rms",      "k_select_best"};
 
 }  // namespace
 
@@ -92,8 +93,8 @@ struct outfit_hip_session {
 
   DevBuf<unsigned long long> traj_offset;
   DevBuf<double> mjd, ra, dec, sra, sdec, helio, geo, obs_pos, noise, coef;
-  DevBuf<double> heap_w, sum, el, dirS, roots, state;
-  DevBuf<unsigned long long> heap_id, triplets, queue;
+  DevBuf<double> heap_w, sum, el, dirS, roots, state, psi0;
+  DevBuf<unsigned long long> heap_id, triplets, queue, slow_list, slow_count;
   DevBuf<unsigned> n_triplets, flags, n_win;
   unsigned n_cu = 256;
   DevBuf<outfit::GaussResultRec> results;
@@ -107,13 +108,14 @@ struct outfit_hip_session {
   bool profiling = false;
   struct Timed { int id; hipEvent_t a, b; };
   std::vector<Timed> timed;
-  float kernel_ms[K_COUNT] = {0, 0, 0, 0, 0, 0};
-  int kernel_launches[K_COUNT] = {0, 0, 0, 0, 0, 0};
+  float kernel_ms[K_COUNT] = {};
+  int kernel_launches[K_COUNT] = {};
 
   void free_all() {
     traj_offset.release(); mjd.release(); ra.release(); dec.release(); sra.release(); sdec.release();
     helio.release(); geo.release(); obs_pos.release(); noise.release(); coef.release();
     heap_w.release(); sum.release(); el.release(); dirS.release(); roots.release(); state.release();
+    psi0.release(); slow_list.release(); slow_count.release();
     heap_id.release(); triplets.release(); queue.release(); n_triplets.release(); flags.release();
     n_win.release(); results.release(); error_flag.release();
     for (auto& t : timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
@@ -218,7 +220,7 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
 
   // chunking: bound the candidate scratch (256 B per candidate) and the heap scratch
   uint64_t chunk = 131072;
-  if (s->cand_per_traj) chunk = std::min<uint64_t>(chunk, std::max<uint64_t>(1, (12ull << 20) / s->cand_per_traj));
+  if (s->cand_per_traj) chunk = std::min<uint64_t>(chunk, std::max<uint64_t>(1, (10ull << 20) / s->cand_per_traj));
   chunk = std::max<uint64_t>(1, std::min<uint64_t>(chunk, s->n_traj));
   s->chunk = chunk;
   const size_t n_cand = (size_t)chunk * s->cand_per_traj;
@@ -235,6 +237,9 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
   HIP_TRY(s->roots.alloc((size_t)outfit::kRootSlots * n_cand));
   HIP_TRY(s->state.alloc(7 * n_cand));
   HIP_TRY(s->queue.alloc(1));
+  HIP_TRY(s->psi0.alloc(2 * n_cand));
+  HIP_TRY(s->slow_list.alloc(n_cand));
+  HIP_TRY(s->slow_count.alloc(1));
   int n_cu = 0;
   HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, s->device));
   s->n_cu = n_cu > 0 ? (unsigned)n_cu : 256u;
@@ -315,14 +320,23 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
     ci.helio = s->helio.p; ci.noise_z = s->noise.p; ci.noise_scale = s->params.noise_scale;
     outfit::CandidateScratch w{};
     w.flags = s->flags.p; w.S = s->dirS.p; w.roots = s->roots.p; w.state = s->state.p; w.el = s->el.p;
-    w.sum = s->sum.p; w.n_win = s->n_win.p;
+    w.sum = s->sum.p; w.n_win = s->n_win.p; w.psi0 = s->psi0.p; w.slow_list = s->slow_list.p;
+    w.slow_count = s->slow_count.p;
     {
       outfit::RootsArgs ra{ci, w, s->gp};
       Stamp stamp(s, st, K_ROOTS);
       HIP_TRY(outfit::launch_gauss_roots(ra, st));
     }
+    const outfit::CorrectArgs ca{ci, w, s->gp, s->queue.p};
     {
-      outfit::CorrectArgs ca{ci, w, s->gp, s->queue.p};
+      Stamp stamp(s, st, K_PRELIM);
+      HIP_TRY(outfit::launch_gauss_prelim(ca, st));
+    }
+    {
+      Stamp stamp(s, st, K_CORRECT_FAST);
+      HIP_TRY(outfit::launch_gauss_correct_fast(ca, s->n_cu, st));
+    }
+    {
       Stamp stamp(s, st, K_CORRECT);
       HIP_TRY(outfit::launch_gauss_correct(ca, s->n_cu, st));
     }
@@ -504,6 +518,25 @@ int outfit_hip_fit_full_iod(const outfit_iod_params_t* params, const outfit_obs_
   }
   for (int d = 0; d < n_devices; ++d)
     if (rc[d] != OUTFIT_OK) return fail(rc[d], msg[d]);
+  return OUTFIT_OK;
+}
+
+int outfit_hip_selftest_division(uint64_t n_pairs, uint64_t seed, uint64_t* mismatches) {
+  if (!mismatches) return fail(OUTFIT_ERR_INVALID_BATCH, "NULL argument");
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+    return fail(OUTFIT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+  DevBuf<unsigned long long> d;
+  HIP_TRY(d.alloc(1));
+  hipError_t e = hipMemset(d.p, 0, sizeof(unsigned long long));
+  const unsigned long long threads = 1ull << 16, per = (n_pairs + threads - 1) / threads;
+  if (e == hipSuccess) e = outfit::launch_selftest_division(threads, per, seed, d.p, nullptr);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  unsigned long long h = 0;
+  if (e == hipSuccess) e = hipMemcpy(&h, d.p, sizeof h, hipMemcpyDeviceToHost);
+  d.release();
+  if (e != hipSuccess) return fail(OUTFIT_ERR_HIP, hipGetErrorString(e));
+  *mismatches = h;
   return OUTFIT_OK;
 }
 

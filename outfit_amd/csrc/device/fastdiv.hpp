@@ -1,0 +1,84 @@
+// fastdiv.hpp — IEEE-exact fp64 divisions with less work than the generic expansion.
+//
+// hipcc expands `a / b` (f64) into
+//   div_scale x2, rcp, 4 fma (two Newton steps on the reciprocal), mul, fma, div_fmas, div_fixup
+// which is correctly rounded. Two situations on the hot path allow the SAME bits for less:
+//
+//  * div_const: the denominators of the Stumpff series are the integer constants
+//    (2j+1)(2j+2) and (2j+2)(2j+3) (kepler/stumpff.rs:153-184). With rc = RN(1/c) known
+//    at compile time, q0 = a*rc; r = fma(-q0, c, a); q = fma(r, rc, q0) is the correctly
+//    rounded quotient (Markstein's theorem: rc correctly rounded and q0 faithful), 3
+//    operations instead of ~11.
+//  * div2_shared: num-complex's reciprocal 1/(x+iy) divides two numerators by the same
+//    |z|^2 (gauss.rs:971 via aberth). The refined reciprocal depends on the denominator
+//    only, so it is computed once; every other operation is the compiler's own sequence.
+//
+// Both fall back to `/` outside a conservative exponent window, where div_scale /
+// div_fixup would intervene. tests/test_gpu_parity.py::test_fast_division_is_exact
+// checks bit-equality with `/` on 2^27 operand pairs on the GPU.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace outfit {
+namespace fdiv {
+
+// |x| in [2^-300, 2^300] (or x == 0 for numerators): no scaling, no fix-up needed
+__device__ __forceinline__ bool in_window(double x) {
+  const double ax = fabs(x);
+  return ax >= 4.909093465297727e-91 && ax <= 2.037035976334486e+90;
+}
+
+// a / c for a compile-time constant c with rc == RN(1/c)
+__device__ __forceinline__ double div_const(double a, double c, double rc) {
+  if (!(in_window(a))) return a / c;
+  const double q0 = a * rc;
+  const double r = fma(-q0, c, a);
+  return fma(r, rc, q0);
+}
+
+// refined reciprocal exactly as in the compiler's f64 division (no scaling case)
+__device__ __forceinline__ double refined_rcp(double b) {
+  const double y0 = __builtin_amdgcn_rcp(b);
+  const double e0 = fma(-b, y0, 1.0);
+  const double y1 = fma(y0, e0, y0);
+  const double e1 = fma(-b, y1, 1.0);
+  return fma(y1, e1, y1);
+}
+__device__ __forceinline__ double div_with_rcp(double a, double b, double y) {
+  const double q = a * y;
+  const double r = fma(-b, q, a);
+  return fma(r, y, q);
+}
+
+// (a1 / b, a2 / b), bit-identical to two `/`
+__device__ __forceinline__ void div2_shared(double a1, double a2, double b, double& q1, double& q2) {
+  const bool safe = in_window(b) && (a1 == 0.0 || in_window(a1)) && (a2 == 0.0 || in_window(a2));
+  if (!safe) {
+    q1 = a1 / b;
+    q2 = a2 / b;
+    return;
+  }
+  const double y = refined_rcp(b);
+  q1 = div_with_rcp(a1, b, y);
+  q2 = div_with_rcp(a2, b, y);
+}
+
+// Stumpff-series denominators and their correctly-rounded reciprocals, term j = 1..70:
+//   s2 series: (2j+1)(2j+2)      s3 series: (2j+2)(2j+3)
+struct SeriesTable {
+  double d2[71], r2[71], d3[71], r3[71];
+};
+constexpr SeriesTable make_series_table() {
+  SeriesTable t{};
+  for (int j = 0; j <= 70; ++j) {
+    t.d2[j] = (double)((2 * j + 1) * (2 * j + 2));
+    t.d3[j] = (double)((2 * j + 2) * (2 * j + 3));
+    t.r2[j] = 1.0 / t.d2[j];  // constant-evaluated: correctly rounded
+    t.r3[j] = 1.0 / t.d3[j];
+  }
+  return t;
+}
+__device__ constexpr SeriesTable kSeries = make_series_table();
+
+}  // namespace fdiv
+}  // namespace outfit

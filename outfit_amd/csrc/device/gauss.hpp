@@ -279,12 +279,14 @@ __device__ __forceinline__ double frob(const Mat3& A) {
 // accept_root (gauss.rs:816-870): root -> positions at the three epochs, Gibbs velocity
 __device__ __forceinline__ bool accept_root(const Mat3& obs, const Mat3& S, const Mat3& Sinv, double t_mid,
                                             const GaussGeometry& q, const GaussParams& P, double r2,
-                                            Mat3& pos, Vec3& vel, double& epoch) {
+                                            Mat3& pos, Vec3& vel, double& epoch, VelCommon& vc) {
   const double r2m3 = 1.0 / (r2 * r2 * r2);
   const Vec3 c = {q.a0 + q.b0 * r2m3, -1.0, q.a2 + q.b2 * r2m3};
   if (!position_and_epoch(obs, S, Sinv, t_mid, c, P.min_rho2_au, pos, epoch)) return false;
   vel = gibbs_correction(pos, q.tau1, q.tau3);
-  const EccControl ec = eccentricity_control(column(pos, 1), vel, P.max_perihelion_au, P.max_ecc);
+  const Vec3 rm = column(pos, 1);
+  const EccControl ec = eccentricity_control(rm, vel, P.max_perihelion_au, P.max_ecc);
+  vc = velocity_common_from(ec, rm, vel);
   return ec.some && ec.accepted;
 }
 
@@ -296,44 +298,70 @@ struct CorrectionState {
   double chi01, chi21;   // warm starts of the two universal-Kepler solves
   bool has01, has21;
   unsigned it;           // iterations consumed so far
+  VelCommon vc;          // velocity.rs:105-129 evaluated on (pos[:,1], vel): shared by both sides
 };
 
-enum CorrStep { kCorrContinue = 0, kCorrSome = 1, kCorrNone = 2 };
+enum CorrStep { kCorrContinue = 0, kCorrSome = 1, kCorrNone = 2, kCorrSlow = 3 };
 
 // ONE iteration of the loop at gauss.rs:1316-1415. `continue` in the reference = return
 // kCorrContinue here (the iteration is consumed, the state is kept).
+//
+// kFast = true is the warm, regular path only: both Kepler solves start from the previous
+// iteration's chi (or the precomputed cold-start value) and every check passes; anything else
+// returns kCorrSlow and the caller hands the candidate to the general (kFast = false) kernel,
+// which replays it from its first iteration. Results are identical by construction.
+//
+// The eccentricity_control at the end of an iteration is evaluated on exactly the (r2, v2)
+// the next iteration starts from (gauss.rs:1385 vs velocity.rs:112), so its outcome is kept in
+// st.vc instead of being recomputed.
+template <bool kFast>
 __device__ __forceinline__ CorrStep correction_iteration(const Mat3& obs, const Mat3& S, const Mat3& Sinv,
                                                          double t_mid, double dt01, double dt21,
                                                          const GaussParams& P, CorrectionState& st) {
   st.it += 1;
   const bool last = st.it >= P.newton_max_it;
+  // An iteration is a pure function of (pos, vel, chi01, chi21, has01, has21). If it ends in a
+  // `continue` and leaves that tuple bit for bit unchanged, every remaining iteration repeats it
+  // and the loop ends with Some(current state) (gauss.rs:1417): return that now. This is the
+  // common fate of spurious roots, which get stuck on rho2 < min_rho2 until itmax.
+  // A `continue` before the chi update changes nothing at all, hence `rare` = Some directly.
+  const CorrStep rare = kFast ? kCorrSlow : kCorrSome;
   const Vec3 r1 = column(st.pos, 0), r2 = column(st.pos, 1), r3 = column(st.pos, 2);
+  if (!st.vc.ok) return rare;
+  const bool had_both = st.has01 && st.has21;
+  const long long chi01_old = __double_as_longlong(st.chi01), chi21_old = __double_as_longlong(st.chi21);
   // the two Lagrange corrections (t1<-t2 and t3<-t2) are independent; a rolled loop keeps ONE
   // copy of the universal-Kepler solver in the instruction stream
   VelCorr a, b;
 #pragma unroll 1
   for (int side = 0; side < 2; ++side) {
-    const VelCorr vc = velocity_correction(side ? r3 : r1, r2, st.vel, side ? dt21 : dt01,
-                                           P.max_perihelion_au, P.max_ecc, side ? st.has21 : st.has01,
-                                           side ? st.chi21 : st.chi01, P.kepler_eps);
+    const double dt = side ? dt21 : dt01;
+    const double chi = side ? st.chi21 : st.chi01;
+    const KeplerProblem p = velocity_problem(st.vc, dt, P.kepler_eps);
+    const KeplerSolution sol = kFast ? run_newton(p, chi) : solve_kepuni(p, side ? st.has21 : st.has01, chi);
+    const VelCorr vc = velocity_finish(sol, side ? r3 : r1, r2, st.vc.r2, dt);
     if (side) b = vc; else a = vc;
   }
-  if (!(a.ok && b.ok)) return last ? kCorrSome : kCorrContinue;
+  if (!(a.ok && b.ok)) return rare;
   st.has01 = true; st.chi01 = a.chi;
   st.has21 = true; st.chi21 = b.chi;
-  if (!isfinite(a.g) || !isfinite(b.g)) return last ? kCorrSome : kCorrContinue;
+  const bool fixed_point = had_both && __double_as_longlong(a.chi) == chi01_old &&
+                           __double_as_longlong(b.chi) == chi21_old;
+  const CorrStep skip = (fixed_point || last) ? kCorrSome : kCorrContinue;
+  if (!isfinite(a.g) || !isfinite(b.g)) return kFast ? kCorrSlow : skip;
   const Vec3 nv = {(a.v.x + b.v.x) * 0.5, (a.v.y + b.v.y) * 0.5, (a.v.z + b.v.z) * 0.5};
   const double fl = a.f * b.g - b.f * a.g;
-  if (!isfinite(fl) || fabs(fl) < kEps) return last ? kCorrSome : kCorrContinue;
+  if (!isfinite(fl) || fabs(fl) < kEps) return kFast ? kCorrSlow : skip;
   const double inv_f = 1.0 / fl;
   const Vec3 c = {b.g * inv_f, -1.0, -a.g * inv_f};
   Mat3 np;
   double ne;
-  if (!position_and_epoch(obs, S, Sinv, t_mid, c, P.min_rho2_au, np, ne)) return last ? kCorrSome : kCorrContinue;
-  const EccControl ec = eccentricity_control(column(np, 1), nv, P.max_perihelion_au, P.max_ecc);
-  if (!ec.some || !ec.accepted) return kCorrNone;
+  if (!position_and_epoch(obs, S, Sinv, t_mid, c, P.min_rho2_au, np, ne)) return skip;  // common
+  const Vec3 nr2 = column(np, 1);
+  const EccControl ec = eccentricity_control(nr2, nv, P.max_perihelion_au, P.max_ecc);
+  if (!ec.some || !ec.accepted) return kFast ? kCorrSlow : kCorrNone;
   const double denom = frob(np);
-  if (!isfinite(denom) || denom <= kEps) return last ? kCorrSome : kCorrContinue;
+  if (!isfinite(denom) || denom <= kEps) return kFast ? kCorrSlow : skip;
   Mat3 d;
 #pragma unroll
   for (int r = 0; r < 3; ++r)
@@ -343,6 +371,7 @@ __device__ __forceinline__ CorrStep correction_iteration(const Mat3& obs, const 
   st.pos = np;
   st.vel = nv;
   st.epoch = ne;
+  st.vc = velocity_common_from(ec, nr2, nv);
   if (rel <= P.newton_eps) return kCorrSome;
   return last ? kCorrSome : kCorrContinue;
 }

@@ -12,6 +12,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "crmath.hpp"
+#include "fastdiv.hpp"
 
 namespace outfit {
 
@@ -59,15 +60,27 @@ __device__ __forceinline__ Stumpff s_funct(double psi, double alpha) {
   if (fabs(beta) < 100.0) {
     double s2 = 0.5 * psi2, t2 = s2;
     double s3 = (s2 * psi) / 3.0, t3 = s3;
-    double d2l = 3.0, d2h = 4.0, d3l = 4.0, d3h = 5.0;
+    // term j divides by the integer constants (2j+1)(2j+2) and (2j+2)(2j+3): exact quotient
+    // from the tabulated correctly-rounded reciprocal (fastdiv.hpp), same bits as `/`
+    const bool fast = fdiv::in_window(beta);
     for (int j = 1; j <= 70; ++j) {
-      t2 *= beta / (d2l * d2h);
+      const double d2 = fdiv::kSeries.d2[j], d3 = fdiv::kSeries.d3[j];
+      double x2, x3;
+      if (fast) {
+        const double rc2 = fdiv::kSeries.r2[j], rc3 = fdiv::kSeries.r3[j];
+        const double q2 = beta * rc2, q3 = beta * rc3;
+        x2 = fma(fma(-q2, d2, beta), rc2, q2);
+        x3 = fma(fma(-q3, d3, beta), rc3, q3);
+      } else {
+        x2 = beta / d2;
+        x3 = beta / d3;
+      }
+      t2 *= x2;
       s2 += t2;
-      t3 *= beta / (d3l * d3h);
+      t3 *= x3;
       s3 += t3;
       const double a2 = fabs(t2), a3 = fabs(t3);
       if ((a2 < tol && a3 < tol) || a2 > ovf || a3 > ovf) break;
-      d2l += 2.0; d2h += 2.0; d3l += 2.0; d3h += 2.0;
     }
     return {1.0 + alpha * s2, psi + alpha * s3, s2, s3};
   }
@@ -224,10 +237,10 @@ struct KeplerSolution {
 };
 
 // kepler/newton_solver.rs:151-161,240-352 (SolverKind::NewtonRaphson)
-__device__ __forceinline__ KeplerSolution solve_kepuni(const KeplerProblem& p, bool has_guess, double guess) {
+// run_newton (newton_solver.rs:240-352) from a given start value
+__device__ __forceinline__ KeplerSolution run_newton(const KeplerProblem& p, double psi) {
   const double sqrt_mu = sqrt(kMu);
   const double res_tol = 10.0 * kEps * (1.0 + fabs(sqrt_mu * p.dt));
-  double psi = has_guess ? guess : prelim_kepuni(p);
   KeplerSolution out;
   out.ok = false;
   out.psi = psi;
@@ -254,10 +267,16 @@ __device__ __forceinline__ KeplerSolution solve_kepuni(const KeplerProblem& p, b
   return out;
 }
 
+// solve_kepuni_with_guess (newton_solver.rs:151-161): psi_guess or the cold-start value
+__device__ __forceinline__ KeplerSolution solve_kepuni(const KeplerProblem& p, bool has_guess, double guess) {
+  return run_newton(p, has_guess ? guess : prelim_kepuni(p));
+}
+
 struct EccControl {
   bool some;      // false = None (zero angular momentum)
   bool accepted;
   double ecc, peri, energy;
+  double dist, h_norm;  // |r| and |r x v| as computed on the way (reused by velocity_common_from)
 };
 
 // orb_elem.rs:257-301
@@ -268,7 +287,9 @@ __device__ __forceinline__ EccControl eccentricity_control(const Vec3& r, const 
   const double dist = norm(r);
   const Vec3 h = cross(r, v);
   const double h2 = dot(h, h);
-  o.some = !(sqrt(h2) == 0.0);
+  o.dist = dist;
+  o.h_norm = sqrt(h2);
+  o.some = !(o.h_norm == 0.0);
   const Vec3 vxh = cross(v, h);
   const double inv_mu = 1.0 / kMu, inv_d = 1.0 / dist;
   const Vec3 lenz = {vxh.x * inv_mu - r.x * inv_d, vxh.y * inv_mu - r.y * inv_d,
@@ -286,24 +307,51 @@ struct VelCorr {
   double f, g, chi;
 };
 
-// kepler/velocity.rs:94-211. Quirk Q7: only the None of eccentricity_control fails.
-__device__ __forceinline__ VelCorr velocity_correction(const Vec3& x1, const Vec3& x2, const Vec3& v2, double dt,
-                                              double peri_max, double ecc_max, bool has_guess,
-                                              double chi_guess, double eps) {
+// kepler/velocity.rs:94-211, split in two. The reference calls velocity_correction_with_guess
+// twice per iteration with the SAME (x2, v2) (gauss.rs:1325-1344): everything up to the
+// Kepler problem's (r0, sig0, alpha, e0) is identical for both calls, so it is computed once.
+// Quirk Q7: only the None of eccentricity_control fails.
+struct VelCommon {
+  bool ok;
+  double r2, sig0, alpha, e0;
+};
+__device__ __forceinline__ VelCommon velocity_common(const Vec3& x2, const Vec3& v2, double peri_max,
+                                                     double ecc_max) {
+  VelCommon c;
+  c.ok = false;
+  c.r2 = norm(x2);
+  c.sig0 = dot(x2, v2) / sqrt(kMu);
+  c.alpha = 0.0; c.e0 = 0.0;
+  const double hn = norm(cross(x2, v2));
+  if (!isfinite(hn) || hn <= 1e6 * kEps) return c;
+  const EccControl ec = eccentricity_control(x2, v2, peri_max, ecc_max);
+  if (!ec.some) return c;
+  c.alpha = 2.0 * ec.energy / kMu;
+  c.e0 = ec.ecc;
+  c.ok = true;
+  return c;
+}
+// the same, from an eccentricity_control already evaluated on (x2, v2): norm(x2) and
+// norm(x2 x v2) are the very values eccentricity_control computed (same operation order)
+__device__ __forceinline__ VelCommon velocity_common_from(const EccControl& ec, const Vec3& x2, const Vec3& v2) {
+  VelCommon c;
+  c.r2 = ec.dist;
+  c.sig0 = dot(x2, v2) / sqrt(kMu);
+  c.alpha = 2.0 * ec.energy / kMu;
+  c.e0 = ec.ecc;
+  c.ok = isfinite(ec.h_norm) && !(ec.h_norm <= 1e6 * kEps) && ec.some;
+  return c;
+}
+__device__ __forceinline__ KeplerProblem velocity_problem(const VelCommon& c, double dt, double eps) {
+  KeplerProblem p;
+  p.dt = dt; p.r0 = c.r2; p.sig0 = c.sig0; p.alpha = c.alpha; p.e0 = c.e0; p.convergency = eps;
+  return p;
+}
+// Lagrange f, g and the corrected velocity from a Kepler solution (velocity.rs:144-161)
+__device__ __forceinline__ VelCorr velocity_finish(const KeplerSolution& sol, const Vec3& x1, const Vec3& x2,
+                                                   double r2, double dt) {
   VelCorr o;
   o.ok = false;
-  const double r2 = norm(x2);
-  const double sig0 = dot(x2, v2) / sqrt(kMu);
-  const double hn = norm(cross(x2, v2));
-  if (!isfinite(hn) || hn <= 1e6 * kEps) return o;
-  const EccControl ec = eccentricity_control(x2, v2, peri_max, ecc_max);
-  if (!ec.some) return o;
-  KeplerProblem p;
-  p.dt = dt; p.r0 = r2; p.sig0 = sig0;
-  p.alpha = 2.0 * ec.energy / kMu;
-  p.e0 = ec.ecc;
-  p.convergency = eps;
-  const KeplerSolution sol = solve_kepuni(p, has_guess, chi_guess);
   if (!sol.ok) return o;
   const double f = 1.0 - sol.s.s2 / r2;
   const double g = dt - sol.s.s3 / sqrt(kMu);
@@ -313,6 +361,13 @@ __device__ __forceinline__ VelCorr velocity_correction(const Vec3& x1, const Vec
   o.f = f; o.g = g; o.chi = sol.psi;
   o.ok = true;
   return o;
+}
+__device__ __forceinline__ VelCorr velocity_correction(const Vec3& x1, const Vec3& x2, const Vec3& v2, double dt,
+                                              double peri_max, double ecc_max, bool has_guess,
+                                              double chi_guess, double eps) {
+  const VelCommon c = velocity_common(x2, v2, peri_max, ecc_max);
+  if (!c.ok) { VelCorr o; o.ok = false; return o; }
+  return velocity_finish(solve_kepuni(velocity_problem(c, dt, eps), has_guess, chi_guess), x1, x2, c.r2, dt);
 }
 
 // kepler/propagation.rs:114-207 ; out = r1[3] v1[3] f g fdot gdot psi ; returns the status code

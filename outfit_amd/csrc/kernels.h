@@ -11,6 +11,8 @@ namespace outfit {
 constexpr unsigned kRootSlots = 8;       // a degree-8 polynomial has at most 8 roots
 constexpr unsigned kCorrectBlock = 256;  // lanes per workgroup of the correction kernel
 constexpr unsigned kCorrectLdsDoubles = 34;  // per lane: S, S^-1, observer matrix (27) + prelim state (7)
+constexpr unsigned kFastBlock = 64;          // lanes per workgroup of the fast correction kernel
+constexpr unsigned kFastWavesPerSimd = 2;    // residency the fast kernel is compiled and launched for
 
 // per-candidate flag word (phase A writes it, phase B/C update it, K3 replays it)
 constexpr unsigned kFlagEmpty = 0x80000000u;  // slot beyond n_triplets (never read by K3)
@@ -20,6 +22,8 @@ constexpr unsigned kFlagCometary = 0x40u;     // OrbitalElements::Cometary
 constexpr unsigned kFlagRmsErr = 0x80u;       // an ephemeris_error returned Err
 constexpr unsigned kFlagConvShift = 8;        // 3 bits: to_equinoctial error (3 / 4)
 constexpr unsigned kFlagRootsShift = 12;      // 4 bits: number of filtered roots (phase A -> B)
+constexpr unsigned kFlagFirstShift = 16;      // 4 bits: slot of the first accepted root (K2a' -> K2b)
+constexpr unsigned kFlagSlow = 0x100000u;     // irregular candidate: handled by the general kernel
 
 // same 96-byte layout as outfit_gauss_result_t (include/outfit_hip.h)
 struct GaussResultRec {
@@ -66,6 +70,9 @@ struct CandidateScratch {
   unsigned* flags;   // [n_cand]
   double* S;         // [9][n_cand]   direction matrix, m[r][c] at (3r+c)
   double* roots;     // [kRootSlots][n_cand] filtered roots in solver order
+  double* psi0;      // [2][n_cand] cold-start values of the two universal-Kepler solves
+  unsigned long long* slow_list;   // [n_cand] candidates for the general kernel
+  unsigned long long* slow_count;  // [1]
   double* state;     // [7][n_cand]   r2[3], v2[3], epoch (equatorial J2000)
   double* el;        // [6][n_cand]
   double* sum;       // [n_cand]
@@ -103,9 +110,13 @@ struct SelectArgs {
 hipError_t launch_triplet_select(const TripletArgs& a, hipStream_t s);
 hipError_t launch_observer_prepass(const PrepassArgs& a, hipStream_t s);
 hipError_t launch_gauss_roots(const RootsArgs& a, hipStream_t s);
+hipError_t launch_gauss_prelim(const CorrectArgs& a, hipStream_t s);
+hipError_t launch_gauss_correct_fast(const CorrectArgs& a, unsigned n_cu, hipStream_t s);
 hipError_t launch_gauss_correct(const CorrectArgs& a, unsigned n_cu, hipStream_t s);
 hipError_t launch_orbit_rms(const RmsArgs& a, hipStream_t s);
 hipError_t launch_select_best(const SelectArgs& a, hipStream_t s);
+hipError_t launch_selftest_division(unsigned long long n_threads, unsigned long long n_per_thread,
+                                    unsigned long long seed, unsigned long long* d_mismatches, hipStream_t s);
 hipError_t launch_propagate_universal(unsigned long long n, const double* rv, const double* t0,
                                       const double* t1, double convergency, double* out, int* status,
                                       hipStream_t s);

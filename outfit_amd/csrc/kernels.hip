@@ -198,19 +198,177 @@ k_gauss_roots(RootsArgs a) {
 }
 
 // ------------------------------------------------------------------------------
-// K2b: persistent lanes. Each lane owns one candidate at a time and walks its
-// filtered roots in solver order exactly like the closure at gauss.rs:1147-1197:
-// accept_root -> correction loop -> first CorrectedOrbit wins (prelim_orbit,
-// gauss.rs:1238-1247), a root whose loop returns None contributes a PrelimOrbit,
-// the walk stops after max_tested_solutions pushes.
+// K2a': first accepted root and the cold-start values of its two universal-Kepler
+// solves, one lane per candidate (dense: every lane runs the expensive correctly-rounded
+// cold start at the same time instead of inside the persistent kernel's divergent trips).
+// The first iteration of pos_and_vel_correction calls solve_kepuni_with_guess with
+// psi_guess = None, i.e. run_newton(prelim_kepuni(params)) (newton_solver.rs:151-161);
+// the value prelim_kepuni(params) is what is stored here.
+// ------------------------------------------------------------------------------
+__device__ __forceinline__ void append_slow(const CandidateScratch& W, unsigned long long cid) {
+  const unsigned long long at = atomicAdd(W.slow_count, 1ull);
+  W.slow_list[at] = cid;
+}
+
+struct CandidateGeometry {
+  Mat3 S, Sinv, obs;
+  double t[3];
+  GaussGeometry q;
+};
+__device__ __forceinline__ CandidateGeometry load_geometry(const CandidateIndex& I, const CandidateScratch& W,
+                                                           unsigned long long cid) {
+  CandidateGeometry g;
+  const CandidateRef c = decode_candidate(I, cid);
+  gather_times_observer(I, c, g.t, g.obs);
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g.S.m[r][k] = W.S[(unsigned long long)(3 * r + k) * I.n_cand + cid];
+  (void)try_inverse(g.S, g.Sinv);  // non-singular: K2a checked it
+  g.q = gauss_times(g.t);
+  return g;
+}
+
+__global__ void __launch_bounds__(256)
+k_gauss_prelim(CorrectArgs a) {
+  const unsigned long long cid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long n = a.I.n_cand;
+  if (cid >= n) return;
+  const unsigned f = a.W.flags[cid];
+  if ((f & kFlagEmpty) || !(f & kFlagOk)) return;
+  const unsigned nf = (f >> kFlagRootsShift) & 0xFu;
+  const CandidateGeometry g = load_geometry(a.I, a.W, cid);
+  Mat3 pos;
+  Vec3 vel;
+  double e_pre;
+  VelCommon vc;
+  unsigned slot = 0;
+  bool accepted = false;
+  for (; slot < nf; ++slot) {
+    const double r2 = a.W.roots[(unsigned long long)slot * n + cid];
+    if (accept_root(g.obs, g.S, g.Sinv, g.t[1], g.q, a.P, r2, pos, vel, e_pre, vc)) { accepted = true; break; }
+  }
+  if (!accepted) { a.W.flags[cid] = (unsigned)kCauseNoRoots; return; }  // no solution at all
+  const double dt01 = g.t[0] - g.t[1], dt21 = g.t[2] - g.t[1];
+  bool slow = !vc.ok || fabs(dt01) <= kEps || fabs(dt21) <= kEps;
+  if (!slow) {
+    a.W.psi0[cid] = prelim_kepuni(velocity_problem(vc, dt01, a.P.kepler_eps));
+    a.W.psi0[n + cid] = prelim_kepuni(velocity_problem(vc, dt21, a.P.kepler_eps));
+  }
+  a.W.flags[cid] = kFlagOk | (nf << kFlagRootsShift) | (slot << kFlagFirstShift) | (slow ? kFlagSlow : 0u);
+  if (slow) append_slow(a.W, cid);
+}
+
+// ------------------------------------------------------------------------------
+// K2b (fast): persistent lanes, regular candidates only. A lane owns one candidate at a
+// time, restarts from the first accepted root (recomputed: cheaper than storing it) with the
+// precomputed cold-start values, and runs warm iterations until the loop ends (Some). Any
+// irregular event hands the candidate to the general kernel through the slow list.
 // ------------------------------------------------------------------------------
 constexpr unsigned kRefillThreshold = 16;  // idle lanes per wave before the queue is touched
 
+// wave-wide grab of the next queue entries for the lanes in need_mask
+__device__ __forceinline__ unsigned long long wave_grab(unsigned long long* queue, unsigned long long need_mask) {
+  const unsigned lane = __lane_id();
+  const unsigned leader = (unsigned)__ffsll((long long)need_mask) - 1u;
+  unsigned long long base = 0;
+  if (lane == leader) base = atomicAdd(queue, (unsigned long long)__popcll(need_mask));
+  base = __shfl(base, (int)leader);
+  return base + (unsigned long long)__popcll(need_mask & ((1ull << lane) - 1ull));
+}
+
+__global__ void __launch_bounds__(kFastBlock, kFastWavesPerSimd)
+k_gauss_correct_fast(CorrectArgs a) {
+  extern __shared__ double lds[];  // [27][blockDim.x]: S, S^-1, observer matrix
+  const unsigned tid = threadIdx.x, bs = blockDim.x;
+  const unsigned long long n = a.I.n_cand;
+  auto L = [&](unsigned k) -> double& { return lds[k * bs + tid]; };
+
+  long long cand = -1;
+  bool exhausted = false;
+  double t_mid = 0.0, dt01 = 0.0, dt21 = 0.0;
+  CorrectionState st{};
+
+  for (;;) {
+    const bool needy = (cand < 0) && !exhausted;
+    const unsigned long long need_mask = __ballot(needy);
+    const unsigned long long active_mask = __ballot(cand >= 0);
+    if (need_mask && ((unsigned)__popcll(need_mask) >= kRefillThreshold || active_mask == 0ull)) {
+      const unsigned long long my = wave_grab(a.queue, need_mask);
+      if (needy) {
+        if (my >= n) {
+          exhausted = true;
+        } else {
+          const unsigned f = a.W.flags[my];
+          if ((f & kFlagOk) && !(f & (kFlagEmpty | kFlagSlow))) {
+            const CandidateGeometry g = load_geometry(a.I, a.W, my);
+            const unsigned slot = (f >> kFlagFirstShift) & 0xFu;
+            double e_pre;
+            // same inputs as in K2a' -> same (pos, vel, vc); accepted there, so accepted here
+            (void)accept_root(g.obs, g.S, g.Sinv, g.t[1], g.q, a.P, a.W.roots[(unsigned long long)slot * n + my],
+                              st.pos, st.vel, e_pre, st.vc);
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+              for (int k = 0; k < 3; ++k) {
+                L(3 * r + k) = g.S.m[r][k];
+                L(9 + 3 * r + k) = g.Sinv.m[r][k];
+                L(18 + 3 * r + k) = g.obs.m[r][k];
+              }
+            t_mid = g.t[1];
+            dt01 = g.t[0] - g.t[1];
+            dt21 = g.t[2] - g.t[1];
+            st.epoch = 0.0; st.it = 0;
+            st.has01 = true; st.chi01 = a.W.psi0[my];
+            st.has21 = true; st.chi21 = a.W.psi0[n + my];
+            cand = (long long)my;
+          }
+        }
+      }
+    }
+    if (__ballot(cand >= 0) == 0ull && __ballot(!exhausted) == 0ull) break;
+    if (cand < 0) continue;
+
+    Mat3 S, Sinv, obs;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        S.m[r][k] = L(3 * r + k);
+        Sinv.m[r][k] = L(9 + 3 * r + k);
+        obs.m[r][k] = L(18 + 3 * r + k);
+      }
+    const CorrStep step = correction_iteration<true>(obs, S, Sinv, t_mid, dt01, dt21, a.P, st);
+    const unsigned long long ucand = (unsigned long long)cand;
+    if (step == kCorrSome) {
+      a.W.state[0 * n + ucand] = st.pos.m[0][1];
+      a.W.state[1 * n + ucand] = st.pos.m[1][1];
+      a.W.state[2 * n + ucand] = st.pos.m[2][1];
+      a.W.state[3 * n + ucand] = st.vel.x;
+      a.W.state[4 * n + ucand] = st.vel.y;
+      a.W.state[5 * n + ucand] = st.vel.z;
+      a.W.state[6 * n + ucand] = st.epoch;
+      a.W.flags[ucand] = kFlagOk | kFlagCorrected;
+      cand = -1;
+    } else if (step == kCorrSlow) {
+      append_slow(a.W, ucand);
+      cand = -1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------
+// K2b (general): the complete root walk of the closure at gauss.rs:1147-1197 for the
+// candidates on the slow list: accept_root -> correction loop -> first CorrectedOrbit
+// wins (prelim_orbit, gauss.rs:1238-1247), a root whose loop returns None contributes a
+// PrelimOrbit, the walk stops after max_tested_solutions pushes. Persistent lanes as above.
+// ------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kCorrectBlock, 2)
 k_gauss_correct(CorrectArgs a) {
   extern __shared__ double lds[];  // [kCorrectLdsDoubles][blockDim.x]
   const unsigned tid = threadIdx.x, bs = blockDim.x;
   const unsigned long long n = a.I.n_cand;
+  const unsigned long long n_items = *a.W.slow_count;
   auto L = [&](unsigned k) -> double& { return lds[k * bs + tid]; };
 
   long long cand = -1;
@@ -221,57 +379,39 @@ k_gauss_correct(CorrectArgs a) {
   CorrectionState st{};
 
   for (;;) {
-    // ---- refill idle lanes from the global queue (wave-uniform decisions) ----------
     const bool needy = (cand < 0) && !exhausted;
     const unsigned long long need_mask = __ballot(needy);
     const unsigned long long active_mask = __ballot(cand >= 0);
-    const unsigned n_need = (unsigned)__popcll(need_mask);
-    if (n_need && (n_need >= kRefillThreshold || active_mask == 0ull)) {
-      unsigned long long base = 0;
-      const unsigned lane = __lane_id();
-      const unsigned leader = (unsigned)__ffsll((long long)need_mask) - 1u;
-      if (lane == leader) base = atomicAdd(a.queue, (unsigned long long)n_need);
-      base = __shfl(base, (int)leader);
+    if (need_mask && ((unsigned)__popcll(need_mask) >= kRefillThreshold || active_mask == 0ull)) {
+      const unsigned long long my = wave_grab(a.queue, need_mask);
       if (needy) {
-        const unsigned rank = (unsigned)__popcll(need_mask & ((1ull << lane) - 1ull));
-        const unsigned long long my = base + rank;
-        if (my >= n) {
+        if (my >= n_items) {
           exhausted = true;
         } else {
-          const unsigned f = a.W.flags[my];
-          const unsigned nf = (f >> kFlagRootsShift) & 0xFu;
-          if ((f & kFlagOk) && !(f & kFlagEmpty) && nf > 0) {
-            cand = (long long)my;
-            n_filt = nf; slot = 0; pushes = 0; have_prelim = false; need_init = true;
-            const CandidateRef c = decode_candidate(a.I, my);
-            double t[3];
-            Mat3 obs, S, Sinv;
-            gather_times_observer(a.I, c, t, obs);
+          const unsigned long long cid = a.W.slow_list[my];
+          const unsigned f = a.W.flags[cid];
+          const CandidateGeometry g = load_geometry(a.I, a.W, cid);
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
+          for (int r = 0; r < 3; ++r)
 #pragma unroll
-              for (int k = 0; k < 3; ++k) S.m[r][k] = a.W.S[(unsigned long long)(3 * r + k) * n + my];
-            (void)try_inverse(S, Sinv);  // non-singular: phase A checked it
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-              for (int k = 0; k < 3; ++k) {
-                L(3 * r + k) = S.m[r][k];
-                L(9 + 3 * r + k) = Sinv.m[r][k];
-                L(18 + 3 * r + k) = obs.m[r][k];
-              }
-            q = gauss_times(t);
-            t_mid = t[1];
-            dt01 = t[0] - t[1];
-            dt21 = t[2] - t[1];
-          }
+            for (int k = 0; k < 3; ++k) {
+              L(3 * r + k) = g.S.m[r][k];
+              L(9 + 3 * r + k) = g.Sinv.m[r][k];
+              L(18 + 3 * r + k) = g.obs.m[r][k];
+            }
+          q = g.q;
+          t_mid = g.t[1];
+          dt01 = g.t[0] - g.t[1];
+          dt21 = g.t[2] - g.t[1];
+          cand = (long long)cid;
+          n_filt = (f >> kFlagRootsShift) & 0xFu;
+          slot = 0; pushes = 0; have_prelim = false; need_init = true;
         }
       }
     }
     if (__ballot(cand >= 0) == 0ull && __ballot(!exhausted) == 0ull) break;
     if (cand < 0) continue;
 
-    // ---- one step of this lane's candidate -------------------------------------------
     Mat3 S, Sinv, obs;
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -289,7 +429,7 @@ k_gauss_correct(CorrectArgs a) {
       while (slot < n_filt) {
         const double r2 = a.W.roots[(unsigned long long)slot * n + (unsigned long long)cand];
         double e_pre;
-        if (accept_root(obs, S, Sinv, t_mid, q, a.P, r2, st.pos, st.vel, e_pre)) {
+        if (accept_root(obs, S, Sinv, t_mid, q, a.P, r2, st.pos, st.vel, e_pre, st.vc)) {
           accepted = true;
           L(27) = st.pos.m[0][1]; L(28) = st.pos.m[1][1]; L(29) = st.pos.m[2][1];
           L(30) = st.vel.x; L(31) = st.vel.y; L(32) = st.vel.z; L(33) = e_pre;
@@ -302,7 +442,7 @@ k_gauss_correct(CorrectArgs a) {
       if (!accepted) finished = true;
       else if (fabs(dt01) <= kEps || fabs(dt21) <= kEps) step = kCorrNone;  // gauss.rs:1311-1313
     } else {
-      step = correction_iteration(obs, S, Sinv, t_mid, dt01, dt21, a.P, st);
+      step = correction_iteration<false>(obs, S, Sinv, t_mid, dt01, dt21, a.P, st);
     }
     const unsigned long long ucand = (unsigned long long)cand;
     if (step == kCorrSome) {
@@ -491,8 +631,57 @@ k_propagate_universal(unsigned long long n, const double* rv, const double* t0, 
 }
 
 // ------------------------------------------------------------------------------
+// self-test: the fast divisions of fastdiv.hpp against the compiler's `/`, bit for bit
+// ------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long& s) {
+  unsigned long long z = (s += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+// random double with a uniformly random mantissa and sign, exponent in [-e_range, e_range]
+__device__ __forceinline__ double random_double(unsigned long long& s, int e_range) {
+  const unsigned long long bits = splitmix64(s);
+  const int e = (int)(splitmix64(s) % (unsigned long long)(2 * e_range + 1)) - e_range;
+  const unsigned long long mant = bits & 0x000FFFFFFFFFFFFFull;
+  const unsigned long long sign = bits & 0x8000000000000000ull;
+  return __longlong_as_double((long long)(sign | ((unsigned long long)(1023 + e) << 52) | mant));
+}
+
+__global__ void __launch_bounds__(256)
+k_selftest_division(unsigned long long n_per_thread, unsigned long long seed, unsigned long long* mismatches) {
+  unsigned long long s = seed + 0x632BE59BD9B4E019ull * ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x + 1);
+  unsigned long long bad = 0;
+  for (unsigned long long it = 0; it < n_per_thread; ++it) {
+    // wide exponents every 8th round so that the out-of-window fallback is exercised too
+    const int er = (it & 7) == 7 ? 600 : 40;
+    const double a1 = random_double(s, er), a2 = (it & 15) == 3 ? 0.0 : random_double(s, er);
+    const double b = random_double(s, er);
+    double q1, q2;
+    fdiv::div2_shared(a1, a2, b, q1, q2);
+    const double r1 = a1 / b, r2 = a2 / b;
+    bad += (__double_as_longlong(q1) != __double_as_longlong(r1));
+    bad += (__double_as_longlong(q2) != __double_as_longlong(r2));
+    const int j = 1 + (int)(it % 70);
+    const double beta = random_double(s, (it & 7) == 7 ? 400 : 8);
+    const double d2 = fdiv::kSeries.d2[j], d3 = fdiv::kSeries.d3[j];
+    const double c2 = fdiv::div_const(beta, d2, fdiv::kSeries.r2[j]);
+    const double c3 = fdiv::div_const(beta, d3, fdiv::kSeries.r3[j]);
+    bad += (__double_as_longlong(c2) != __double_as_longlong(beta / d2));
+    bad += (__double_as_longlong(c3) != __double_as_longlong(beta / d3));
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+
+// ------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------
+hipError_t launch_selftest_division(unsigned long long n_threads, unsigned long long n_per_thread,
+                                    unsigned long long seed, unsigned long long* d_mismatches, hipStream_t s) {
+  const unsigned grid = (unsigned)((n_threads + 255) / 256);
+  hipLaunchKernelGGL(k_selftest_division, dim3(grid), dim3(256), 0, s, n_per_thread, seed, d_mismatches);
+  return hipGetLastError();
+}
 hipError_t launch_triplet_select(const TripletArgs& a, hipStream_t s) {
   if (a.n_traj == 0) return hipSuccess;
   const unsigned grid = (unsigned)((a.n_traj + 63) / 64);
@@ -511,10 +700,31 @@ hipError_t launch_gauss_roots(const RootsArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_gauss_roots, dim3(grid), dim3(256), 0, s, a);
   return hipGetLastError();
 }
+hipError_t launch_gauss_prelim(const CorrectArgs& a, hipStream_t s) {
+  if (a.I.n_cand == 0) return hipSuccess;
+  hipError_t e = hipMemsetAsync(a.W.slow_count, 0, sizeof(unsigned long long), s);
+  if (e != hipSuccess) return e;
+  const unsigned grid = (unsigned)((a.I.n_cand + 255) / 256);
+  hipLaunchKernelGGL(k_gauss_prelim, dim3(grid), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_gauss_correct_fast(const CorrectArgs& a, unsigned n_cu, hipStream_t s) {
+  if (a.I.n_cand == 0) return hipSuccess;
+  // persistent grid sized by residency (LDS: 27 doubles per lane; kFastWavesPerSimd waves per
+  // SIMD), never more workgroups than there is work; every wave exits once the queue is drained
+  const unsigned long long per_cu = (4ull * kFastWavesPerSimd * 64ull) / kFastBlock;
+  const unsigned long long want = (a.I.n_cand + kFastBlock - 1) / kFastBlock;
+  const unsigned grid = (unsigned)(want < per_cu * n_cu ? want : per_cu * n_cu);
+  const size_t lds = (size_t)27 * kFastBlock * sizeof(double);
+  hipError_t e = hipMemsetAsync(a.queue, 0, sizeof(unsigned long long), s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_gauss_correct_fast, dim3(grid), dim3(kFastBlock), lds, s, a);
+  return hipGetLastError();
+}
 hipError_t launch_gauss_correct(const CorrectArgs& a, unsigned n_cu, hipStream_t s) {
   if (a.I.n_cand == 0) return hipSuccess;
-  // persistent grid: two 256-lane workgroups per CU (LDS: 34 doubles per lane), never more
-  // workgroups than there is work; every wave exits once the queue is drained
+  // general kernel over the slow list (its length is only known on the device): a modest
+  // persistent grid, two 256-lane workgroups per CU at most
   const unsigned long long want = (a.I.n_cand + kCorrectBlock - 1) / kCorrectBlock;
   const unsigned grid = (unsigned)(want < 2ull * n_cu ? want : 2ull * n_cu);
   const size_t lds = (size_t)kCorrectLdsDoubles * kCorrectBlock * sizeof(double);

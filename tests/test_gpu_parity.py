@@ -64,6 +64,15 @@ def test_library_loads_on_gpu():
     assert _lib.lib().outfit_hip_device_count() >= 1
 
 
+def test_fast_division_is_exact():
+    """fastdiv.hpp (division by the Stumpff-series constants, shared-reciprocal complex division)
+    must return the bits of IEEE division: 2^27 operand pairs, zero mismatches."""
+    from outfit_amd import _lib
+    bad = C.c_uint64(12345)
+    assert _lib.lib().outfit_hip_selftest_division(1 << 27, 20260101, C.byref(bad)) == 0
+    assert bad.value == 0
+
+
 def test_config2_1000_objects(ephem_dict):
     """BASELINE config 2: 1000 synthetic objects x 20 obs, 100 triplets each, fp64."""
     ds = synth.make_dataset(1000, ephem=ephem_dict)
