@@ -97,6 +97,7 @@ struct outfit_hip_session {
   DevBuf<unsigned long long> heap_id, triplets, queue, slow_list, slow_count;
   DevBuf<unsigned> n_triplets, flags, n_win;
   unsigned n_cu = 256;
+  bool triplet_lds = false;  // K0 keeps its heap in LDS (small k_cap, <= 1024 reduced observations)
   DevBuf<outfit::GaussResultRec> results;
   DevBuf<int> error_flag;
   outfit::EphemTable table{};
@@ -261,6 +262,12 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
   s->tp.inv_dtw = 1.0 / params->optimal_interval_time;  // f64::recip (mod.rs:347)
   s->tp.max_keep = params->max_obs_for_triplets;
   s->tp.k_cap = params->max_triplets;
+  {
+    uint64_t max_len = 0;
+    for (uint64_t t = 0; t < s->n_traj; ++t) max_len = std::max<uint64_t>(max_len, off[t + 1] - off[t]);
+    const uint64_t reduced = std::min<uint64_t>(max_len, std::max<uint64_t>(params->max_obs_for_triplets, 3));
+    s->triplet_lds = reduced <= 1024 && (uint64_t)s->k_cap * 64 * 12 <= 160 * 1024 - 1024 && s->k_cap > 0;
+  }
   return OUTFIT_OK;
 }
 
@@ -310,7 +317,7 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
     ta.n_triplets = s->n_triplets.p; ta.triplets = s->triplets.p;
     {
       Stamp stamp(s, st, K_TRIPLETS);
-      HIP_TRY(outfit::launch_triplet_select(ta, st));
+      HIP_TRY(outfit::launch_triplet_select(ta, s->triplet_lds, st));
     }
     outfit::CandidateIndex ci{};
     ci.n_cand = n_cand; ci.traj0 = t0; ci.cand_per_traj = s->cand_per_traj; ci.n_real = s->n_real;

@@ -31,7 +31,9 @@ __device__ __forceinline__ void unpack_triplet(unsigned long long p, unsigned& i
   k = (unsigned)p & 0x1FFFFFu;
 }
 
-// Per-lane view of the heap: slot s of this lane is at [s * stride].
+// Per-lane views of the heap: slot s of this lane is at [s * stride]. Two storages:
+// global scratch with 64-bit ids (any size), and LDS with 32-bit ids (10 bits per index,
+// reduced trajectories of <= 1024 observations) for the common small case.
 struct HeapView {
   double* w;
   unsigned long long* id;
@@ -47,13 +49,34 @@ struct HeapView {
     id[dst * stride] = id[src * stride];
   }
 };
+struct LdsHeapView {
+  double* w;
+  unsigned* id;
+  unsigned stride;
+  __device__ __forceinline__ double W(unsigned s) const { return w[s * stride]; }
+  __device__ __forceinline__ unsigned long long I(unsigned s) const {
+    const unsigned p = id[s * stride];  // 10-bit fields -> the 21-bit packing
+    return pack_triplet(p >> 20, (p >> 10) & 0x3FFu, p & 0x3FFu);
+  }
+  __device__ __forceinline__ void set(unsigned s, double ww, unsigned long long ii) const {
+    unsigned i, j, k;
+    unpack_triplet(ii, i, j, k);
+    w[s * stride] = ww;
+    id[s * stride] = (i << 20) | (j << 10) | k;
+  }
+  __device__ __forceinline__ void move(unsigned dst, unsigned src) const {
+    w[dst * stride] = w[src * stride];
+    id[dst * stride] = id[src * stride];
+  }
+};
 
 // WeightedTriplet::cmp (mod.rs:135-146): weight first; indices only when a weight is NaN.
 // Weights here are finite (non-finite ones are skipped, mod.rs:382-384), so `a <= b` is wa <= wb.
 __device__ __forceinline__ bool wt_le(double wa, double wb) { return wa <= wb; }
 
 // std::collections::BinaryHeap::sift_up(start, pos) with the element held out of the array
-__device__ __forceinline__ unsigned heap_sift_up(const HeapView& h, unsigned start, unsigned pos, double ew,
+template <class View>
+__device__ __forceinline__ unsigned heap_sift_up(const View& h, unsigned start, unsigned pos, double ew,
                                         unsigned long long ei) {
   while (pos > start) {
     const unsigned parent = (pos - 1) / 2;
@@ -66,7 +89,8 @@ __device__ __forceinline__ unsigned heap_sift_up(const HeapView& h, unsigned sta
 }
 
 // BinaryHeap::pop(): swap the last element into the root, sift_down_to_bottom(0), sift_up
-__device__ __forceinline__ void heap_pop(const HeapView& h, unsigned& len) {
+template <class View>
+__device__ __forceinline__ void heap_pop(const View& h, unsigned& len) {
   const double lw = h.W(len - 1);
   const unsigned long long li = h.I(len - 1);
   --len;
@@ -105,53 +129,48 @@ __device__ __forceinline__ double s_gap(double dt, double inv_dtw) {
 
 // Enumerate, keep the best K, sort by weight (stable on the heap's vector order).
 // Returns the number of triplets; slot s of the heap then holds triplet s.
-__device__ __forceinline__ unsigned select_triplets(const double* mjd /* this trajectory */, unsigned long long n_obs,
-                                           const TripletParams& P, const HeapView& h) {
-  if (P.k_cap == 0 || n_obs < 3) return 0;
-  const unsigned long long n = reduced_len(n_obs, P.max_keep);
-  auto ep = [&](unsigned long long i) { return mjd[keep_index(i, n_obs, P.max_keep)]; };
-  auto window = [&](unsigned long long anchor, unsigned long long& lo, unsigned long long& hi) {
-    const double t0 = ep(anchor);
-    lo = anchor + 2;
-    while (lo < n && ep(lo) - t0 < P.dt_min) ++lo;
-    hi = lo - 1;  // lo >= 2
-    if (hi < anchor + 1) hi = anchor + 1;
-    while (hi + 1 < n && ep(hi + 1) - t0 <= P.dt_max) ++hi;
+//
+// The reference's TripletIndexGenerator (index_generator.rs:228-271) is a state machine that
+// emits, for each anchor with a non-empty window [lo, hi], every middle in (anchor, hi) and every
+// last in [max(lo, middle+1), hi] in lexicographic order; the nested loops below produce the
+// same sequence (the oracle keeps the literal state machine). The first gap's term of the weight
+// depends on (anchor, middle) only and is hoisted out of the innermost loop (pure function).
+template <class View>
+__device__ __forceinline__ unsigned select_triplets(const double* mjd /* this trajectory */, unsigned long long n_obs64,
+                                           const TripletParams& P, const View& h) {
+  if (P.k_cap == 0 || n_obs64 < 3) return 0;
+  const unsigned n_obs = (unsigned)n_obs64;                       // < 2^21 (checked by the host)
+  const unsigned n = (unsigned)reduced_len(n_obs64, P.max_keep);
+  const bool identity = P.max_keep >= n_obs64;
+  auto ep = [&](unsigned i) -> double {
+    return mjd[identity ? i : (unsigned)keep_index(i, n_obs, P.max_keep)];
   };
   unsigned len = 0;
-  unsigned long long lo, hi;
-  if (n >= 3) window(0, lo, hi); else { lo = n; hi = 0; }
-  unsigned long long anchor = 0, middle = 1, last = lo > 2 ? lo : 2;
-  for (;;) {
-    if (anchor + 2 >= n) break;
-    const bool empty = lo >= n || lo > hi || hi <= anchor + 1;
-    if (empty || middle >= hi) {
-      anchor += 1;
-      if (anchor + 2 >= n) break;
-      window(anchor, lo, hi);
-      middle = anchor + 1;
-      last = lo > middle + 1 ? lo : middle + 1;
-      continue;
-    }
-    if (last <= middle) last = lo > middle + 1 ? lo : middle + 1;
-    if (last > hi) {
-      middle += 1;
-      last = lo > middle + 1 ? lo : middle + 1;
-      continue;
-    }
-    const unsigned long long f = anchor, m = middle, l = last;
-    last += 1;
-    const double tm = ep(m);
-    const double w = s_gap(tm - ep(f), P.inv_dtw) + s_gap(ep(l) - tm, P.inv_dtw);
-    if (!isfinite(w)) continue;
-    const unsigned long long id = pack_triplet((unsigned)f, (unsigned)m, (unsigned)l);
-    if (len < P.k_cap) {
-      heap_sift_up(h, 0, len, w, id);
-      ++len;
-    } else if (w < h.W(0)) {
-      heap_pop(h, len);
-      heap_sift_up(h, 0, len, w, id);
-      ++len;
+  for (unsigned anchor = 0; anchor + 2 < n; ++anchor) {
+    // LastWindow::compute (index_generator.rs:94-114)
+    const double t0 = ep(anchor);
+    unsigned lo = anchor + 2;
+    while (lo < n && ep(lo) - t0 < P.dt_min) ++lo;
+    unsigned hi = lo - 1;
+    if (hi < anchor + 1) hi = anchor + 1;
+    while (hi + 1 < n && ep(hi + 1) - t0 <= P.dt_max) ++hi;
+    if (lo >= n || lo > hi || hi <= anchor + 1) continue;  // LastWindow::is_empty
+    for (unsigned middle = anchor + 1; middle < hi; ++middle) {
+      const double tm = ep(middle);
+      const double g12 = s_gap(tm - t0, P.inv_dtw);
+      for (unsigned last = lo > middle + 1 ? lo : middle + 1; last <= hi; ++last) {
+        const double w = g12 + s_gap(ep(last) - tm, P.inv_dtw);
+        if (!isfinite(w)) continue;
+        const unsigned long long id = pack_triplet(anchor, middle, last);
+        if (len < P.k_cap) {
+          heap_sift_up(h, 0, len, w, id);
+          ++len;
+        } else if (w < h.W(0)) {
+          heap_pop(h, len);
+          heap_sift_up(h, 0, len, w, id);
+          ++len;
+        }
+      }
     }
   }
   // sort_unstable_by(weight) restated as a stable insertion sort (equal weights keep heap order)

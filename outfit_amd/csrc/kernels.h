@@ -12,7 +12,7 @@ constexpr unsigned kRootSlots = 8;       // a degree-8 polynomial has at most 8 
 constexpr unsigned kCorrectBlock = 256;  // lanes per workgroup of the correction kernel
 constexpr unsigned kCorrectLdsDoubles = 34;  // per lane: S, S^-1, observer matrix (27) + prelim state (7)
 constexpr unsigned kFastBlock = 64;          // lanes per workgroup of the fast correction kernel
-constexpr unsigned kFastWavesPerSimd = 2;    // residency the fast kernel is compiled and launched for
+constexpr unsigned kFastWavesPerSimd = 3;    // residency the fast kernel is compiled and launched for
 
 // per-candidate flag word (phase A writes it, phase B/C update it, K3 replays it)
 constexpr unsigned kFlagEmpty = 0x80000000u;  // slot beyond n_triplets (never read by K3)
@@ -107,7 +107,7 @@ struct SelectArgs {
   GaussResultRec* out;  // indexed by absolute trajectory
 };
 
-hipError_t launch_triplet_select(const TripletArgs& a, hipStream_t s);
+hipError_t launch_triplet_select(const TripletArgs& a, bool lds_heap, hipStream_t s);
 hipError_t launch_observer_prepass(const PrepassArgs& a, hipStream_t s);
 hipError_t launch_gauss_roots(const RootsArgs& a, hipStream_t s);
 hipError_t launch_gauss_prelim(const CorrectArgs& a, hipStream_t s);

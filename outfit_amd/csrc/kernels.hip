@@ -47,6 +47,24 @@ k_triplet_select(TripletArgs a) {
   for (unsigned s = 0; s < n; ++s) a.triplets[lt * a.P.k_cap + s] = h.I(s);
 }
 
+// Same selection with the heap in LDS ([slot][lane]: conflict-free, ~100-cycle latency instead
+// of a round trip to L2 for every sift step). Chosen by the host when k_cap * 12 B * 64 lanes
+// fits and no reduced trajectory exceeds 1024 observations (10-bit indices).
+__global__ void __launch_bounds__(64)
+k_triplet_select_lds(TripletArgs a) {
+  extern __shared__ double lds_heap[];  // [k_cap][64] weights, then [k_cap][64] 32-bit ids
+  const unsigned long long lt = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (lt >= a.n_traj) return;
+  const unsigned long long traj = a.traj0 + lt;
+  const unsigned long long base = a.traj_offset[traj];
+  const unsigned long long n_obs = a.traj_offset[traj + 1] - base;
+  LdsHeapView h{lds_heap + threadIdx.x, reinterpret_cast<unsigned*>(lds_heap + (size_t)a.P.k_cap * 64) + threadIdx.x,
+                64u};
+  const unsigned n = select_triplets(a.mjd + base, n_obs, a.P, h);
+  a.n_triplets[lt] = n;
+  for (unsigned s = 0; s < n; ++s) a.triplets[lt * a.P.k_cap + s] = h.I(s);
+}
+
 // ------------------------------------------------------------------------------
 // K1: observer position used by the residuals. Blocks of coefficient data are
 // staged through LDS when the workgroup's epochs span at most kStageBlocks
@@ -682,10 +700,15 @@ hipError_t launch_selftest_division(unsigned long long n_threads, unsigned long 
   hipLaunchKernelGGL(k_selftest_division, dim3(grid), dim3(256), 0, s, n_per_thread, seed, d_mismatches);
   return hipGetLastError();
 }
-hipError_t launch_triplet_select(const TripletArgs& a, hipStream_t s) {
+hipError_t launch_triplet_select(const TripletArgs& a, bool lds_heap, hipStream_t s) {
   if (a.n_traj == 0) return hipSuccess;
   const unsigned grid = (unsigned)((a.n_traj + 63) / 64);
-  hipLaunchKernelGGL(k_triplet_select, dim3(grid), dim3(64), 0, s, a);
+  if (lds_heap) {
+    const size_t lds = (size_t)a.P.k_cap * 64 * (sizeof(double) + sizeof(unsigned));
+    hipLaunchKernelGGL(k_triplet_select_lds, dim3(grid), dim3(64), lds, s, a);
+  } else {
+    hipLaunchKernelGGL(k_triplet_select, dim3(grid), dim3(64), 0, s, a);
+  }
   return hipGetLastError();
 }
 hipError_t launch_observer_prepass(const PrepassArgs& a, hipStream_t s) {
