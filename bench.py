@@ -29,11 +29,29 @@ BYTES_PER_OBS_GEO = 24         # obs_geo_ecl[3] when the Earth is evaluated on d
 BYTES_PER_RESULT = 96          # outfit_gauss_result_t
 
 
+def host_cores():
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, -(-q // per)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(batch, ephem, params, n_obj_max, budget_s=15.0):
     """The CPU oracle (a restatement of the reference's Rayon path: one task per trajectory,
     dynamic scheduling) timed on the host cores, on a bounded prefix of the same workload."""
     import oracle_lib as O
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     n0 = min(n_obj_max, 64 * cores)
     sub = batch.slice(0, n0)
     t = time.perf_counter()
@@ -112,7 +130,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    ktimes = session.kernel_times()      # HIP events on the run's stream, summed over the LAST step
+    ktimes = session.kernel_times()      # HIP events on the run's stream over the whole timed region
     session.set_profiling(False)
 
     if world > 1:
@@ -128,19 +146,18 @@ def main():
         total_objects = world * n_obj
         value = total_objects * args.steps / elapsed
         # dominant kernel and its roofline (algorithmic bytes, SURVEY §8d / DESIGN.md)
-        dom = max(ktimes, key=ktimes.get) if ktimes else None
-        n_chunks = max(1, -(-n_obj // 131072))
-        launches = n_chunks
+        dom = max(ktimes, key=lambda k: ktimes[k][0]) if ktimes else None
         bytes_per_obj = (n_obs / n_obj) * (BYTES_PER_OBS_IN + BYTES_PER_OBS_GEO) + BYTES_PER_RESULT
         roof = None
         if dom:
-            avg_ms = ktimes[dom] / launches
-            units = n_obj / launches
+            total_ms, launches = ktimes[dom]
+            avg_ms = total_ms / launches
+            units = n_obj * args.steps / launches          # objects one launch processes
             achieved = units * bytes_per_obj / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                     "avg_launch_ms": avg_ms, "units_per_launch": units, "algorithmic_bytes_per_object": bytes_per_obj,
-                    "all_kernels_ms_last_step": ktimes}
+                    "all_kernels_avg_ms_per_step": {k: v[0] / args.steps for k, v in ktimes.items()}}
         line = {
             "metric": "objects/s full Gauss IOD (20 obs, 100 triplets/obj)",
             "value": value, "unit": "objects/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

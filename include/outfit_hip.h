@@ -186,11 +186,12 @@ int outfit_hip_session_run(outfit_hip_session_t *s, void *stream, void *d_out);
 int outfit_hip_session_results(outfit_hip_session_t *s, outfit_gauss_result_t *out);
 /* Device pointer of the session's own result buffer (n_traj records). */
 void *outfit_hip_session_device_results(outfit_hip_session_t *s);
-/* Per-kernel durations of the most recent run, measured with HIP events on the
- * run's stream (ms). names[i] are static strings; returns the kernel count. */
+/* Per-kernel totals since profiling was switched on: summed duration (ms, HIP events
+ * recorded on the stream each run was enqueued on) and number of launches. names[i]
+ * are static strings; returns the number of kernels reported. Synchronises. */
 int outfit_hip_session_kernel_times(outfit_hip_session_t *s, int max_n,
-                                    const char **names, float *ms);
-/* Enable/disable the per-kernel HIP-event timing above (default off). */
+                                    const char **names, float *ms, int *launches);
+/* Enable/disable the per-kernel HIP-event timing above (default off); enabling resets the totals. */
 int outfit_hip_session_set_profiling(outfit_hip_session_t *s, int enabled);
 void outfit_hip_session_destroy(outfit_hip_session_t *s);
 

@@ -59,7 +59,8 @@ def lib():
     L.outfit_hip_session_results.argtypes = [vp, C.POINTER(GaussResultC)]
     L.outfit_hip_session_device_results.argtypes = [vp]
     L.outfit_hip_session_device_results.restype = vp
-    L.outfit_hip_session_kernel_times.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float)]
+    L.outfit_hip_session_kernel_times.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float),
+                                                  C.POINTER(C.c_int)]
     L.outfit_hip_session_set_profiling.argtypes = [vp, C.c_int]
     L.outfit_hip_session_destroy.argtypes = [vp]
     L.outfit_hip_session_destroy.restype = None

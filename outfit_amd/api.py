@@ -339,12 +339,14 @@ class IODSession:
         self._L.outfit_hip_session_set_profiling(self._h, 1 if on else 0)
 
     def kernel_times(self):
-        names = (C.c_char_p * 8)()
-        ms = (C.c_float * 8)()
-        n = self._L.outfit_hip_session_kernel_times(self._h, 8, names, ms)
+        """{kernel: (total ms, launches)} since set_profiling(True)."""
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        launches = (C.c_int * 16)()
+        n = self._L.outfit_hip_session_kernel_times(self._h, 16, names, ms, launches)
         if n < 0:
             _raise_rc(n)
-        return {names[i].decode(): float(ms[i]) for i in range(n)}
+        return {names[i].decode(): (float(ms[i]), int(launches[i])) for i in range(n)}
 
     def close(self):
         if self._h:

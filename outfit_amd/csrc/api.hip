@@ -293,8 +293,6 @@ struct Stamp {
 
 int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d_out) {
   HIP_TRY(hipSetDevice(s->device));
-  for (auto& t : s->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
-  s->timed.clear();
   s->last_stream = st;
   if (s->n_traj == 0) return OUTFIT_OK;
 
@@ -453,10 +451,15 @@ void* outfit_hip_session_device_results(outfit_hip_session_t* s) { return s ? s-
 int outfit_hip_session_set_profiling(outfit_hip_session_t* s, int enabled) {
   if (!s) return fail(OUTFIT_ERR_BAD_HANDLE, "session is NULL");
   s->profiling = enabled != 0;
+  if (s->profiling) {
+    for (auto& t : s->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    s->timed.clear();
+  }
   return OUTFIT_OK;
 }
 
-int outfit_hip_session_kernel_times(outfit_hip_session_t* s, int max_n, const char** names, float* ms) {
+int outfit_hip_session_kernel_times(outfit_hip_session_t* s, int max_n, const char** names, float* ms,
+                                    int* launches) {
   if (!s) return fail(OUTFIT_ERR_BAD_HANDLE, "session is NULL");
   if (collect_times(s) != OUTFIT_OK) return OUTFIT_ERR_HIP;
   int n = 0;
@@ -464,6 +467,7 @@ int outfit_hip_session_kernel_times(outfit_hip_session_t* s, int max_n, const ch
     if (s->kernel_launches[k] == 0) continue;
     if (names) names[n] = kKernelNames[k];
     if (ms) ms[n] = s->kernel_ms[k];
+    if (launches) launches[n] = s->kernel_launches[k];
     ++n;
   }
   return n;

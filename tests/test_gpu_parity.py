@@ -177,7 +177,7 @@ def test_session_api_and_idempotence(ephem_dict):
     times = s.kernel_times()
     for k in ("k_triplet_select", "k_observer_prepass", "k_gauss_roots", "k_gauss_correct", "k_orbit_rms",
               "k_select_best"):
-        assert times.get(k, 0.0) > 0, k
+        assert times[k][0] > 0 and times[k][1] >= 1, k
     s.run()
     b = s.results()
     assert a.tobytes() == b.tobytes()  # deterministic, run to run
@@ -221,3 +221,44 @@ def test_propagate_universal(kats):
         assert rc == st[i]
         if rc == 0:
             assert np.abs(np.array(list(o)) - out[i]).max() <= 1e-11 * max(1.0, np.abs(out[i]).max())
+
+
+def test_golden_fixture_on_gpu():
+    """tests/golden/synth64_oracle.json (committed oracle output) reproduced by the HIP path."""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "synth64_oracle.json")))
+    ds = synth.make_dataset(64)
+    assert synth.dataset_sha256(ds) == g["dataset_sha256"]
+    got = outfit_amd.fit_full_iod_records(outfit_amd.ObsBatch.from_dict(ds), outfit_amd.Ephemeris.from_dict(ds["ephem"]),
+                                          synth.bench_params(outfit_amd.IODParams()), 1)
+    for r, e in zip(got, g["records"]):
+        for k in ("status", "cause", "stage", "kind", "attempts", "best_triplet", "n_triplets"):
+            assert int(r[k]) == e[k], k
+        if e["status"] == 0:
+            ref = np.array([float.fromhex(x) for x in e["elem"]])
+            assert np.abs(r["elem"][:2] - ref[:2]).max() <= TOL_LEN
+            assert ang_diff(r["elem"][2:], ref[2:]).max() <= TOL_ANG
+            assert abs(r["rms"] - float.fromhex(e["rms"])) <= 1e-9 * max(1.0, float.fromhex(e["rms"]))
+
+
+def test_full_size_properties(ephem_dict):
+    """BASELINE config 3 size (100 000 objects): properties that need no oracle — determinism across
+    runs and across chunking (sub-batches give the same records), every trajectory answered, RMS sane."""
+    ds = synth.make_dataset(100000, seed=31, ephem=ephem_dict)
+    batch = outfit_amd.ObsBatch.from_dict(ds)
+    ephem = outfit_amd.Ephemeris.from_dict(ephem_dict)
+    params = synth.bench_params(outfit_amd.IODParams())
+    a = outfit_amd.fit_full_iod_records(batch, ephem, params, 1)
+    assert set(np.unique(a["status"])) <= {0, 1, 2, 3, 4} and (a["status"] == 0).mean() > 0.98
+    ok = a["status"] == 0
+    assert np.isfinite(a["rms"][ok]).all() and np.median(a["rms"][ok]) < 3.0 and (a["elem"][ok, 1] < 1.0).all()
+    # independence of trajectories: any slice alone gives the same bytes
+    for t0, t1 in ((0, 777), (50000, 50123), (99000, 100000)):
+        b = outfit_amd.fit_full_iod_records(batch.slice(t0, t1), ephem, params, 1)
+        assert b.tobytes() == a[t0:t1].tobytes()
+    # against the oracle on a random subset
+    idx = np.sort(synth.SplitMix64(8).next_u64(300) % np.uint64(100000)).astype(int)
+    for i in idx[::10]:
+        sub = batch.slice(int(i), int(i) + 1)
+        compare(a[i:i + 1], oracle(params, sub, ephem))

@@ -1,0 +1,131 @@
+"""The C-ABI shared library without a GPU: it builds, loads, exports every symbol that
+include/outfit_hip.h declares, validates parameters like the reference's builder, and
+fails LOUDLY (no CPU fallback) when no HIP device is present."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import outfit_amd
+from outfit_amd import _abi, _lib, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    outfit_amd.build_native()
+    return _lib.lib()
+
+
+def test_library_exports_every_declared_symbol(L):
+    header = open(os.path.join(ROOT, "include", "outfit_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(outfit_hip_\w+)\s*\(", header))
+    assert declared, "no declarations found in the header"
+    assert declared == set(_lib.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert hasattr(L, name), f"{name} is declared in outfit_hip.h but not exported"
+    assert L.outfit_hip_abi_version() == _abi.ABI_VERSION
+
+
+def test_struct_layouts_match_the_header():
+    assert C.sizeof(_abi.GaussResultC) == 96
+    assert C.sizeof(_abi.IODParamsC) == 176
+    assert _abi.GaussResultC.epoch.offset == 32 and _abi.GaussResultC.rms.offset == 88
+    assert np.dtype(_abi.RESULT_DTYPE).itemsize == 96
+
+
+def test_params_default_matches_reference_defaults(L):
+    """IODParams::default() (mod.rs:308-344), and product == oracle restatement."""
+    p = outfit_amd.IODParams()
+    q = O.default_params()
+    for name, _ in _abi.IODParamsC._fields_:
+        if not name.startswith("_"):
+            assert getattr(p, name) == getattr(q, name), name
+    assert (p.n_noise_realizations, p.noise_scale, p.extf, p.dtmax) == (20, 1.0, -1.0, 30.0)
+    assert (p.dt_min, p.dt_max_triplet, p.optimal_interval_time) == (0.03, 150.0, 20.0)
+    assert (p.max_obs_for_triplets, p.max_triplets, p.gap_max) == (100, 10, 8.0 / 24.0)
+    assert (p.max_ecc, p.max_perihelion_au, p.min_rho2_au) == (5.0, 1e3, 0.01)
+    assert (p.aberth_max_iter, p.aberth_eps, p.kepler_eps) == (50, 1e-6, 1e3 * 2.220446049250313e-16)
+    assert (p.max_tested_solutions, p.r2_min_au, p.r2_max_au) == (3, 0.05, 200.0)
+    assert (p.newton_eps, p.newton_max_it, p.root_imag_eps) == (1e-10, 50, 1e-6)
+
+
+@pytest.mark.parametrize("field,bad", [
+    ("noise_scale", -1.0), ("dt_min", -0.1), ("dt_max_triplet", float("nan")), ("dtmax", -1.0),
+    ("max_ecc", -0.5), ("root_imag_eps", -1e-9), ("max_perihelion_au", 0.0), ("min_rho2_au", 0.0),
+    ("aberth_eps", 0.0), ("kepler_eps", float("nan")), ("newton_eps", 0.0), ("newton_max_it", 0),
+    ("aberth_max_iter", 0), ("max_tested_solutions", 0), ("r2_min_au", 0.0), ("r2_max_au", 0.01),
+])
+def test_builder_rejects_what_the_reference_rejects(field, bad):
+    """IODParamsBuilder::build (mod.rs:544-624)."""
+    b = outfit_amd.IODParams.builder()
+    getattr(b, field)(bad)
+    with pytest.raises(outfit_amd.InvalidIODParameter):
+        b.build()
+
+
+def test_builder_accepts_valid_and_infinite_bounds():
+    p = (outfit_amd.IODParams.builder().max_triplets(100).n_noise_realizations(0)
+         .max_perihelion_au(float("inf")).r2_min_au(0.5).r2_max_au(0.5).build())
+    assert p.max_triplets == 100 and p.r2_min_au == p.r2_max_au
+
+
+def test_malformed_batches_are_rejected_before_touching_the_gpu(L):
+    ds = synth.make_dataset(3)
+    params = synth.bench_params(outfit_amd.IODParams())
+    good = outfit_amd.ObsBatch.from_dict(ds)
+    bad = outfit_amd.ObsBatch.from_dict(ds)
+    bad.traj_offset = np.array([0, 40, 20, 60], dtype=np.uint64)
+    with pytest.raises(outfit_amd.InvalidBatch):
+        outfit_amd.fit_full_iod_records(bad, None, params)
+    with pytest.raises(outfit_amd.InvalidBatch):  # noise requested, no normals supplied
+        outfit_amd.fit_full_iod_records(good, None, outfit_amd.IODParams())
+    with pytest.raises(outfit_amd.InvalidIODParameter):
+        outfit_amd.fit_full_iod_records(good, None, outfit_amd.IODParams(n_noise_realizations=0, newton_max_it=0))
+
+
+def test_no_cpu_fallback(L):
+    """Without a HIP device the product path must fail loudly, never compute on the CPU."""
+    if L.outfit_hip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    ds = synth.make_dataset(2)
+    with pytest.raises(outfit_amd.NativeLibraryError, match="no CPU fallback"):
+        outfit_amd.fit_full_iod_records(outfit_amd.ObsBatch.from_dict(ds), None,
+                                        synth.bench_params(outfit_amd.IODParams()))
+    with pytest.raises(outfit_amd.NativeLibraryError):
+        outfit_amd.IODSession(outfit_amd.ObsBatch.from_dict(ds), None, synth.bench_params(outfit_amd.IODParams()))
+    with pytest.raises(outfit_amd.NativeLibraryError):
+        outfit_amd.propagate_universal([[1.0, 0, 0]], [[0, 0.017, 0]], 0.0, 1.0)
+
+
+def test_product_does_not_reference_the_oracle():
+    """The oracle is test infrastructure: nothing under outfit_amd/ may import, link or call it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "outfit_amd")):
+        if "_build" in dirpath or "__pycache__" in dirpath:
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle_lib" not in text and "liboutfit_oracle" not in text \
+                    and not re.search(r"\borc_\w+\(", text), \
+                    f"{os.path.join(dirpath, f)} refers to the oracle"
+
+
+def test_record_to_result_mirrors_reference_variants():
+    rec = np.zeros(1, dtype=_abi.RESULT_DTYPE)[0]
+    rec["status"], rec["stage"], rec["kind"], rec["rms"] = 0, 1, 0, 0.5
+    r = outfit_amd.api.record_to_result(rec)
+    assert isinstance(r, outfit_amd.IODGauss) and r.gauss_result.stage == "CorrectedOrbit"
+    assert r.orbital_elements().kind == "Keplerian" and r.orbit_quality() == 0.5
+    rec["status"], rec["cause"], rec["attempts"] = 2, 1, 100
+    e = outfit_amd.api.record_to_result(rec)
+    assert isinstance(e, outfit_amd.NoViableOrbit) and e.cause == "GaussNoRootsFound" and e.attempts == 100
+    rec["status"] = 1
+    assert isinstance(outfit_amd.api.record_to_result(rec), outfit_amd.NoFeasibleTriplets)
+    rec["status"] = 3
+    assert isinstance(outfit_amd.api.record_to_result(rec), outfit_amd.InvalidConversion)
