@@ -76,10 +76,10 @@ struct DevBuf {
   }
 };
 
-enum KernelId { K_TRIPLETS = 0, K_PREPASS, K_ROOTS, K_PRELIM, K_CORRECT_FAST, K_CORRECT, K_RMS, K_SELECT, K_COUNT };
+enum KernelId { K_TRIPLETS = 0, K_PREPASS, K_ROOTS, K_PRELIM, K_CORRECT_FAST, K_CORRECT, K_RMS, K_RMS_SLOW, K_SELECT, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"k_triplet_select", "k_observer_prepass",   "k_gauss_roots",
                                            "k_gauss_prelim",   "k_gauss_correct_fast", "k_gauss_correct",
-                                           "k_orbit_rms",      "k_select_best"};
+                                           "k_orbit_rms",      "k_orbit_rms_slow",     "k_select_best"};
 
 }  // namespace
 
@@ -105,6 +105,8 @@ struct outfit_hip_session {
   outfit::TripletParams tp{};
 
   hipStream_t own_stream = nullptr;
+  hipStream_t aux_stream = nullptr;  // runs K0 one chunk ahead of the candidate kernels
+  hipEvent_t ev_start = nullptr, ev_fast = nullptr, ev_general = nullptr, ev_sub[4] = {nullptr, nullptr, nullptr, nullptr};
   hipStream_t last_stream = nullptr;
   bool profiling = false;
   struct Timed { int id; hipEvent_t a, b; };
@@ -122,6 +124,12 @@ struct outfit_hip_session {
     for (auto& t : timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     timed.clear();
     if (own_stream) (void)hipStreamDestroy(own_stream);
+    if (aux_stream) (void)hipStreamDestroy(aux_stream);
+    aux_stream = nullptr;
+    for (hipEvent_t* e : {&ev_start, &ev_fast, &ev_general, &ev_sub[0], &ev_sub[1], &ev_sub[2], &ev_sub[3]}) {
+      if (*e) (void)hipEventDestroy(*e);
+      *e = nullptr;
+    }
     own_stream = nullptr;
   }
 };
@@ -174,6 +182,9 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
                   const outfit_ephem_t* eph) {
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&s->aux_stream, hipStreamNonBlocking));
+  for (hipEvent_t* e : {&s->ev_start, &s->ev_fast, &s->ev_general, &s->ev_sub[0], &s->ev_sub[1], &s->ev_sub[2], &s->ev_sub[3]})
+    HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
   s->params = *params;
   s->n_traj = b->n_traj;
   const uint64_t o0 = b->n_traj ? b->traj_offset[0] : 0;
@@ -237,7 +248,7 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
   HIP_TRY(s->dirS.alloc(9 * n_cand));
   HIP_TRY(s->roots.alloc((size_t)outfit::kRootSlots * n_cand));
   HIP_TRY(s->state.alloc(7 * n_cand));
-  HIP_TRY(s->queue.alloc(1));
+  HIP_TRY(s->queue.alloc(2));  // [0] fast kernel, [1] general kernel
   HIP_TRY(s->psi0.alloc(2 * n_cand));
   HIP_TRY(s->slow_list.alloc(n_cand));
   HIP_TRY(s->slow_count.alloc(1));
@@ -295,6 +306,7 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
   HIP_TRY(hipSetDevice(s->device));
   s->last_stream = st;
   if (s->n_traj == 0) return OUTFIT_OK;
+  hipStream_t aux = s->aux_stream;
 
   const double* obs_pos = s->helio.p;
   if (s->has_ephem && s->has_geo) {
@@ -305,18 +317,19 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
     HIP_TRY(outfit::launch_observer_prepass(pa, st));
     obs_pos = s->obs_pos.p;
   }
+  // Two latency-bound kernels run on a second stream in the shadow of VALU-bound ones:
+  //   * K0 (sequential heap per lane) in kSub slices, each one slice ahead of the K2a slice that
+  //     consumes its triplets;
+  //   * the general correction kernel (few items, long serial chains) beside K2c, which first
+  //     handles every regular candidate and then the slow list.
+  //     aux :  K0(0) K0(1) K0(2) K0(3)                      general
+  //     main:        K2a(0) K2a(1) K2a(2) K2a(3) prelim fast         rms(regular) rms(slow) select
+  constexpr unsigned kSub = 4;
   for (uint64_t t0 = 0; t0 < s->n_traj; t0 += s->chunk) {
     const uint64_t nt = std::min<uint64_t>(s->chunk, s->n_traj - t0);
     const unsigned long long n_cand = (unsigned long long)nt * s->cand_per_traj;
-    outfit::TripletArgs ta{};
-    ta.n_traj = nt; ta.traj0 = t0; ta.traj_offset = s->traj_offset.p; ta.mjd = s->mjd.p; ta.P = s->tp;
-    ta.heap_w = s->heap_w.p; ta.heap_id = s->heap_id.p;
-    ta.heap_stride = (unsigned long long)((s->chunk + 63) / 64 * 64);
-    ta.n_triplets = s->n_triplets.p; ta.triplets = s->triplets.p;
-    {
-      Stamp stamp(s, st, K_TRIPLETS);
-      HIP_TRY(outfit::launch_triplet_select(ta, s->triplet_lds, st));
-    }
+    const unsigned n_sub = nt >= 4096 * kSub ? kSub : 1;
+
     outfit::CandidateIndex ci{};
     ci.n_cand = n_cand; ci.traj0 = t0; ci.cand_per_traj = s->cand_per_traj; ci.n_real = s->n_real;
     ci.k_cap = s->k_cap; ci.traj_offset = s->traj_offset.p;
@@ -327,8 +340,27 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
     w.flags = s->flags.p; w.S = s->dirS.p; w.roots = s->roots.p; w.state = s->state.p; w.el = s->el.p;
     w.sum = s->sum.p; w.n_win = s->n_win.p; w.psi0 = s->psi0.p; w.slow_list = s->slow_list.p;
     w.slow_count = s->slow_count.p;
-    {
-      outfit::RootsArgs ra{ci, w, s->gp};
+
+    // aux waits for everything enqueued on the caller's stream so far (previous chunk included)
+    HIP_TRY(hipEventRecord(s->ev_start, st));
+    HIP_TRY(hipStreamWaitEvent(aux, s->ev_start, 0));
+    for (unsigned i = 0; i < n_sub; ++i) {
+      const uint64_t a0 = nt * i / n_sub, a1 = nt * (i + 1) / n_sub;
+      outfit::TripletArgs ta{};
+      ta.n_traj = a1 - a0; ta.traj0 = t0 + a0; ta.traj_offset = s->traj_offset.p; ta.mjd = s->mjd.p; ta.P = s->tp;
+      ta.heap_w = s->heap_w.p; ta.heap_id = s->heap_id.p;
+      ta.heap_stride = (unsigned long long)((s->chunk + 63) / 64 * 64);
+      ta.n_triplets = s->n_triplets.p + a0; ta.triplets = s->triplets.p + a0 * s->k_cap;
+      {
+        Stamp stamp(s, aux, K_TRIPLETS);
+        HIP_TRY(outfit::launch_triplet_select(ta, s->triplet_lds, aux));
+      }
+      HIP_TRY(hipEventRecord(s->ev_sub[i], aux));
+    }
+    for (unsigned i = 0; i < n_sub; ++i) {
+      const uint64_t a0 = nt * i / n_sub, a1 = nt * (i + 1) / n_sub;
+      HIP_TRY(hipStreamWaitEvent(st, s->ev_sub[i], 0));
+      outfit::RootsArgs ra{ci, w, s->gp, a0 * s->cand_per_traj, (a1 - a0) * s->cand_per_traj};
       Stamp stamp(s, st, K_ROOTS);
       HIP_TRY(outfit::launch_gauss_roots(ra, st));
     }
@@ -341,14 +373,24 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
       Stamp stamp(s, st, K_CORRECT_FAST);
       HIP_TRY(outfit::launch_gauss_correct_fast(ca, s->n_cu, st));
     }
+    HIP_TRY(hipEventRecord(s->ev_fast, st));
+    HIP_TRY(hipStreamWaitEvent(aux, s->ev_fast, 0));
     {
-      Stamp stamp(s, st, K_CORRECT);
-      HIP_TRY(outfit::launch_gauss_correct(ca, s->n_cu, st));
+      outfit::CorrectArgs cg = ca;
+      cg.queue = s->queue.p + 1;  // its own queue head
+      Stamp stamp(s, aux, K_CORRECT);
+      HIP_TRY(outfit::launch_gauss_correct(cg, s->n_cu, aux));
     }
+    HIP_TRY(hipEventRecord(s->ev_general, aux));
+    const outfit::RmsArgs rm{ci, w, obs_pos, s->params.extf, s->params.dtmax};
     {
-      outfit::RmsArgs ra{ci, w, obs_pos, s->params.extf, s->params.dtmax};
       Stamp stamp(s, st, K_RMS);
-      HIP_TRY(outfit::launch_orbit_rms(ra, st));
+      HIP_TRY(outfit::launch_orbit_rms(rm, /*slow_list=*/false, st));
+    }
+    HIP_TRY(hipStreamWaitEvent(st, s->ev_general, 0));
+    {
+      Stamp stamp(s, st, K_RMS_SLOW);
+      HIP_TRY(outfit::launch_orbit_rms(rm, /*slow_list=*/true, st));
     }
     outfit::SelectArgs sa{};
     sa.n_traj = nt; sa.traj0 = t0; sa.n_cand = n_cand; sa.cand_per_traj = s->cand_per_traj;

@@ -83,6 +83,7 @@ struct RootsArgs {
   CandidateIndex I;
   CandidateScratch W;
   GaussParams P;
+  unsigned long long cand_begin, cand_count;  // slice of the chunk's candidates handled by this launch
 };
 
 struct CorrectArgs {
@@ -113,7 +114,7 @@ hipError_t launch_gauss_roots(const RootsArgs& a, hipStream_t s);
 hipError_t launch_gauss_prelim(const CorrectArgs& a, hipStream_t s);
 hipError_t launch_gauss_correct_fast(const CorrectArgs& a, unsigned n_cu, hipStream_t s);
 hipError_t launch_gauss_correct(const CorrectArgs& a, unsigned n_cu, hipStream_t s);
-hipError_t launch_orbit_rms(const RmsArgs& a, hipStream_t s);
+hipError_t launch_orbit_rms(const RmsArgs& a, bool slow_list, hipStream_t s);
 hipError_t launch_select_best(const SelectArgs& a, hipStream_t s);
 hipError_t launch_selftest_division(unsigned long long n_threads, unsigned long long n_per_thread,
                                     unsigned long long seed, unsigned long long* d_mismatches, hipStream_t s);

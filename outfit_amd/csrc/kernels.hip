@@ -176,8 +176,9 @@ __device__ __forceinline__ void gather_times_observer(const CandidateIndex& I, c
 // ------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_gauss_roots(RootsArgs a) {
-  const unsigned long long cid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (cid >= a.I.n_cand) return;
+  const unsigned long long lid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (lid >= a.cand_count) return;
+  const unsigned long long cid = a.cand_begin + lid;
   const CandidateRef c = decode_candidate(a.I, cid);
   if (!c.live) { a.W.flags[cid] = kFlagEmpty; return; }
   const unsigned long long n = a.I.n_cand;
@@ -369,6 +370,7 @@ k_gauss_correct_fast(CorrectArgs a) {
       a.W.flags[ucand] = kFlagOk | kFlagCorrected;
       cand = -1;
     } else if (step == kCorrSlow) {
+      a.W.flags[ucand] |= kFlagSlow;  // marks it for the general kernel and the second RMS pass
       append_slow(a.W, ucand);
       cand = -1;
     }
@@ -471,7 +473,7 @@ k_gauss_correct(CorrectArgs a) {
       a.W.state[4 * n + ucand] = st.vel.y;
       a.W.state[5 * n + ucand] = st.vel.z;
       a.W.state[6 * n + ucand] = st.epoch;
-      a.W.flags[ucand] = kFlagOk | kFlagCorrected;
+      a.W.flags[ucand] = kFlagOk | kFlagCorrected | kFlagSlow;
       cand = -1;
     } else if (step == kCorrNone) {
       if (!have_prelim) {  // the first PrelimOrbit is the fallback (gauss.rs:1245-1246)
@@ -485,7 +487,7 @@ k_gauss_correct(CorrectArgs a) {
       else need_init = true;
     }
     if (finished) {
-      a.W.flags[ucand] = have_prelim ? kFlagOk : (unsigned)kCauseNoRoots;
+      a.W.flags[ucand] = have_prelim ? (kFlagOk | kFlagSlow) : (unsigned)kCauseNoRoots;
       cand = -1;
     }
   }
@@ -515,12 +517,22 @@ __device__ __forceinline__ void select_rms_interval(const double* mjd, unsigned 
   i_end = e;
 }
 
+// kSlowList = false: every candidate of the chunk except those marked kFlagSlow (their state is
+// being produced concurrently by the general correction kernel); true: exactly the slow list.
+template <bool kSlowList>
 __global__ void __launch_bounds__(256)
 k_orbit_rms(RmsArgs a) {
-  const unsigned long long cid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (cid >= a.I.n_cand) return;
+  const unsigned long long lid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long cid = lid;
+  if (kSlowList) {
+    if (lid >= *a.W.slow_count) return;
+    cid = a.W.slow_list[lid];
+  } else if (lid >= a.I.n_cand) {
+    return;
+  }
   const unsigned f0 = a.W.flags[cid];
   if ((f0 & kFlagEmpty) || !(f0 & kFlagOk)) return;
+  if (!kSlowList && (f0 & kFlagSlow)) return;
   const unsigned long long n = a.I.n_cand;
   const CandidateRef c = decode_candidate(a.I, cid);
   const Vec3 r2 = {a.W.state[0 * n + cid], a.W.state[1 * n + cid], a.W.state[2 * n + cid]};
@@ -529,7 +541,7 @@ k_orbit_rms(RmsArgs a) {
 
   // build_result -> compute_orbit_from_state -> ccek1 (gauss.rs:906-923,1063-1076)
   const Elements el = ccek1(equ_to_ecl(r2), equ_to_ecl(v2), epoch);
-  unsigned flags = (f0 & (kFlagOk | kFlagCorrected)) | (el.kind ? kFlagCometary : 0u);
+  unsigned flags = (f0 & (kFlagOk | kFlagCorrected | kFlagSlow)) | (el.kind ? kFlagCometary : 0u);
 #pragma unroll
   for (int k = 0; k < 6; ++k) a.W.el[(unsigned long long)k * n + cid] = el.e[k];
 
@@ -718,8 +730,8 @@ hipError_t launch_observer_prepass(const PrepassArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 hipError_t launch_gauss_roots(const RootsArgs& a, hipStream_t s) {
-  if (a.I.n_cand == 0) return hipSuccess;
-  const unsigned grid = (unsigned)((a.I.n_cand + 255) / 256);
+  if (a.cand_count == 0) return hipSuccess;
+  const unsigned grid = (unsigned)((a.cand_count + 255) / 256);
   hipLaunchKernelGGL(k_gauss_roots, dim3(grid), dim3(256), 0, s, a);
   return hipGetLastError();
 }
@@ -756,10 +768,17 @@ hipError_t launch_gauss_correct(const CorrectArgs& a, unsigned n_cu, hipStream_t
   hipLaunchKernelGGL(k_gauss_correct, dim3(grid), dim3(kCorrectBlock), lds, s, a);
   return hipGetLastError();
 }
-hipError_t launch_orbit_rms(const RmsArgs& a, hipStream_t s) {
+hipError_t launch_orbit_rms(const RmsArgs& a, bool slow_list, hipStream_t s) {
   if (a.I.n_cand == 0) return hipSuccess;
-  const unsigned grid = (unsigned)((a.I.n_cand + 255) / 256);
-  hipLaunchKernelGGL(k_orbit_rms, dim3(grid), dim3(256), 0, s, a);
+  if (slow_list) {
+    // the list length lives on the device: launch for 1/8 of the candidates (far above any observed
+    // slow fraction) and fall back to a second sweep only through the grid-stride guard below
+    const unsigned grid = (unsigned)((a.I.n_cand + 255) / 256);
+    hipLaunchKernelGGL(k_orbit_rms<true>, dim3(grid), dim3(256), 0, s, a);
+  } else {
+    const unsigned grid = (unsigned)((a.I.n_cand + 255) / 256);
+    hipLaunchKernelGGL(k_orbit_rms<false>, dim3(grid), dim3(256), 0, s, a);
+  }
   return hipGetLastError();
 }
 hipError_t launch_select_best(const SelectArgs& a, hipStream_t s) {
