@@ -92,7 +92,7 @@ struct outfit_hip_session {
   uint64_t chunk = 0;
 
   DevBuf<unsigned long long> traj_offset;
-  DevBuf<double> mjd, ra, dec, sra, sdec, helio, geo, obs_pos, noise, coef;
+  DevBuf<double> mjd, ra, dec, sra, sdec, helio, geo, obs_pos, cos_dec, noise, coef;
   DevBuf<double> heap_w, sum, el, dirS, roots, state, psi0;
   DevBuf<unsigned long long> heap_id, triplets, queue, slow_list, slow_count;
   DevBuf<unsigned> n_triplets, flags, n_win;
@@ -116,7 +116,7 @@ struct outfit_hip_session {
 
   void free_all() {
     traj_offset.release(); mjd.release(); ra.release(); dec.release(); sra.release(); sdec.release();
-    helio.release(); geo.release(); obs_pos.release(); noise.release(); coef.release();
+    helio.release(); geo.release(); obs_pos.release(); cos_dec.release(); noise.release(); coef.release();
     heap_w.release(); sum.release(); el.release(); dirS.release(); roots.release(); state.release();
     psi0.release(); slow_list.release(); slow_count.release();
     heap_id.release(); triplets.release(); queue.release(); n_triplets.release(); flags.release();
@@ -206,6 +206,7 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
   TRY_RC(upload(s->sra, n ? b->sigma_ra + o0 : nullptr, n));
   TRY_RC(upload(s->sdec, n ? b->sigma_dec + o0 : nullptr, n));
   TRY_RC(upload(s->helio, n ? b->obs_helio_equ + 3 * o0 : nullptr, 3 * n));
+  HIP_TRY(s->cos_dec.alloc(n));
   if (s->has_ephem && s->has_geo) {
     TRY_RC(upload(s->geo, n ? b->obs_geo_ecl + 3 * o0 : nullptr, 3 * n));
     HIP_TRY(s->obs_pos.alloc(3 * n));
@@ -308,14 +309,15 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
   if (s->n_traj == 0) return OUTFIT_OK;
   hipStream_t aux = s->aux_stream;
 
-  const double* obs_pos = s->helio.p;
-  if (s->has_ephem && s->has_geo) {
+  const bool on_device_earth = s->has_ephem && s->has_geo;
+  const double* obs_pos = on_device_earth ? s->obs_pos.p : s->helio.p;
+  {
     outfit::PrepassArgs pa{};
-    pa.n_obs = s->n_obs; pa.mjd = s->mjd.p; pa.geo_ecl = s->geo.p; pa.obs_pos = s->obs_pos.p;
+    pa.n_obs = s->n_obs; pa.mjd = s->mjd.p; pa.dec = s->dec.p; pa.geo_ecl = s->geo.p; pa.obs_pos = s->obs_pos.p;
+    pa.cos_dec = s->cos_dec.p; pa.has_table = on_device_earth;
     pa.T = s->table; pa.error_flag = s->error_flag.p;
     Stamp stamp(s, st, K_PREPASS);
     HIP_TRY(outfit::launch_observer_prepass(pa, st));
-    obs_pos = s->obs_pos.p;
   }
   // Two latency-bound kernels run on a second stream in the shadow of VALU-bound ones:
   //   * K0 (sequential heap per lane) in kSub slices, each one slice ahead of the K2a slice that
@@ -382,7 +384,7 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
       HIP_TRY(outfit::launch_gauss_correct(cg, s->n_cu, aux));
     }
     HIP_TRY(hipEventRecord(s->ev_general, aux));
-    const outfit::RmsArgs rm{ci, w, obs_pos, s->params.extf, s->params.dtmax};
+    const outfit::RmsArgs rm{ci, w, obs_pos, s->cos_dec.p, s->params.extf, s->params.dtmax};
     {
       Stamp stamp(s, st, K_RMS);
       HIP_TRY(outfit::launch_orbit_rms(rm, /*slow_list=*/false, st));

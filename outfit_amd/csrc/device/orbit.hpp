@@ -28,6 +28,24 @@ __device__ __forceinline__ Vec3 ecl_to_equ(const Vec3& v) {
           (0.0 * v.x + kCosEps * v.y) + (-kSinEps) * v.z,
           (0.0 * v.x + kSinEps * v.y) + kCosEps * v.z};
 }
+// The same product for FINITE vectors without the exact-zero terms (x + 0*y + 0*z == x,
+// 0*x + c*y == c*y whenever x, y, z are finite): used in the residual loop, where a non-finite
+// position ends in a non-finite score either way.
+__device__ __forceinline__ Vec3 ecl_to_equ_finite(const Vec3& v) {
+  return {v.x, kCosEps * v.y + (-kSinEps) * v.z, kSinEps * v.y + kCosEps * v.z};
+}
+// fmod(a, 2*pi), exactly, without the generic remainder loop when |a| < 4*pi: for
+// 2*pi <= |a| < 4*pi the subtraction is exact (Sterbenz) and equals the IEEE remainder.
+__device__ __forceinline__ double fmod_2pi(double a) {
+  const double aa = fabs(a);
+  if (aa < kTwoPi) return a;
+  if (aa < 2.0 * kTwoPi) return a < 0.0 ? a + kTwoPi : a - kTwoPi;
+  return fmod(a, kTwoPi);
+}
+__device__ __forceinline__ double principal_angle_fast(double a) {
+  const double r = fmod_2pi(a);
+  return r < 0.0 ? r + kTwoPi : r;
+}
 
 struct Elements {
   int kind;      // 0 Keplerian (a,e,i,Om,om,M) ; 1 Cometary (q,e,i,Om,om,nu)
@@ -188,7 +206,7 @@ __device__ __forceinline__ TwoBodyFrame twobody_frame(const Equinoctial& q) {
 // equinoctial_element.rs:809-867 with t0 = 0, t1 = dt ; false = Err(RootFindingError)
 __device__ __forceinline__ bool propagate_twobody(const Equinoctial& q, const TwoBodyFrame& F, double dt,
                                          Vec3& pos, Vec3& vel) {
-  double lam = principal_angle(q.lambda + F.n * (dt - 0.0));
+  double lam = principal_angle_fast(q.lambda + F.n * (dt - 0.0));
   if (lam < F.varpi) lam += kTwoPi;
   // roots::find_root_newton_raphson, SimpleConvergency{eps: 100*EPSILON, max_iter: 25}
   constexpr double eps = kEps * 1e2;
@@ -222,20 +240,20 @@ __device__ __forceinline__ bool propagate_twobody(const Equinoctial& q, const Tw
 
 // observation_ephemeris.rs:369-416 for one observation; false = Err(_)
 __device__ __forceinline__ bool ephemeris_error(const Equinoctial& q, const TwoBodyFrame& F, double mjd, double ra,
-                                       double dec, double sra, double sdec, const Vec3& obs_pos_equ,
-                                       double& term) {
+                                       double dec, double cos_dec, double sra, double sdec,
+                                       const Vec3& obs_pos_equ, double& term) {
   Vec3 pe, ve;
   if (!propagate_twobody(q, F, mjd - q.epoch, pe, ve)) return false;
-  const Vec3 pq = ecl_to_equ(pe), vq = ecl_to_equ(ve);
+  const Vec3 pq = ecl_to_equ_finite(pe), vq = ecl_to_equ_finite(ve);
   const Vec3 rel = {pq.x - obs_pos_equ.x, pq.y - obs_pos_equ.y, pq.z - obs_pos_equ.z};
   const double lt = norm(rel) / kVlightAU;
   const Vec3 cor = {rel.x - lt * vq.x, rel.y - lt * vq.y, rel.z - lt * vq.z};
   const double delta = atan2(cor.z, hypot(cor.x, cor.y));
-  double alpha = fmod(atan2(cor.y, cor.x), kTwoPi);
+  double alpha = atan2(cor.y, cor.x);  // |atan2| <= pi < 2*pi: rem_euclid(TAU) only adds 2*pi when negative
   if (alpha < 0.0) alpha += kTwoPi;
-  double da = fmod(ra - alpha, kTwoPi);  // sign of the dividend is kept (quirk Q6)
+  double da = fmod_2pi(ra - alpha);  // Rust `%`: sign of the dividend is kept (quirk Q6)
   if (da > kPi) da -= kTwoPi;
-  const double t1 = cos(dec) * (da / sra);
+  const double t1 = cos_dec * (da / sra);  // cos(dec_obs) is per observation: precomputed by K1
   const double t2 = (dec - delta) / sdec;
   term = t1 * t1 + t2 * t2;
   return true;

@@ -48,8 +48,11 @@ struct TripletArgs {
 struct PrepassArgs {
   unsigned long long n_obs;
   const double* mjd;
+  const double* dec;
   const double* geo_ecl;
   double* obs_pos;
+  double* cos_dec;
+  bool has_table;  // false: only cos(dec) is produced, the residuals use obs_helio_equ
   EphemTable T;
   int* error_flag;
 };
@@ -97,6 +100,7 @@ struct RmsArgs {
   CandidateIndex I;
   CandidateScratch W;
   const double* obs_pos;
+  const double* cos_dec;
   double extf, dtmax;
 };
 

@@ -80,6 +80,9 @@ k_observer_prepass(PrepassArgs a) {
   __shared__ int s_bad;
   const unsigned long long o = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = o < a.n_obs;
+  // cos(dec_obs) of ephemeris_error (observation_ephemeris.rs:411) depends on the observation only
+  if (live) a.cos_dec[o] = cos(a.dec[o]);
+  if (!a.has_table) return;
   if (threadIdx.x == 0) { s_min = ~0ull; s_max = 0ull; s_bad = 0; }
   __syncthreads();
   unsigned long long nr = 0;
@@ -565,7 +568,8 @@ k_orbit_rms(RmsArgs a) {
       const unsigned long long o = c.base + i;
       const Vec3 op = {a.obs_pos[3 * o], a.obs_pos[3 * o + 1], a.obs_pos[3 * o + 2]};
       double term;
-      if (!ephemeris_error(eq, F, a.I.mjd[o], a.I.ra[o], a.I.dec[o], a.I.sra[o], a.I.sdec[o], op, term)) {
+      if (!ephemeris_error(eq, F, a.I.mjd[o], a.I.ra[o], a.I.dec[o], a.cos_dec[o], a.I.sra[o], a.I.sdec[o], op,
+                           term)) {
         err = true;
         break;
       }
