@@ -76,6 +76,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--objects", type=int, default=100000, help="objects per GPU (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, the real path) or gloo (rehearsal of the N>1 logic on one GPU)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal only: every rank uses GPU 0 (needs --backend gloo)")
     args = ap.parse_args()
 
     import numpy as np
@@ -91,11 +95,17 @@ def main():
             raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if args.single_device:
+        assert args.backend == "gloo", "--single-device is a rehearsal mode: use --backend gloo"
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
 
     # ---- this rank's shard of the synthetic dataset (weak scaling: fixed objects per GPU) ----
     n_obj = args.objects
@@ -108,13 +118,17 @@ def main():
 
     session = outfit_amd.IODSession(batch, ephem, params, device=local_rank)
     out_local = torch.empty((n_obj, BYTES_PER_RESULT), dtype=torch.uint8, device="cuda")
-    out_all = torch.empty((world * n_obj, BYTES_PER_RESULT), dtype=torch.uint8, device="cuda") if world > 1 else None
+    gather_dev = "cuda" if args.backend == "nccl" else "cpu"
+    out_all = torch.empty((world * n_obj, BYTES_PER_RESULT), dtype=torch.uint8, device=gather_dev) if world > 1 else None
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
         session.run(stream=stream, d_out=out_local.data_ptr())
         if world > 1:
-            dist.all_gather_into_tensor(out_all, out_local)
+            if args.backend == "nccl":
+                dist.all_gather_into_tensor(out_all, out_local)
+            else:  # rehearsal: gloo gathers host copies
+                dist.all_gather_into_tensor(out_all, out_local.cpu())
 
     def fence():
         if world > 1:
@@ -134,7 +148,7 @@ def main():
     session.set_profiling(False)
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -1,0 +1,70 @@
+// run_full_iod.cpp — the plumbing of the reference's examples/run_full_iod.rs (BASELINE config 1)
+// through the C++ host mirror: build IODParams with the builder, hand a prepared dataset to
+// FitIOD::fit_full_iod, walk the FullOrbitResult map and print per-trajectory outcomes.
+//
+// The reference example reads tests/data/test_data_traj_str.parquet and downloads DE440 — neither
+// is available offline — so the dataset here is the reference's own OrbFit-matched triplet of
+// K09R05F (src/initial_orbit_determination/gauss.rs:1703-1755) as a 3-observation trajectory,
+// plus a 2-observation trajectory that must come back as NoFeasibleTriplets.
+//
+//   g++ -std=c++17 -Iinclude examples/run_full_iod.cpp -Loutfit_amd/csrc/_build -loutfit_hip \
+//       -Wl,-rpath,$PWD/outfit_amd/csrc/_build -o examples/_build/run_full_iod
+#include <cstdio>
+#include <cstdlib>
+
+#include "outfit_host.hpp"
+
+int main() {
+  using namespace outfit;
+  const double ra[3] = {1.6894680985108945, 1.6898614520910629, 1.7526450904422723};
+  const double dec[3] = {1.0825984522657437, 0.9436790189346231, 0.8275173215712014};
+  const double t[3] = {57028.45404759259, 57049.23185759259, 57063.95948759259};
+  const double helio[3][3] = {{-0.264135633607079, 0.869046620910086, 0.3767466856665725},
+                              {-0.5889735526505735, 0.724011718791646, 0.313873420677094},
+                              {-0.774192148350372, 0.5615102195489182, 0.2434447914016585}};
+  ObsDataset ds;
+  for (int k = 0; k < 3; ++k) {
+    Observation o{t[k], ra[k], dec[k], 1e-6, 1e-6, {helio[k][0], helio[k][1], helio[k][2]}, {0, 0, 0}};
+    ds.push("K09R05F", o);
+    if (k < 2) ds.push("too_short", o);
+  }
+  IODParams params;
+  try {
+    params = IODParams::builder().n_noise_realizations(0).max_triplets(30).build();
+    IODParams::builder().min_rho2_au(0.0).build();
+    std::fprintf(stderr, "builder accepted an invalid parameter\n");
+    return 2;
+  } catch (const InvalidIODParameter& e) {
+    std::printf("builder rejected min_rho2_au = 0: %s\n", e.what());
+  }
+  FullOrbitResult res;
+  try {
+    res = FitIOD::fit_full_iod(ds, JPLEphem{}, params);
+  } catch (const OutfitError& e) {
+    std::fprintf(stderr, "fit_full_iod failed: %s\n", e.what());
+    return 1;
+  }
+  int ok = 0;
+  for (const auto& [id, r] : res) {
+    if (auto fit = std::get_if<FitOrbitResult>(&r)) {
+      const auto& k = std::get<KeplerianElements>(fit->orbital_elements());
+      std::printf("%s: %s a=%.16g e=%.16g i=%.16g Omega=%.16g omega=%.16g M=%.16g epoch=%.11f rms=%.6g\n", id.c_str(),
+                  fit->gauss.stage == GaussResult::CorrectedOrbit ? "CorrectedOrbit" : "PrelimOrbit",
+                  k.semi_major_axis, k.eccentricity, k.inclination, k.ascending_node_longitude,
+                  k.periapsis_argument, k.mean_anomaly, k.reference_epoch, fit->rms);
+      // the reference's expected orbit (gauss.rs:1735-1747), tolerance 1e-13
+      const double exp[6] = {1.8014943988486352, 0.2835141422490807, 0.20264170920820326,
+                             8.118562444269591e-3, 1.244795311814302, 0.44065425435816186};
+      const double got[6] = {k.semi_major_axis, k.eccentricity, k.inclination, k.ascending_node_longitude,
+                             k.periapsis_argument, k.mean_anomaly};
+      bool match = std::fabs(k.reference_epoch - 57049.22904524422) < 1e-13 * 1e5;
+      for (int j = 0; j < 6; ++j) match = match && std::fabs(got[j] - exp[j]) <= 1e-13;
+      std::printf("%s: matches the reference's OrbFit orbit to 1e-13: %s\n", id.c_str(), match ? "yes" : "NO");
+      ok += match;
+    } else {
+      std::printf("%s: Err(%s)\n", id.c_str(), FitIOD::describe(std::get<TrajError>(r)).c_str());
+      ok += std::holds_alternative<NoFeasibleTriplets>(std::get<TrajError>(r));
+    }
+  }
+  return ok == 2 ? 0 : 3;
+}

@@ -262,3 +262,21 @@ def test_full_size_properties(ephem_dict):
     for i in idx[::10]:
         sub = batch.slice(int(i), int(i) + 1)
         compare(a[i:i + 1], oracle(params, sub, ephem))
+
+
+def test_cpp_host_example_config1():
+    """BASELINE config 1 (plumbing): examples/run_full_iod.cpp through include/outfit_host.hpp —
+    builder validation, fit_full_iod, FullOrbitResult with an Ok and an Err entry; the Ok orbit is the
+    reference's OrbFit-matched one (gauss.rs:1735-1747) to 1e-13."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "_build", "run_full_iod")
+    if not os.path.exists(exe):
+        import __graft_entry__ as g
+        g.build()
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "K09R05F: CorrectedOrbit" in out.stdout
+    assert "matches the reference's OrbFit orbit to 1e-13: yes" in out.stdout
+    assert "too_short: Err(NoFeasibleTriplets" in out.stdout
