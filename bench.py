@@ -168,8 +168,20 @@ def main():
             avg_ms = total_ms / launches
             units = n_obj * args.steps / launches          # objects one launch processes
             achieved = units * bytes_per_obj / (avg_ms * 1e-3) / 1e9
+            # HBM bytes of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
+            # separate runs; profiles/), scaled to one launch; null when no profile matches
+            traffic = None
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
+                key = dom.replace("k_orbit_rms_slow", "k_orbit_rms<true>").replace("k_orbit_rms", "k_orbit_rms<false>") \
+                    if dom.startswith("k_orbit_rms") else dom
+                key = {"k_triplet_select": "k_triplet_select_lds"}.get(key, key)
+                per_step = pmc["kernels"][key]["hbm_bytes_per_step"] * (n_obj / pmc["objects_per_step"])
+                traffic = per_step * args.steps / launches
+            except (OSError, KeyError, ValueError):
+                pass
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "avg_launch_ms": avg_ms, "units_per_launch": units, "algorithmic_bytes_per_object": bytes_per_obj,
                     "all_kernels_avg_ms_per_step": {k: v[0] / args.steps for k, v in ktimes.items()}}
         line = {
