@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define OUTFIT_HIP_ABI_VERSION 1
+#define OUTFIT_HIP_ABI_VERSION 2
 
 /* ---- whole-call return codes --------------------------------------------- */
 #define OUTFIT_OK                 0
@@ -205,6 +205,114 @@ int outfit_hip_propagate_universal(uint64_t n, const double *r0v0 /* 6n */,
                                    const double *t0, const double *t1,
                                    double convergency,
                                    double *out /* 11n */, int32_t *status /* n */);
+
+/* ==== next row: FitLSQ::fit_lsq — differential orbit correction =========
+ * Replaces the per-trajectory loop of `FitLSQ::fit_lsq`
+ * (differential_orbit_correction/obs_dataset_api.rs:57-130) after the dataset
+ * preparation (:68-74, stays with the caller as for fit_full_iod): for every
+ * trajectory `differential_correction` (mod.rs:66-112) = IOD seed ->
+ * to_equinoctial -> `run_differential_correction` (diff_cor.rs:282-436: Newton
+ * weighted least squares with two-body partials, chi-square outlier rejection,
+ * covariance rescaling), falling back to the IOD orbit when the corrector errs. */
+
+#define OUTFIT_PROPAGATOR_TWOBODY 0 /* PropagatorKind::TwoBody (propagator/mod.rs). NBody is not
+                                       implemented here: any other value is OUTFIT_ERR_INVALID_PARAM */
+
+/* Mirrors `DifferentialCorrectionConfig` (diff_cor.rs:39-159; defaults :161-178) with
+ * `OutlierRejectionConfig` (outlier_rejection.rs:24-55) and `EquinoctialLimits`
+ * (equinoctial_element.rs:161-179) flattened in declaration order. */
+typedef struct outfit_diffcor_config {
+  uint64_t max_newton_iterations;                  /* 30   */
+  uint64_t max_outlier_rejection_passes;           /* 10   */
+  double   convergence_threshold;                  /* 1e-4 */
+  double   convergence_before_rejection_threshold; /* 2.0  */
+  double   rms_stagnation_ratio;                   /* 0.98 */
+  double   rms_divergence_ratio;                   /* 1.5  */
+  uint64_t max_stagnation_iterations;              /* 3    */
+  uint32_t enable_outlier_rejection;               /* 1    */
+  uint32_t propagator;                             /* OUTFIT_PROPAGATOR_TWOBODY */
+  double   chi_squared_rejection_threshold;        /* 25   */
+  double   chi_squared_recovery_threshold;         /* 9    */
+  double   eccentricity_limit;                     /* 1.2  */
+  double   min_semi_major_axis;                    /* 1e-6 */
+  double   max_semi_major_axis;                    /* 1e4  */
+  double   min_periapsis_distance;                 /* 1e-6 */
+  double   max_apoapsis_distance;                  /* 1e4  */
+  uint8_t  free_elements[6];                       /* all 1: (a, h, k, p, q, lambda) */
+  uint8_t  _pad[2];
+} outfit_diffcor_config_t;
+
+/* outfit_lsq_result_t.status */
+#define OUTFIT_LSQ_DIFFCOR          0 /* Ok(FitOrbitResult::DifferentialCorrection((Equinoctial{..}, normalised_rms))) */
+#define OUTFIT_LSQ_IOD_KEPT         1 /* corrector returned Err(_) => Ok(initial_orbit) (mod.rs:109): elements are in `iod` */
+#define OUTFIT_LSQ_IOD_ERROR        2 /* no usable seed: run_iod_on_observations(..)? failed (mod.rs:86); see iod.status/cause */
+#define OUTFIT_LSQ_CONVERSION_ERROR 3 /* seed.to_equinoctial()? failed (mod.rs:89-91); conv_error = OUTFIT_TRAJ_INVALID_* */
+/* outfit_lsq_result_t.dc_error: why the corrector gave up (status IOD_KEPT) */
+#define OUTFIT_DC_NONE      0
+#define OUTFIT_DC_FAILED    1 /* OutfitError::DifferentialCorrectionFailed: normal-equation inversion failed (diff_cor.rs:335-341) */
+#define OUTFIT_DC_BIZARRE   2 /* OutfitError::BizarreOrbit (diff_cor.rs:344-349)                                                  */
+#define OUTFIT_DC_DIVERGED  3 /* OutfitError::DifferentialCorrectionDiverged (diff_cor.rs:354-356)                                */
+/* ObsSelection (obs_fit_data.rs:22-45) */
+#define OUTFIT_OBS_ACTIVE     0
+#define OUTFIT_OBS_REJECTED   1
+#define OUTFIT_OBS_FORCED_OUT 2
+
+/* `DifferentialCorrectionOutput` (diff_cor.rs:185-209) as converted by
+ * `From<DifferentialCorrectionOutput> for OrbitalElements` (:211-224), plus the seed. */
+typedef struct outfit_lsq_result {
+  int32_t  status;                  /* OUTFIT_LSQ_*                                              */
+  int32_t  dc_error;                /* OUTFIT_DC_*                                               */
+  int32_t  conv_error;              /* OUTFIT_TRAJ_INVALID_* when status == CONVERSION_ERROR     */
+  uint32_t total_newton_iterations; /* over all outer passes                                      */
+  uint32_t num_measurements;        /* 2 x active observations at the last accepted iteration     */
+  uint32_t n_rejected;              /* observations whose final selection is not Active           */
+  uint32_t outer_passes;            /* outlier-rejection passes started                           */
+  uint32_t _pad;
+  double   epoch;                   /* reference_epoch of the seed (unchanged by the corrector)   */
+  double   elem[6];                 /* equinoctial (a, h, k, p, q, lambda)                        */
+  double   normalised_rms;          /* the `Chi2` slot of FitOrbitResult::DifferentialCorrection  */
+  double   covariance[36];          /* rescaled; covariance[6*i+j] = matrix[(i,j)]                */
+  outfit_gauss_result_t iod;        /* the seed (given or computed here)                          */
+} outfit_lsq_result_t;
+
+/* `ObsFitData` (obs_fit_data.rs:63-100) after the last iteration, one per observation. */
+typedef struct outfit_obs_fit {
+  double  residual_ra;  /* O-C, wrapped to [-pi, pi] (least_square.rs:188-198) */
+  double  residual_dec;
+  double  chi;
+  int32_t selection;    /* OUTFIT_OBS_* */
+  int32_t _pad;
+} outfit_obs_fit_t;
+
+/* DifferentialCorrectionConfig::default() (diff_cor.rs:161-178). */
+void outfit_hip_diffcor_config_default(outfit_diffcor_config_t *c);
+/* 0, or OUTFIT_ERR_INVALID_PARAM for an unsupported propagator. */
+int  outfit_hip_diffcor_config_validate(const outfit_diffcor_config_t *c);
+
+/* Blocking drop-in for the trajectory loop of fit_lsq. `initial_orbits` (nullable) holds one
+ * record per trajectory, the `initial_orbits: Option<&FullOrbitResult>` map flattened:
+ * status OUTFIT_TRAJ_OK = use as the seed; any other status = absent/Err entry, for which the
+ * reference runs the IOD (obs_dataset_api.rs:118-120, mod.rs:86). NULL = run the IOD for all.
+ * `obs_fit` (nullable) receives one record per observation, indexed like the observation arrays
+ * (row traj_offset[t] + i). */
+int outfit_hip_fit_lsq(const outfit_iod_params_t     *iod_params,
+                       const outfit_diffcor_config_t *config,
+                       const outfit_obs_batch_t      *batch,
+                       const outfit_ephem_t          *ephem /* nullable */,
+                       const outfit_gauss_result_t   *initial_orbits /* nullable, n_traj */,
+                       int n_devices,
+                       outfit_lsq_result_t           *out /* n_traj */,
+                       outfit_obs_fit_t              *obs_fit /* nullable, n_obs */);
+
+/* Session form: the corrector runs on the session's resident observations. With
+ * `initial_orbits` NULL the seeds are the session's own IOD results (outfit_hip_session_run
+ * must have been enqueued before on the same stream); otherwise entries with status
+ * OUTFIT_TRAJ_OK replace them. Asynchronous; fetch with outfit_hip_session_lsq_results. */
+int outfit_hip_session_run_lsq(outfit_hip_session_t *s, const outfit_diffcor_config_t *config,
+                               const outfit_gauss_result_t *initial_orbits /* nullable, host */,
+                               void *stream);
+int outfit_hip_session_lsq_results(outfit_hip_session_t *s, outfit_lsq_result_t *out,
+                                   outfit_obs_fit_t *obs_fit /* nullable */);
 
 /* ---- diagnostics ------------------------------------------------------------ */
 /* Device self-test: the kernels replace some fp64 divisions by cheaper sequences that

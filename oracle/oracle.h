@@ -173,6 +173,67 @@ void orc_estimate_best_orbit(const outfit_iod_params_t *ip, const outfit_obs_bat
 void orc_iod_params_default(outfit_iod_params_t *p);
 int  orc_iod_params_validate(const outfit_iod_params_t *p);
 
+/* ---- differential_orbit_correction/  --------------------------------- */
+typedef struct { /* ObservationEquation, least_square.rs:66-95 */
+  double d_ra[6], d_dec[6];
+  double residual_ra, residual_dec;
+  double weight_ra, weight_dec, weight_cross;
+  int active;
+} orc_obs_equation;
+typedef struct { /* ObsFitData, obs_fit_data.rs:63-100 */
+  double sigma_ra, sigma_dec, bias_ra, bias_dec, residual_ra, residual_dec, chi;
+  int selection; /* OUTFIT_OBS_* */
+} orc_obs_fit;
+typedef struct { /* DifferentialCorrectionResult + OrbitalUncertainty, least_square.rs:23-60,135-160 */
+  double dx[6];
+  double normal[6][6], covariance[6][6]; /* [i][j] = matrix[(i,j)] */
+  int inversion_succeeded, used_qr;
+  double normalised_rms;
+  uint32_t num_measurements;
+} orc_lsq_solution;
+typedef struct { /* DifferentialCorrectionOutput, diff_cor.rs:185-209 */
+  orc_equinoctial elements;
+  double covariance[6][6], normal[6][6];
+  double normalised_rms;
+  uint32_t total_newton_iterations, num_measurements, outer_passes;
+} orc_diffcor_output;
+
+void   orc_diffcor_config_default(outfit_diffcor_config_t *c);
+int    orc_is_bizarre(const orc_equinoctial *eq, const outfit_diffcor_config_t *c);
+void   orc_compute_derivative(const orc_equinoctial *eq, double t0, double t1, double n, double lam1,
+                              double F, double inv_u, double beta, double sF, double cF, double xe,
+                              double ye, double vxe, double vye, const double f[3], const double g[3],
+                              const double pos[3], const double vel[3], double dpos[6][3],
+                              double dvel[6][3]);
+int    orc_propagate_twobody_partials(const orc_equinoctial *eq, double t0, double t1, double pos[3],
+                                      double vel[3], double dpos[6][3], double dvel[6][3]);
+void   orc_topocentric_radec_and_partials(const double ast_pos[3], const double ast_vel[3],
+                                          const double obs_pos[3], double *ra, double *dec,
+                                          double d_ra[3], double d_dec[3]);
+int    orc_obs_and_partials_2body(const orc_equinoctial *eq, double mjd, const double obs_pos_equ[3],
+                                  double *ra, double *dec, double d_ra_d_elem[6],
+                                  double d_dec_d_elem[6]);
+double orc_angular_diff(double a, double b);
+void   orc_solve_weighted_least_squares(const orc_obs_equation *eqs, size_t n,
+                                        const uint8_t free_elements[6], orc_lsq_solution *out);
+void   orc_rescale_covariance(double covariance[6][6], double normal[6][6], size_t num_free,
+                              size_t num_measurements, double normalised_rms);
+size_t orc_update_observation_selection(orc_obs_fit *fit, const orc_obs_equation *eqs, size_t n,
+                                        const double covariance[6][6], double chi2_reject,
+                                        double chi2_recover);
+int    orc_run_differential_correction(const orc_equinoctial *initial, const double *mjd,
+                                       const double *ra, const double *dec, const double *obs_pos,
+                                       size_t n, orc_obs_fit *fit, const outfit_diffcor_config_t *cfg,
+                                       orc_diffcor_output *out);
+void   orc_differential_correction(const outfit_iod_params_t *ip, const outfit_diffcor_config_t *cfg,
+                                   const outfit_obs_batch_t *b, const outfit_ephem_t *eph, uint64_t traj,
+                                   const outfit_gauss_result_t *initial, outfit_lsq_result_t *out,
+                                   outfit_obs_fit_t *obs_fit);
+int    orc_fit_lsq(const outfit_iod_params_t *ip, const outfit_diffcor_config_t *cfg,
+                   const outfit_obs_batch_t *batch, const outfit_ephem_t *ephem,
+                   const outfit_gauss_result_t *initial, int n_threads, outfit_lsq_result_t *out,
+                   outfit_obs_fit_t *obs_fit);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,7 +7,7 @@ src/initial_orbit_determination/obs_dataset_api.rs:145-296).
 """
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OUTFIT_OK = 0
 OUTFIT_ERR_INVALID_PARAM = -1
@@ -119,3 +119,83 @@ RESULT_DTYPE = [
     ("attempts", "<u4"), ("best_triplet", "<u4"), ("best_realization", "<u4"),
     ("n_triplets", "<u4"), ("epoch", "<f8"), ("elem", "<f8", (6,)), ("rms", "<f8"),
 ]
+
+
+# ---- differential correction (FitLSQ::fit_lsq, differential_orbit_correction/) --------------
+PROPAGATOR_TWOBODY = 0
+LSQ_DIFFCOR = 0
+LSQ_IOD_KEPT = 1
+LSQ_IOD_ERROR = 2
+LSQ_CONVERSION_ERROR = 3
+DC_NONE = 0
+DC_FAILED = 1
+DC_BIZARRE = 2
+DC_DIVERGED = 3
+OBS_ACTIVE = 0
+OBS_REJECTED = 1
+OBS_FORCED_OUT = 2
+
+
+class DiffCorConfigC(C.Structure):
+    _fields_ = [
+        ("max_newton_iterations", C.c_uint64),
+        ("max_outlier_rejection_passes", C.c_uint64),
+        ("convergence_threshold", C.c_double),
+        ("convergence_before_rejection_threshold", C.c_double),
+        ("rms_stagnation_ratio", C.c_double),
+        ("rms_divergence_ratio", C.c_double),
+        ("max_stagnation_iterations", C.c_uint64),
+        ("enable_outlier_rejection", C.c_uint32),
+        ("propagator", C.c_uint32),
+        ("chi_squared_rejection_threshold", C.c_double),
+        ("chi_squared_recovery_threshold", C.c_double),
+        ("eccentricity_limit", C.c_double),
+        ("min_semi_major_axis", C.c_double),
+        ("max_semi_major_axis", C.c_double),
+        ("min_periapsis_distance", C.c_double),
+        ("max_apoapsis_distance", C.c_double),
+        ("free_elements", C.c_uint8 * 6),
+        ("_pad", C.c_uint8 * 2),
+    ]
+
+
+class LsqResultC(C.Structure):
+    _fields_ = [
+        ("status", C.c_int32),
+        ("dc_error", C.c_int32),
+        ("conv_error", C.c_int32),
+        ("total_newton_iterations", C.c_uint32),
+        ("num_measurements", C.c_uint32),
+        ("n_rejected", C.c_uint32),
+        ("outer_passes", C.c_uint32),
+        ("_pad", C.c_uint32),
+        ("epoch", C.c_double),
+        ("elem", C.c_double * 6),
+        ("normalised_rms", C.c_double),
+        ("covariance", C.c_double * 36),
+        ("iod", GaussResultC),
+    ]
+
+
+class ObsFitC(C.Structure):
+    _fields_ = [
+        ("residual_ra", C.c_double),
+        ("residual_dec", C.c_double),
+        ("chi", C.c_double),
+        ("selection", C.c_int32),
+        ("_pad", C.c_int32),
+    ]
+
+
+assert C.sizeof(DiffCorConfigC) == 128
+assert C.sizeof(LsqResultC) == 480
+assert C.sizeof(ObsFitC) == 32
+
+LSQ_DTYPE = [
+    ("status", "<i4"), ("dc_error", "<i4"), ("conv_error", "<i4"), ("total_newton_iterations", "<u4"),
+    ("num_measurements", "<u4"), ("n_rejected", "<u4"), ("outer_passes", "<u4"), ("_pad", "<u4"),
+    ("epoch", "<f8"), ("elem", "<f8", (6,)), ("normalised_rms", "<f8"), ("covariance", "<f8", (6, 6)),
+    ("iod", RESULT_DTYPE),
+]
+OBS_FIT_DTYPE = [("residual_ra", "<f8"), ("residual_dec", "<f8"), ("chi", "<f8"),
+                 ("selection", "<i4"), ("_pad", "<i4")]

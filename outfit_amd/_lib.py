@@ -7,7 +7,8 @@ import ctypes as C
 import os
 import subprocess
 
-from ._abi import ABI_VERSION, EphemC, GaussResultC, IODParamsC, ObsBatchC
+from ._abi import (ABI_VERSION, DiffCorConfigC, EphemC, GaussResultC, IODParamsC, LsqResultC, ObsBatchC,
+                   ObsFitC)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
@@ -68,6 +69,14 @@ def lib():
         C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double,
         C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     L.outfit_hip_selftest_division.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.outfit_hip_diffcor_config_default.argtypes = [C.POINTER(DiffCorConfigC)]
+    L.outfit_hip_diffcor_config_default.restype = None
+    L.outfit_hip_diffcor_config_validate.argtypes = [C.POINTER(DiffCorConfigC)]
+    L.outfit_hip_fit_lsq.argtypes = [C.POINTER(IODParamsC), C.POINTER(DiffCorConfigC), C.POINTER(ObsBatchC),
+                                     C.POINTER(EphemC), C.POINTER(GaussResultC), C.c_int,
+                                     C.POINTER(LsqResultC), C.POINTER(ObsFitC)]
+    L.outfit_hip_session_run_lsq.argtypes = [vp, C.POINTER(DiffCorConfigC), C.POINTER(GaussResultC), vp]
+    L.outfit_hip_session_lsq_results.argtypes = [vp, C.POINTER(LsqResultC), C.POINTER(ObsFitC)]
     _lib = L
     return L
 
@@ -78,7 +87,8 @@ EXPORTED_SYMBOLS = [
     "outfit_hip_session_device_results", "outfit_hip_session_kernel_times",
     "outfit_hip_session_set_profiling", "outfit_hip_session_destroy", "outfit_hip_propagate_universal",
     "outfit_hip_last_error", "outfit_hip_abi_version", "outfit_hip_device_count",
-    "outfit_hip_selftest_division",
+    "outfit_hip_selftest_division", "outfit_hip_diffcor_config_default", "outfit_hip_diffcor_config_validate",
+    "outfit_hip_fit_lsq", "outfit_hip_session_run_lsq", "outfit_hip_session_lsq_results",
 ]
 
 

@@ -17,7 +17,8 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from . import _abi
-from ._abi import EphemC, GaussResultC, IODParamsC, ObsBatchC, RESULT_DTYPE
+from ._abi import (DiffCorConfigC, EphemC, GaussResultC, IODParamsC, LSQ_DTYPE, LsqResultC, OBS_FIT_DTYPE,
+                   ObsBatchC, ObsFitC, RESULT_DTYPE)
 from ._lib import NativeLibraryError, last_error, lib
 
 _dp = C.POINTER(C.c_double)
@@ -313,6 +314,7 @@ class IODSession:
     def __init__(self, batch, ephem, params, device=0):
         self._L = lib()
         self.n_traj = batch.n_traj
+        self.n_obs = int(batch.traj_offset[-1]) if batch.n_traj else 0
         self._keep = (batch, ephem)
         pc, bc = params.as_c(), batch.as_c()
         ec = ephem.as_c() if ephem is not None else None
@@ -358,6 +360,139 @@ class IODSession:
             self.close()
         except Exception:
             pass
+
+
+# ----------------------------------------------------------------------------- differential correction
+_DC_FIELDS = [n for n, _ in DiffCorConfigC._fields_ if not n.startswith("_")]
+_DC_ERRORS = {_abi.DC_FAILED: "DifferentialCorrectionFailed", _abi.DC_BIZARRE: "BizarreOrbit",
+              _abi.DC_DIVERGED: "DifferentialCorrectionDiverged"}
+
+
+class DifferentialCorrectionConfig:
+    """`DifferentialCorrectionConfig` (differential_orbit_correction/diff_cor.rs:39-178) with
+    `OutlierRejectionConfig` and `EquinoctialLimits` flattened; defaults = `::default()`."""
+
+    def __init__(self, **kw):
+        c = DiffCorConfigC()
+        lib().outfit_hip_diffcor_config_default(C.byref(c))
+        for n in _DC_FIELDS:
+            setattr(self, n, list(getattr(c, n)) if n == "free_elements" else getattr(c, n))
+        for k, v in kw.items():
+            if k not in _DC_FIELDS:
+                raise TypeError(f"unknown DifferentialCorrectionConfig field {k!r}")
+            setattr(self, k, v)
+
+    def as_c(self):
+        c = DiffCorConfigC()
+        for n in _DC_FIELDS:
+            if n == "free_elements":
+                for j in range(6):
+                    c.free_elements[j] = 1 if self.free_elements[j] else 0
+            else:
+                setattr(c, n, int(getattr(self, n)) if n == "enable_outlier_rejection" else getattr(self, n))
+        return c
+
+
+@dataclass
+class EquinoctialElements:
+    """`OrbitalElements::Equinoctial { elements, uncertainty, covariance }` (orbit_type/mod.rs)."""
+    reference_epoch: float
+    elements: tuple          # (a, h, k, p, q, lambda)
+    covariance: np.ndarray   # 6x6, rescaled (least_square.rs:341-362)
+
+    @property
+    def uncertainty(self):
+        """EquinoctialUncertainty::from_covariance (orbit_type/uncertainty.rs:261-271)."""
+        return tuple(float(np.sqrt(self.covariance[i, i])) for i in range(6))
+
+
+@dataclass
+class DifferentialCorrection:
+    """`FitOrbitResult::DifferentialCorrection((OrbitalElements, Chi2))` (constants.rs:136)."""
+    orbit: EquinoctialElements
+    normalised_rms: float
+    total_newton_iterations: int = 0
+    num_measurements: int = 0
+    n_rejected: int = 0
+
+    def orbital_elements(self):
+        return self.orbit
+
+    def orbit_quality(self):
+        return self.normalised_rms
+
+
+def lsq_record_to_result(rec, batch=None, traj_index=None, params=None):
+    """One `outfit_lsq_result_t` -> FitOrbitResult (DifferentialCorrection, or the IOD orbit the reference
+    falls back to, mod.rs:109) or an OutfitError instance (not raised)."""
+    st = int(rec["status"])
+    if st == _abi.LSQ_DIFFCOR:
+        orb = EquinoctialElements(float(rec["epoch"]), tuple(float(x) for x in rec["elem"]),
+                                  np.array(rec["covariance"], dtype=np.float64).reshape(6, 6))
+        return DifferentialCorrection(orb, float(rec["normalised_rms"]), int(rec["total_newton_iterations"]),
+                                      int(rec["num_measurements"]), int(rec["n_rejected"]))
+    if st == _abi.LSQ_IOD_KEPT or st == _abi.LSQ_IOD_ERROR:
+        return record_to_result(rec["iod"], batch, traj_index, params)
+    if st == _abi.LSQ_CONVERSION_ERROR:
+        if int(rec["conv_error"]) == _abi.TRAJ_INVALID_CONVERSION:
+            return InvalidConversion("Parabolic orbit cannot be represented with finite a")
+        return InvalidOrbit("eccentricity must be > 1 for hyperbolic orbits")
+    return OutfitError(f"unknown status {st}")
+
+
+def _initial_c(initial, n):
+    if initial is None:
+        return None
+    a = np.ascontiguousarray(initial, dtype=RESULT_DTYPE)
+    if a.shape != (n,):
+        raise InvalidBatch("initial_orbits must hold one record per trajectory")
+    return (GaussResultC * max(n, 1)).from_buffer_copy(a.tobytes() if n else bytes(96))
+
+
+def fit_lsq_records(batch, ephem, iod_params, diff_cor_config, initial_orbits=None, n_devices=0):
+    """The blocking C-ABI call `outfit_hip_fit_lsq`; returns (records, per-observation fit data)."""
+    L = lib()
+    pc, cc, bc = iod_params.as_c(), diff_cor_config.as_c(), batch.as_c()
+    ec = ephem.as_c() if ephem is not None else None
+    n, n_obs = batch.n_traj, int(batch.traj_offset[-1]) if batch.n_traj else 0
+    out = (LsqResultC * max(n, 1))()
+    fit = (ObsFitC * max(n_obs, 1))()
+    rc = L.outfit_hip_fit_lsq(C.byref(pc), C.byref(cc), C.byref(bc), C.byref(ec) if ec is not None else None,
+                              _initial_c(initial_orbits, n), n_devices, out, fit)
+    if rc != 0:
+        _raise_rc(rc)
+    return (np.frombuffer(out, dtype=LSQ_DTYPE)[:n].copy(), np.frombuffer(fit, dtype=OBS_FIT_DTYPE)[:n_obs].copy())
+
+
+def fit_lsq(batch, ephem, iod_params, diff_cor_config, initial_orbits=None, n_devices=0):
+    """`FitLSQ::fit_lsq` after the dataset preparation (obs_dataset_api.rs:57-99):
+    {traj_id: FitOrbitResult | OutfitError}. `initial_orbits`: records of a previous `fit_full_iod_records`."""
+    recs, _ = fit_lsq_records(batch, ephem, iod_params, diff_cor_config, initial_orbits, n_devices)
+    return {tid: lsq_record_to_result(recs[i], batch, i, iod_params) for i, tid in enumerate(batch.traj_ids)}
+
+
+def _session_run_lsq(self, diff_cor_config, initial_orbits=None, stream=None):
+    """Enqueue the corrector on the session's resident observations (seeds: the session's IOD results,
+    overridden by `initial_orbits` records with status 0)."""
+    cc = diff_cor_config.as_c()
+    rc = self._L.outfit_hip_session_run_lsq(self._h, C.byref(cc), _initial_c(initial_orbits, self.n_traj),
+                                            C.c_void_p(stream or 0))
+    if rc != 0:
+        _raise_rc(rc)
+
+
+def _session_lsq_results(self):
+    out = (LsqResultC * max(self.n_traj, 1))()
+    fit = (ObsFitC * max(self.n_obs, 1))()
+    rc = self._L.outfit_hip_session_lsq_results(self._h, out, fit)
+    if rc != 0:
+        _raise_rc(rc)
+    return (np.frombuffer(out, dtype=LSQ_DTYPE)[:self.n_traj].copy(),
+            np.frombuffer(fit, dtype=OBS_FIT_DTYPE)[:self.n_obs].copy())
+
+
+IODSession.run_lsq = _session_run_lsq
+IODSession.lsq_results = _session_lsq_results
 
 
 def propagate_universal(r, v, t0, t1, convergency=100 * 2.220446049250313e-16):

@@ -76,10 +76,11 @@ struct DevBuf {
   }
 };
 
-enum KernelId { K_TRIPLETS = 0, K_PREPASS, K_ROOTS, K_PRELIM, K_CORRECT_FAST, K_CORRECT, K_RMS, K_RMS_SLOW, K_SELECT, K_COUNT };
+enum KernelId { K_TRIPLETS = 0, K_PREPASS, K_ROOTS, K_PRELIM, K_CORRECT_FAST, K_CORRECT, K_RMS, K_RMS_SLOW, K_SELECT, K_DIFFCOR, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"k_triplet_select", "k_observer_prepass",   "k_gauss_roots",
                                            "k_gauss_prelim",   "k_gauss_correct_fast", "k_gauss_correct",
-                                           "k_orbit_rms",      "k_orbit_rms_slow",     "k_select_best"};
+                                           "k_orbit_rms",      "k_orbit_rms_slow",     "k_select_best",
+                                           "k_diffcor"};
 
 }  // namespace
 
@@ -100,6 +101,13 @@ struct outfit_hip_session {
   bool triplet_lds = false;  // K0 keeps its heap in LDS (small k_cap, <= 1024 reduced observations)
   DevBuf<outfit::GaussResultRec> results;
   DevBuf<int> error_flag;
+  // differential correction (allocated by the first run_lsq)
+  DevBuf<double> dc_part, dc_res, dc_cov, dc_qr;
+  DevBuf<unsigned char> dc_sel;
+  DevBuf<outfit::GaussResultRec> dc_initial;
+  DevBuf<outfit::LsqResultRec> dc_out;
+  DevBuf<outfit::ObsFitRec> dc_fit;
+  bool prepass_done = false, ra_bounded = true, lsq_ran = false;
   outfit::EphemTable table{};
   outfit::GaussParams gp{};
   outfit::TripletParams tp{};
@@ -121,6 +129,8 @@ struct outfit_hip_session {
     psi0.release(); slow_list.release(); slow_count.release();
     heap_id.release(); triplets.release(); queue.release(); n_triplets.release(); flags.release();
     n_win.release(); results.release(); error_flag.release();
+    dc_part.release(); dc_res.release(); dc_cov.release(); dc_qr.release(); dc_sel.release();
+    dc_initial.release(); dc_out.release(); dc_fit.release();
     for (auto& t : timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     timed.clear();
     if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -228,6 +238,10 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
     TRY_RC(upload(s->noise, b->noise_z,
                   (size_t)s->n_traj * s->k_cap * (size_t)params->n_noise_realizations * 6));
   HIP_TRY(s->results.alloc((size_t)s->n_traj));
+  // status -1 until an IOD run fills the records (outfit_hip_session_run_lsq reads them as "no seed")
+  if (s->n_traj) HIP_TRY(hipMemset(s->results.p, 0xFF, (size_t)s->n_traj * sizeof(outfit::GaussResultRec)));
+  for (size_t i = 0; i < n; ++i)
+    if (!(std::fabs(b->ra[o0 + i]) <= 1.0e3) || !std::isfinite(b->dec[o0 + i])) { s->ra_bounded = false; break; }
   HIP_TRY(s->error_flag.alloc(1));
   HIP_TRY(hipMemset(s->error_flag.p, 0, sizeof(int)));
 
@@ -318,6 +332,7 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
     pa.T = s->table; pa.error_flag = s->error_flag.p;
     Stamp stamp(s, st, K_PREPASS);
     HIP_TRY(outfit::launch_observer_prepass(pa, st));
+    s->prepass_done = true;
   }
   // Two latency-bound kernels run on a second stream in the shadow of VALU-bound ones:
   //   * K0 (sequential heap per lane) in kSub slices, each one slice ahead of the K2a slice that
@@ -402,6 +417,86 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
       Stamp stamp(s, st, K_SELECT);
       HIP_TRY(outfit::launch_select_best(sa, st));
     }
+  }
+  return OUTFIT_OK;
+}
+
+const char* validate_diffcor(const outfit_diffcor_config_t* c) {
+  if (c->propagator != OUTFIT_PROPAGATOR_TWOBODY)
+    return "propagator: only PropagatorKind::TwoBody is implemented";
+  return nullptr;
+}
+
+outfit::DiffCorConfig make_diffcor_config(const outfit_diffcor_config_t* c) {
+  outfit::DiffCorConfig d{};
+  d.max_newton_iterations = saturate_u32(c->max_newton_iterations);
+  // `0..=passes` (diff_cor.rs:316): keep passes + 1 representable
+  d.max_outlier_rejection_passes = std::min<unsigned>(saturate_u32(c->max_outlier_rejection_passes), 0xFFFFFFFEu);
+  d.max_stagnation_iterations = saturate_u32(c->max_stagnation_iterations);
+  d.enable_outlier_rejection = c->enable_outlier_rejection ? 1u : 0u;
+  d.convergence_threshold = c->convergence_threshold;
+  d.convergence_before_rejection_threshold = c->convergence_before_rejection_threshold;
+  d.rms_stagnation_ratio = c->rms_stagnation_ratio;
+  d.rms_divergence_ratio = c->rms_divergence_ratio;
+  d.chi2_reject = c->chi_squared_rejection_threshold;
+  d.chi2_recover = c->chi_squared_recovery_threshold;
+  d.eccentricity_limit = c->eccentricity_limit;
+  d.min_a = c->min_semi_major_axis; d.max_a = c->max_semi_major_axis;
+  d.min_peri = c->min_periapsis_distance; d.max_apo = c->max_apoapsis_distance;
+  unsigned nf = 0;
+  for (int j = 0; j < 6; ++j) { d.free_el[j] = c->free_elements[j] ? 1 : 0; nf += d.free_el[j]; }
+  d.n_free = (unsigned char)nf;
+  return d;
+}
+
+int session_run_lsq(outfit_hip_session* s, const outfit_diffcor_config_t* cfg,
+                    const outfit_gauss_result_t* initial, hipStream_t st) {
+  HIP_TRY(hipSetDevice(s->device));
+  if (const char* m = validate_diffcor(cfg)) return fail(OUTFIT_ERR_INVALID_PARAM, m);
+  if (!s->ra_bounded)
+    return fail(OUTFIT_ERR_INVALID_BATCH, "fit_lsq needs |ra| <= 1e3 rad and finite dec (angular_diff loops on the difference)");
+  s->last_stream = st;
+  s->lsq_ran = true;
+  if (s->n_traj == 0) return OUTFIT_OK;
+  const size_t n_obs = (size_t)s->n_obs, n_traj = (size_t)s->n_traj;
+  if (!s->dc_out.p) {
+    HIP_TRY(s->dc_part.alloc(12 * n_obs));
+    HIP_TRY(s->dc_res.alloc(6 * n_obs));
+    HIP_TRY(s->dc_sel.alloc(n_obs));
+    HIP_TRY(s->dc_cov.alloc(36 * n_traj));
+    HIP_TRY(s->dc_qr.alloc(42 * n_traj));
+    HIP_TRY(s->dc_fit.alloc(n_obs));
+    HIP_TRY(s->dc_initial.alloc(n_traj));
+    HIP_TRY(s->dc_out.alloc(n_traj));
+  }
+  const bool on_device_earth = s->has_ephem && s->has_geo;
+  if (!s->prepass_done) {
+    outfit::PrepassArgs pa{};
+    pa.n_obs = s->n_obs; pa.mjd = s->mjd.p; pa.dec = s->dec.p; pa.geo_ecl = s->geo.p; pa.obs_pos = s->obs_pos.p;
+    pa.cos_dec = s->cos_dec.p; pa.has_table = on_device_earth;
+    pa.T = s->table; pa.error_flag = s->error_flag.p;
+    Stamp stamp(s, st, K_PREPASS);
+    HIP_TRY(outfit::launch_observer_prepass(pa, st));
+    s->prepass_done = true;
+  }
+  if (initial) {
+    // The caller may free `initial` as soon as this call returns and an earlier run on `st` may still
+    // read dc_initial: drain the stream, then copy synchronously.
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(s->dc_initial.p, initial, n_traj * sizeof(outfit_gauss_result_t), hipMemcpyHostToDevice));
+  }
+  outfit::DiffCorArgs a{};
+  a.n_traj = s->n_traj; a.n_obs = s->n_obs; a.traj_offset = s->traj_offset.p;
+  a.mjd = s->mjd.p; a.ra = s->ra.p; a.dec = s->dec.p; a.sra = s->sra.p; a.sdec = s->sdec.p;
+  a.obs_pos = on_device_earth ? s->obs_pos.p : s->helio.p;
+  a.iod = s->results.p;
+  a.initial = initial ? s->dc_initial.p : nullptr;
+  a.cfg = make_diffcor_config(cfg);
+  a.part = s->dc_part.p; a.res = s->dc_res.p; a.sel = s->dc_sel.p; a.cov = s->dc_cov.p; a.qr_work = s->dc_qr.p;
+  a.out = s->dc_out.p; a.obs_fit = s->dc_fit.p;
+  {
+    Stamp stamp(s, st, K_DIFFCOR);
+    HIP_TRY(outfit::launch_diffcor(a, st));
   }
   return OUTFIT_OK;
 }
@@ -560,6 +655,105 @@ int outfit_hip_fit_full_iod(const outfit_iod_params_t* params, const outfit_obs_
     int r = outfit_hip_session_create(params, &sub, ephem, d, &s);
     if (r == OUTFIT_OK) r = outfit_hip_session_run(s, nullptr, nullptr);
     if (r == OUTFIT_OK) r = outfit_hip_session_results(s, out + t0);
+    if (r != OUTFIT_OK) msg[d] = g_last_error;
+    outfit_hip_session_destroy(s);
+    rc[d] = r;
+  };
+  if (n_devices == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int d = 0; d < n_devices; ++d) th.emplace_back(work, d);
+    for (auto& t : th) t.join();
+  }
+  for (int d = 0; d < n_devices; ++d)
+    if (rc[d] != OUTFIT_OK) return fail(rc[d], msg[d]);
+  return OUTFIT_OK;
+}
+
+void outfit_hip_diffcor_config_default(outfit_diffcor_config_t* c) {
+  std::memset(c, 0, sizeof *c);
+  c->max_newton_iterations = 30; c->max_outlier_rejection_passes = 10;
+  c->convergence_threshold = 1e-4; c->convergence_before_rejection_threshold = 2.0;
+  c->rms_stagnation_ratio = 0.98; c->rms_divergence_ratio = 1.5; c->max_stagnation_iterations = 3;
+  c->enable_outlier_rejection = 1; c->propagator = OUTFIT_PROPAGATOR_TWOBODY;
+  c->chi_squared_rejection_threshold = 25.0; c->chi_squared_recovery_threshold = 9.0;
+  c->eccentricity_limit = 1.2; c->min_semi_major_axis = 1e-6; c->max_semi_major_axis = 1e4;
+  c->min_periapsis_distance = 1e-6; c->max_apoapsis_distance = 1e4;
+  for (int j = 0; j < 6; ++j) c->free_elements[j] = 1;
+}
+
+int outfit_hip_diffcor_config_validate(const outfit_diffcor_config_t* c) {
+  if (!c) return fail(OUTFIT_ERR_INVALID_PARAM, "config is NULL");
+  if (const char* m = validate_diffcor(c)) return fail(OUTFIT_ERR_INVALID_PARAM, m);
+  return OUTFIT_OK;
+}
+
+int outfit_hip_session_run_lsq(outfit_hip_session_t* s, const outfit_diffcor_config_t* config,
+                               const outfit_gauss_result_t* initial_orbits, void* stream) {
+  if (!s) return fail(OUTFIT_ERR_BAD_HANDLE, "session is NULL");
+  if (!config) return fail(OUTFIT_ERR_INVALID_PARAM, "config is NULL");
+  hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : s->own_stream;
+  return session_run_lsq(s, config, initial_orbits, st);
+}
+
+int outfit_hip_session_lsq_results(outfit_hip_session_t* s, outfit_lsq_result_t* out, outfit_obs_fit_t* obs_fit) {
+  if (!s || !out) return fail(OUTFIT_ERR_BAD_HANDLE, "session or out is NULL");
+  if (!s->lsq_ran) return fail(OUTFIT_ERR_BAD_HANDLE, "outfit_hip_session_run_lsq has not been called");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->last_stream ? s->last_stream : s->own_stream));
+  int flag = 0;
+  HIP_TRY(hipMemcpy(&flag, s->error_flag.p, sizeof(int), hipMemcpyDeviceToHost));
+  if (flag) return fail(OUTFIT_ERR_EPHEM_RANGE, "an observation epoch lies outside the ephemeris table");
+  if (s->n_traj)
+    HIP_TRY(hipMemcpy(out, s->dc_out.p, (size_t)s->n_traj * sizeof(outfit_lsq_result_t), hipMemcpyDeviceToHost));
+  if (obs_fit && s->n_obs)
+    HIP_TRY(hipMemcpy(obs_fit, s->dc_fit.p, (size_t)s->n_obs * sizeof(outfit_obs_fit_t), hipMemcpyDeviceToHost));
+  return OUTFIT_OK;
+}
+
+int outfit_hip_fit_lsq(const outfit_iod_params_t* params, const outfit_diffcor_config_t* config,
+                       const outfit_obs_batch_t* batch, const outfit_ephem_t* ephem,
+                       const outfit_gauss_result_t* initial, int n_devices, outfit_lsq_result_t* out,
+                       outfit_obs_fit_t* obs_fit) {
+  TRY_RC(outfit_hip_iod_params_validate(params));
+  TRY_RC(outfit_hip_diffcor_config_validate(config));
+  TRY_RC(check_batch(params, batch, ephem));
+  if (!out && batch->n_traj) return fail(OUTFIT_ERR_INVALID_BATCH, "out is NULL");
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+    return fail(OUTFIT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+  if (n_devices <= 0 || n_devices > n_dev) n_devices = n_dev;
+  if (batch->n_traj == 0) return OUTFIT_OK;
+  n_devices = (int)std::min<uint64_t>((uint64_t)n_devices, batch->n_traj);
+
+  const uint64_t o0 = batch->traj_offset[0], total = batch->traj_offset[batch->n_traj] - o0;
+  std::vector<uint64_t> cut(n_devices + 1, batch->n_traj);
+  cut[0] = 0;
+  for (int d = 1; d < n_devices; ++d) {
+    const uint64_t target = o0 + total * (uint64_t)d / (uint64_t)n_devices;
+    const uint64_t* lo = std::lower_bound(batch->traj_offset, batch->traj_offset + batch->n_traj, target);
+    cut[d] = std::max<uint64_t>(cut[d - 1], (uint64_t)(lo - batch->traj_offset));
+  }
+  std::vector<int> rc(n_devices, OUTFIT_OK);
+  std::vector<std::string> msg(n_devices);
+  auto work = [&](int d) {
+    const uint64_t t0 = cut[d], t1 = cut[d + 1];
+    if (t1 <= t0) return;
+    outfit_obs_batch_t sub = *batch;
+    sub.n_traj = t1 - t0;
+    sub.traj_offset = batch->traj_offset + t0;
+    if (batch->noise_z)
+      sub.noise_z = batch->noise_z + (size_t)t0 * params->max_triplets * (size_t)params->n_noise_realizations * 6;
+    // the IOD runs only when some trajectory has no usable seed (obs_dataset_api.rs:118-120, mod.rs:86)
+    bool need_iod = initial == nullptr;
+    for (uint64_t t = t0; t < t1 && !need_iod; ++t) need_iod = initial[t].status != OUTFIT_TRAJ_OK;
+    outfit_hip_session_t* s = nullptr;
+    int r = outfit_hip_session_create(params, &sub, ephem, d, &s);
+    if (r == OUTFIT_OK && need_iod) r = outfit_hip_session_run(s, nullptr, nullptr);
+    if (r == OUTFIT_OK) r = outfit_hip_session_run_lsq(s, config, initial ? initial + t0 : nullptr, nullptr);
+    if (r == OUTFIT_OK)
+      r = outfit_hip_session_lsq_results(s, out + t0, obs_fit ? obs_fit + batch->traj_offset[t0] : nullptr);
     if (r != OUTFIT_OK) msg[d] = g_last_error;
     outfit_hip_session_destroy(s);
     rc[d] = r;

@@ -1,0 +1,274 @@
+// diffcor.hip — K4 `k_diffcor`: differential orbit correction (Newton weighted least squares with
+// two-body partials, chi-square outlier rejection, covariance rescaling), one lane per trajectory.
+// Replaces `differential_correction` (differential_orbit_correction/mod.rs:66-112) as driven by
+// FitLSQ::fit_lsq (obs_dataset_api.rs:57-130); device code in device/diffcor.hpp.
+#include "kernels.h"
+#include "device/diffcor.hpp"
+
+namespace outfit {
+
+namespace {
+constexpr double kF64Max = 1.7976931348623157e308;
+constexpr unsigned char kSelMask = 0x3, kEqActive = 0x80;
+}  // namespace
+
+// Per-observation scratch (global, indexed by observation row o):
+//   part[c][o], c < 12 : d_ra_d_elem[6], d_dec_d_elem[6] of the current iteration's equations
+//   res[b][c][o]       : (residual_ra, residual_dec, chi) double-buffered: b = cur is written by the
+//                        running iteration, b = cur^1 holds the last ACCEPTED iteration (ObsFitData)
+//   sel[o]             : ObsSelection in bits 0-1, ObservationEquation.active of the current iteration in bit 7
+// Per-trajectory scratch: cov[36][n_traj] = OrbitalUncertainty.covariance of the last accepted iteration.
+__global__ void __launch_bounds__(64)
+k_diffcor(DiffCorArgs A) {
+  const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= A.n_traj) return;
+  const DiffCorConfig& C = A.cfg;
+  LsqResultRec* out = A.out + t;
+  const unsigned long long base = A.traj_offset[t];
+  const unsigned n = (unsigned)(A.traj_offset[t + 1] - base);
+
+  GaussResultRec seed = A.iod[t];
+  if (A.initial) {
+    const GaussResultRec given = A.initial[t];
+    if (given.status == 0) seed = given;  // Some(Ok(orbit)) ; anything else => run_iod_on_observations
+  }
+  out->iod = seed;
+  int status = 0, dc_error = 0, conv_error = 0;
+  unsigned total_iters = 0, outer_started = 0, last_num_meas = 0, n_rejected = 0;
+  double last_rms = kF64Max;
+  Equinoctial q{};
+  if (seed.status != 0) {
+    status = 2;  // OUTFIT_LSQ_IOD_ERROR
+  } else {
+    Elements el;
+    el.kind = seed.kind;
+    el.epoch = seed.epoch;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) el.e[k] = seed.elem[k];
+    conv_error = to_equinoctial(el, q);
+    if (conv_error) status = 3;  // OUTFIT_LSQ_CONVERSION_ERROR
+  }
+
+  unsigned cur = 0;
+  const unsigned long long RB = 3ull * A.n_obs;  // one residual buffer
+  if (status == 0) {
+    for (unsigned i = 0; i < n; ++i) {  // ObsFitData::new (obs_fit_data.rs:103-116)
+      const unsigned long long o = base + i;
+      A.sel[o] = 0;
+      A.res[RB + o] = 0.0;
+      A.res[RB + A.n_obs + o] = 0.0;
+      A.res[RB + 2 * A.n_obs + o] = 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 36; ++i) A.cov[(unsigned long long)i * A.n_traj + t] = 0.0;
+
+    bool done = false;
+    for (unsigned outer = 0; outer <= C.max_outlier_rejection_passes && !done; ++outer) {
+      outer_started += 1;
+      double prev_rms = kF64Max;
+      unsigned stagnation = 0;
+      bool inner_converged = false;
+      for (unsigned inner = 0; inner < C.max_newton_iterations; ++inner) {
+        total_iters += 1;
+        // ---- single_iteration (single_iteration.rs:158-328) --------------------------------
+        const PartialsFrame P = partials_frame(q);
+        double N[36], rhs[6], wss = 0.0;
+#pragma unroll
+        for (int i = 0; i < 36; ++i) N[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) rhs[i] = 0.0;
+        unsigned active = 0;
+        double* rc_ = A.res + (unsigned long long)cur * RB;
+        const double* ra_ = A.res + (unsigned long long)(cur ^ 1u) * RB;
+#pragma unroll 1
+        for (unsigned i = 0; i < n; ++i) {
+          const unsigned long long o = base + i;
+          const unsigned char s = A.sel[o] & kSelMask;
+          bool eq_active = false;
+          if (s == 0) {
+            ObsPartials ob;
+            const Vec3 op = {A.obs_pos[3 * o], A.obs_pos[3 * o + 1], A.obs_pos[3 * o + 2]};
+            if (obs_and_partials(q, P, A.mjd[o], op, ob)) {
+              eq_active = true;
+              const double sra = A.sra[o], sdec = A.sdec[o];
+              const double rra = angular_diff(A.ra[o] - 0.0, ob.ra);
+              const double rdec = (A.dec[o] - 0.0) - ob.dec;
+              const double ta = rra / sra, td = rdec / sdec;
+              const double chi = sqrt(ta * ta + td * td);
+              const double wa = 1.0 / (sra * sra), wd = 1.0 / (sdec * sdec), wc = 0.0;
+#pragma unroll
+              for (int j = 0; j < 6; ++j) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                  N[6 * j + k] += ob.ga[j] * wa * ob.ga[k] + ob.gd[j] * wd * ob.gd[k] +
+                                  wc * (ob.gd[j] * ob.ga[k] + ob.ga[j] * ob.gd[k]);
+                rhs[j] += (ob.ga[j] * wa + ob.gd[j] * wc) * rra + (ob.ga[j] * wc + ob.gd[j] * wd) * rdec;
+              }
+              wss += wa * rra * rra + wd * rdec * rdec + 2.0 * wc * rra * rdec;
+              active += 1;
+#pragma unroll
+              for (int j = 0; j < 6; ++j) {
+                A.part[(unsigned long long)j * A.n_obs + o] = ob.ga[j];
+                A.part[(unsigned long long)(6 + j) * A.n_obs + o] = ob.gd[j];
+              }
+              rc_[o] = rra;
+              rc_[A.n_obs + o] = rdec;
+              rc_[2 * A.n_obs + o] = chi;
+            }
+          }
+          if (!eq_active) {  // fit_data.clone(): the accepted residuals carry over
+            rc_[o] = ra_[o];
+            rc_[A.n_obs + o] = ra_[A.n_obs + o];
+            rc_[2 * A.n_obs + o] = ra_[2 * A.n_obs + o];
+          }
+          A.sel[o] = (unsigned char)(s | (eq_active ? kEqActive : 0));
+        }
+        // ---- solve_weighted_least_squares (least_square.rs:211-303) ---------------------------
+        const unsigned num_meas = active * 2;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          if (!C.free_el[j]) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { N[6 * j + k] = 0.0; N[6 * k + j] = 0.0; }
+            N[6 * j + j] = 1.0;
+            rhs[j] = 0.0;
+          }
+        }
+        double cov[36];
+        bool inv_ok = cholesky_inverse6(N, cov);
+        if (!inv_ok) inv_ok = qr_inverse6(A.qr_work + t, A.n_traj, N, cov);
+        if (!inv_ok) { dc_error = 1; done = true; break; }  // DifferentialCorrectionFailed
+        double dx[6], cdx[6];
+        gemv6(cov, rhs, dx);
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+          if (!C.free_el[j]) dx[j] = 0.0;
+        const double new_rms = num_meas > 0 ? sqrt(wss / (double)num_meas) : 0.0;
+        gemv6(N, dx, cdx);
+        const double cnorm = sqrt(dot6(dx, cdx));
+        Equinoctial corrected = q;
+        if (C.free_el[0]) corrected.a = q.a + dx[0];
+        if (C.free_el[1]) corrected.h = q.h + dx[1];
+        if (C.free_el[2]) corrected.k = q.k + dx[2];
+        if (C.free_el[3]) corrected.p = q.p + dx[3];
+        if (C.free_el[4]) corrected.q = q.q + dx[4];
+        if (C.free_el[5]) corrected.lambda = q.lambda + dx[5];
+        // ---- run_differential_correction bookkeeping (diff_cor.rs:335-392) -------------------------
+        if (is_bizarre(corrected, C)) { dc_error = 2; done = true; break; }
+        if (prev_rms < kF64Max && new_rms / prev_rms >= C.rms_divergence_ratio) { dc_error = 3; done = true; break; }
+        const bool stagnated = prev_rms < kF64Max && new_rms / prev_rms >= C.rms_stagnation_ratio;
+        if (stagnated) {
+          stagnation += 1;
+          if (stagnation >= C.max_stagnation_iterations) break;
+        } else {
+          stagnation = 0;
+        }
+#pragma unroll
+        for (int i = 0; i < 36; ++i) A.cov[(unsigned long long)i * A.n_traj + t] = cov[i];
+        last_rms = new_rms;
+        last_num_meas = num_meas;
+        q = corrected;
+        cur ^= 1u;  // the buffer just written becomes the accepted one
+        prev_rms = new_rms;
+        if (cnorm < C.convergence_threshold) { inner_converged = true; break; }
+      }
+      if (done) break;
+      if (!C.enable_outlier_rejection) break;
+      if (outer == 0 && last_rms < C.convergence_before_rejection_threshold) break;
+      if (!inner_converged) break;
+      // ---- update_observation_selection (outlier_rejection.rs:132-235) -----------------------------
+      double cov[36];
+#pragma unroll
+      for (int i = 0; i < 36; ++i) cov[i] = A.cov[(unsigned long long)i * A.n_traj + t];
+      const double* ra_ = A.res + (unsigned long long)(cur ^ 1u) * RB;
+      unsigned changes = 0;
+#pragma unroll 1
+      for (unsigned i = 0; i < n; ++i) {
+        const unsigned long long o = base + i;
+        const unsigned char sb = A.sel[o];
+        const unsigned char s = sb & kSelMask;
+        if (s == 2) continue;  // ForcedOut
+        const bool eq_active = (sb & kEqActive) != 0;
+        double ga[6], gd[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          ga[j] = eq_active ? A.part[(unsigned long long)j * A.n_obs + o] : 0.0;
+          gd[j] = eq_active ? A.part[(unsigned long long)(6 + j) * A.n_obs + o] : 0.0;
+        }
+        const double sra = A.sra[o], sdec = A.sdec[o];
+        const double wa = eq_active ? 1.0 / (sra * sra) : 1.0, wd = eq_active ? 1.0 / (sdec * sdec) : 1.0;
+        const double var_ra = sra * sra, var_dec = sdec * sdec;
+        const double cov_cross = -sra * sdec * 0.0 / (wa * wd);
+        double gga[6], ggd[6];
+        gemv6(cov, ga, gga);
+        gemv6(cov, gd, ggd);
+        const double paa = dot6(ga, gga), pdd = dot6(gd, ggd), pad = dot6(ga, ggd);
+        const double p00 = var_ra - paa, p01 = cov_cross - pad, p10 = cov_cross - pad, p11 = var_dec - pdd;
+        const double det = p00 * p11 - p01 * p01;
+        const double scale = fmax(fabs(p00), fabs(p11));
+        const double thr = kEps * scale * scale;
+        if (fabs(det) < thr || scale == 0.0) continue;
+        const double i00 = p11 / det, i01 = -p01 / det, i10 = -p10 / det, i11 = p00 / det;
+        const double r0 = ra_[o], r1 = ra_[A.n_obs + o];
+        const double v0 = i00 * r0 + i01 * r1, v1 = i10 * r0 + i11 * r1;
+        const double chi2 = r0 * v0 + r1 * v1;
+        if (s == 0 && chi2 > C.chi2_reject) { A.sel[o] = (unsigned char)((sb & ~kSelMask) | 1); changes += 1; }
+        else if (s == 1 && chi2 <= C.chi2_recover) { A.sel[o] = (unsigned char)(sb & ~kSelMask); changes += 1; }
+      }
+      if (changes == 0) break;
+    }
+    if (dc_error) status = 1;  // OUTFIT_LSQ_IOD_KEPT: Err(_) => Ok(initial_orbit)
+  }
+
+  // ---- output --------------------------------------------------------------------------------------
+  out->status = status;
+  out->dc_error = dc_error;
+  out->conv_error = conv_error;
+  out->total_newton_iterations = total_iters;
+  out->outer_passes = outer_started;
+  out->pad = 0;
+  const bool ok = status == 0;
+  out->epoch = (status == 0 || status == 1) ? q.epoch : 0.0;
+  out->elem[0] = ok ? q.a : 0.0; out->elem[1] = ok ? q.h : 0.0; out->elem[2] = ok ? q.k : 0.0;
+  out->elem[3] = ok ? q.p : 0.0; out->elem[4] = ok ? q.q : 0.0; out->elem[5] = ok ? q.lambda : 0.0;
+  out->normalised_rms = ok ? last_rms : 0.0;
+  out->num_measurements = ok ? last_num_meas : 0u;
+  // rescale_covariance (least_square.rs:341-362)
+  double mu2 = 1.0;
+  if (ok) {
+    double mu = 1.0;
+    if ((unsigned)C.n_free < last_num_meas) {
+      const double factor = sqrt((double)last_num_meas / (double)(last_num_meas - (unsigned)C.n_free));
+      mu = last_rms > 1.0 ? last_rms * factor : factor;
+    }
+    mu2 = mu * mu;
+  }
+#pragma unroll
+  for (int i = 0; i < 36; ++i)
+    out->covariance[i] = ok ? A.cov[(unsigned long long)i * A.n_traj + t] * mu2 : 0.0;
+  const double* ra_ = A.res + (unsigned long long)(cur ^ 1u) * RB;
+  for (unsigned i = 0; i < n; ++i) {
+    const unsigned long long o = base + i;
+    const unsigned char s = ok ? (A.sel[o] & kSelMask) : 0;
+    n_rejected += s != 0;
+    if (A.obs_fit) {
+      ObsFitRec f;
+      f.residual_ra = ok ? ra_[o] : 0.0;
+      f.residual_dec = ok ? ra_[A.n_obs + o] : 0.0;
+      f.chi = ok ? ra_[2 * A.n_obs + o] : 0.0;
+      f.selection = s;
+      f.pad = 0;
+      A.obs_fit[o] = f;
+    }
+  }
+  out->n_rejected = n_rejected;
+}
+
+hipError_t launch_diffcor(const DiffCorArgs& a, hipStream_t s) {
+  if (a.n_traj == 0) return hipSuccess;
+  const unsigned grid = (unsigned)((a.n_traj + 63) / 64);
+  hipLaunchKernelGGL(k_diffcor, dim3(grid), dim3(64), 0, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace outfit

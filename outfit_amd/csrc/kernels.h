@@ -5,6 +5,7 @@
 #include "device/ephem.hpp"
 #include "device/gauss.hpp"
 #include "device/triplets.hpp"
+#include "device/diffcor.hpp"
 
 namespace outfit {
 
@@ -112,6 +113,36 @@ struct SelectArgs {
   GaussResultRec* out;  // indexed by absolute trajectory
 };
 
+// same layouts as outfit_lsq_result_t (480 B) / outfit_obs_fit_t (32 B)
+struct LsqResultRec {
+  int status, dc_error, conv_error;
+  unsigned total_newton_iterations, num_measurements, n_rejected, outer_passes, pad;
+  double epoch, elem[6], normalised_rms, covariance[36];
+  GaussResultRec iod;
+};
+static_assert(sizeof(LsqResultRec) == 480, "record must match outfit_lsq_result_t");
+struct ObsFitRec {
+  double residual_ra, residual_dec, chi;
+  int selection, pad;
+};
+static_assert(sizeof(ObsFitRec) == 32, "record must match outfit_obs_fit_t");
+
+struct DiffCorArgs {
+  unsigned long long n_traj, n_obs;
+  const unsigned long long* traj_offset;
+  const double *mjd, *ra, *dec, *sra, *sdec, *obs_pos;
+  const GaussResultRec* iod;       // the session's own IOD results
+  const GaussResultRec* initial;   // nullable: caller-provided seeds (status 0 = use)
+  DiffCorConfig cfg;
+  double* part;                    // [12][n_obs]
+  double* res;                     // [2][3][n_obs]
+  unsigned char* sel;              // [n_obs]
+  double* cov;                     // [36][n_traj]
+  double* qr_work;                 // [42][n_traj]
+  LsqResultRec* out;               // [n_traj]
+  ObsFitRec* obs_fit;              // nullable [n_obs]
+};
+
 hipError_t launch_triplet_select(const TripletArgs& a, bool lds_heap, hipStream_t s);
 hipError_t launch_observer_prepass(const PrepassArgs& a, hipStream_t s);
 hipError_t launch_gauss_roots(const RootsArgs& a, hipStream_t s);
@@ -120,6 +151,7 @@ hipError_t launch_gauss_correct_fast(const CorrectArgs& a, unsigned n_cu, hipStr
 hipError_t launch_gauss_correct(const CorrectArgs& a, unsigned n_cu, hipStream_t s);
 hipError_t launch_orbit_rms(const RmsArgs& a, bool slow_list, hipStream_t s);
 hipError_t launch_select_best(const SelectArgs& a, hipStream_t s);
+hipError_t launch_diffcor(const DiffCorArgs& a, hipStream_t s);
 hipError_t launch_selftest_division(unsigned long long n_threads, unsigned long long n_per_thread,
                                     unsigned long long seed, unsigned long long* d_mismatches, hipStream_t s);
 hipError_t launch_propagate_universal(unsigned long long n, const double* rv, const double* t0,

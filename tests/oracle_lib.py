@@ -9,7 +9,8 @@ import subprocess
 
 import numpy as np
 
-from outfit_amd._abi import EphemC, GaussResultC, IODParamsC, ObsBatchC, RESULT_DTYPE
+from outfit_amd._abi import (DiffCorConfigC, EphemC, GaussResultC, IODParamsC, LSQ_DTYPE, LsqResultC,
+                             OBS_FIT_DTYPE, ObsBatchC, ObsFitC, RESULT_DTYPE)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
@@ -58,6 +59,34 @@ class GaussPrelim(C.Structure):
 
 class GaussResult(C.Structure):
     _fields_ = [("stage", C.c_int), ("el", Elements)]
+
+
+D6 = C.c_double * 6
+M63 = (C.c_double * 3) * 6
+M66 = (C.c_double * 6) * 6
+
+
+class ObsEquation(C.Structure):
+    _fields_ = [("d_ra", D6), ("d_dec", D6), ("residual_ra", C.c_double), ("residual_dec", C.c_double),
+                ("weight_ra", C.c_double), ("weight_dec", C.c_double), ("weight_cross", C.c_double),
+                ("active", C.c_int)]
+
+
+class ObsFit(C.Structure):
+    _fields_ = [("sigma_ra", C.c_double), ("sigma_dec", C.c_double), ("bias_ra", C.c_double),
+                ("bias_dec", C.c_double), ("residual_ra", C.c_double), ("residual_dec", C.c_double),
+                ("chi", C.c_double), ("selection", C.c_int)]
+
+
+class LsqSolution(C.Structure):
+    _fields_ = [("dx", D6), ("normal", M66), ("covariance", M66), ("inversion_succeeded", C.c_int),
+                ("used_qr", C.c_int), ("normalised_rms", C.c_double), ("num_measurements", C.c_uint32)]
+
+
+class DiffCorOutput(C.Structure):
+    _fields_ = [("elements", Equinoctial), ("covariance", M66), ("normal", M66),
+                ("normalised_rms", C.c_double), ("total_newton_iterations", C.c_uint32),
+                ("num_measurements", C.c_uint32), ("outer_passes", C.c_uint32)]
 
 
 def build():
@@ -116,6 +145,27 @@ def lib():
                                        C.c_int, C.c_int, C.POINTER(GaussResultC)]
         L.orc_iod_params_default.argtypes = [C.POINTER(IODParamsC)]
         L.orc_iod_params_validate.argtypes = [C.POINTER(IODParamsC)]
+        L.orc_diffcor_config_default.argtypes = [C.POINTER(DiffCorConfigC)]
+        L.orc_is_bizarre.argtypes = [C.POINTER(Equinoctial), C.POINTER(DiffCorConfigC)]
+        L.orc_compute_derivative.argtypes = [C.POINTER(Equinoctial)] + [C.c_double] * 13 + [D3, D3, D3, D3, M63, M63]
+        L.orc_propagate_twobody_partials.argtypes = [C.POINTER(Equinoctial), C.c_double, C.c_double, D3, D3,
+                                                     M63, M63]
+        L.orc_topocentric_radec_and_partials.argtypes = [D3, D3, D3, _dp, _dp, D3, D3]
+        L.orc_obs_and_partials_2body.argtypes = [C.POINTER(Equinoctial), C.c_double, D3, _dp, _dp, D6, D6]
+        L.orc_angular_diff.restype = C.c_double
+        L.orc_angular_diff.argtypes = [C.c_double, C.c_double]
+        L.orc_solve_weighted_least_squares.argtypes = [C.POINTER(ObsEquation), C.c_size_t, C.c_uint8 * 6,
+                                                       C.POINTER(LsqSolution)]
+        L.orc_rescale_covariance.argtypes = [M66, M66, C.c_size_t, C.c_size_t, C.c_double]
+        L.orc_update_observation_selection.restype = C.c_size_t
+        L.orc_update_observation_selection.argtypes = [C.POINTER(ObsFit), C.POINTER(ObsEquation), C.c_size_t,
+                                                       M66, C.c_double, C.c_double]
+        L.orc_run_differential_correction.argtypes = [C.POINTER(Equinoctial), _dp, _dp, _dp, _dp, C.c_size_t,
+                                                      C.POINTER(ObsFit), C.POINTER(DiffCorConfigC),
+                                                      C.POINTER(DiffCorOutput)]
+        L.orc_fit_lsq.argtypes = [C.POINTER(IODParamsC), C.POINTER(DiffCorConfigC), C.POINTER(ObsBatchC),
+                                  C.POINTER(EphemC), C.POINTER(GaussResultC), C.c_int,
+                                  C.POINTER(LsqResultC), C.POINTER(ObsFitC)]
         _lib = L
     return _lib
 
@@ -169,3 +219,25 @@ def fit_full_iod(params, batch_c, ephem_c=None, n_threads=1, hoist=0):
                                 n_threads, hoist, out)
     arr = np.frombuffer(out, dtype=RESULT_DTYPE).copy()
     return rc, arr
+
+
+def default_diffcor_config():
+    c = DiffCorConfigC()
+    lib().orc_diffcor_config_default(C.byref(c))
+    return c
+
+
+def fit_lsq(params, config, batch_c, ephem_c=None, initial=None, n_threads=1):
+    """initial: numpy RESULT_DTYPE array or None. Returns (rc, LSQ_DTYPE array, OBS_FIT_DTYPE array)."""
+    n = batch_c.n_traj
+    n_obs = batch_c.traj_offset[n] if n else 0
+    out = (LsqResultC * max(n, 1))()
+    fit = (ObsFitC * max(n_obs, 1))()
+    init_c = None
+    if initial is not None:
+        init_c = (GaussResultC * max(n, 1)).from_buffer_copy(np.ascontiguousarray(initial).tobytes())
+    rc = lib().orc_fit_lsq(C.byref(params), C.byref(config), C.byref(batch_c),
+                           C.byref(ephem_c) if ephem_c is not None else None, init_c, n_threads, out, fit)
+    res = np.frombuffer(out, dtype=LSQ_DTYPE)[:n].copy()
+    obs = np.frombuffer(fit, dtype=OBS_FIT_DTYPE)[:n_obs].copy()
+    return rc, res, obs
