@@ -69,6 +69,22 @@ def cpu_baseline(batch, ephem, params, n_obj_max, budget_s=15.0):
                       "per (candidate, observation) as the reference does"}
 
 
+def cpu_baseline_lsq(batch, ephem, params, seeds, n_obj_max, budget_s=5.0):
+    """The oracle's differential correction (the reference loops over trajectories sequentially,
+    obs_dataset_api.rs:76-96; threads here = the same dynamic schedule as the IOD baseline) on given seeds."""
+    import oracle_lib as O
+    cores = host_cores()
+    cfg = O.default_diffcor_config()
+    n0 = min(n_obj_max, 2048 * cores)
+    sub = batch.slice(0, n0)
+    t = time.perf_counter()
+    rc, _, _ = O.fit_lsq(params.as_c(), cfg, sub.as_c(), ephem.as_c(), seeds[:n0], n_threads=cores)
+    dt = time.perf_counter() - t
+    assert rc == 0
+    return {"value": n0 / dt, "unit": "objects/s", "cores": cores, "kind": "port",
+            "sample": f"first {n0} objects of the same batch, seeds = this run's IOD records, {dt:.1f} s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -76,6 +92,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--objects", type=int, default=100000, help="objects per GPU (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-lsq", action="store_true", help="skip the differential-correction side measurement")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the real path) or gloo (rehearsal of the N>1 logic on one GPU)")
     ap.add_argument("--single-device", action="store_true",
@@ -147,6 +164,26 @@ def main():
     ktimes = session.kernel_times()      # HIP events on the run's stream over the whole timed region
     session.set_profiling(False)
 
+    # ---- next row (BASELINE configs[4]): IOD seed -> differential correction ----
+    # Measured after the headline region and reported beside it, never mixed into `value`.
+    lsq = None
+    if not args.no_lsq:
+        cfg = outfit_amd.DifferentialCorrectionConfig()
+        session.run_lsq(cfg, stream=stream)   # warm-up (allocates the corrector's scratch)
+        fence()
+        session.set_profiling(True)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            session.run_lsq(cfg, stream=stream)
+        fence()
+        lsq_elapsed = time.perf_counter() - t1
+        kt = session.kernel_times()
+        session.set_profiling(False)
+        lrec, _ = session.lsq_results()
+        lsq = {"elapsed": lsq_elapsed, "kernel_ms": kt.get("k_diffcor", (0.0, 1)),
+               "n_diffcor": int((lrec["status"] == 0).sum()), "n_iod_kept": int((lrec["status"] == 1).sum()),
+               "mean_newton_iterations": float(lrec["total_newton_iterations"].mean())}
+
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -196,8 +233,20 @@ def main():
                        "parallelism": f"objects sharded over {world} GPU(s); RCCL all_gather of 96-B results"},
             "roofline": roof,
         }
+        if lsq is not None:
+            ms = 1e3 * lsq["elapsed"] / args.steps
+            line["fit_lsq"] = {
+                "what": "differential correction stage alone (k_diffcor on the resident IOD seeds, default "
+                        "DifferentialCorrectionConfig), rank 0; BASELINE configs[4] per-GPU shape",
+                "ms_per_step": ms, "objects_per_s_stage": n_obj * args.steps / lsq["elapsed"],
+                "objects_per_s_iod_plus_lsq": n_obj / (1e-3 * ms + elapsed / args.steps),
+                "kernel_avg_ms": lsq["kernel_ms"][0] / max(1, lsq["kernel_ms"][1]),
+                "converged": lsq["n_diffcor"], "kept_iod_orbit": lsq["n_iod_kept"],
+                "mean_newton_iterations": lsq["mean_newton_iterations"]}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(batch, ephem, params, n_obj)
+            if lsq is not None:
+                line["fit_lsq"]["cpu_baseline"] = cpu_baseline_lsq(batch, ephem, params, res, n_obj)
         print(json.dumps(line), flush=True)
     session.close()
     if world > 1:

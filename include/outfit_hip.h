@@ -305,9 +305,10 @@ int outfit_hip_fit_lsq(const outfit_iod_params_t     *iod_params,
                        outfit_obs_fit_t              *obs_fit /* nullable, n_obs */);
 
 /* Session form: the corrector runs on the session's resident observations. With
- * `initial_orbits` NULL the seeds are the session's own IOD results (outfit_hip_session_run
- * must have been enqueued before on the same stream); otherwise entries with status
- * OUTFIT_TRAJ_OK replace them. Asynchronous; fetch with outfit_hip_session_lsq_results. */
+ * `initial_orbits` NULL the seeds are the records the last outfit_hip_session_run wrote (its
+ * `d_out`, which must still be alive, or the session's own buffer; enqueued before on the same
+ * stream); otherwise entries with status OUTFIT_TRAJ_OK replace them. Asynchronous unless seeds
+ * are given; fetch with outfit_hip_session_lsq_results. */
 int outfit_hip_session_run_lsq(outfit_hip_session_t *s, const outfit_diffcor_config_t *config,
                                const outfit_gauss_result_t *initial_orbits /* nullable, host */,
                                void *stream);

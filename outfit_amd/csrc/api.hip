@@ -108,6 +108,7 @@ struct outfit_hip_session {
   DevBuf<outfit::LsqResultRec> dc_out;
   DevBuf<outfit::ObsFitRec> dc_fit;
   bool prepass_done = false, ra_bounded = true, lsq_ran = false;
+  const outfit::GaussResultRec* iod_out = nullptr;  // where the last IOD run wrote (d_out or `results`)
   outfit::EphemTable table{};
   outfit::GaussParams gp{};
   outfit::TripletParams tp{};
@@ -320,6 +321,7 @@ struct Stamp {
 int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d_out) {
   HIP_TRY(hipSetDevice(s->device));
   s->last_stream = st;
+  s->iod_out = d_out ? d_out : s->results.p;
   if (s->n_traj == 0) return OUTFIT_OK;
   hipStream_t aux = s->aux_stream;
 
@@ -489,7 +491,7 @@ int session_run_lsq(outfit_hip_session* s, const outfit_diffcor_config_t* cfg,
   a.n_traj = s->n_traj; a.n_obs = s->n_obs; a.traj_offset = s->traj_offset.p;
   a.mjd = s->mjd.p; a.ra = s->ra.p; a.dec = s->dec.p; a.sra = s->sra.p; a.sdec = s->sdec.p;
   a.obs_pos = on_device_earth ? s->obs_pos.p : s->helio.p;
-  a.iod = s->results.p;
+  a.iod = s->iod_out ? s->iod_out : s->results.p;
   a.initial = initial ? s->dc_initial.p : nullptr;
   a.cfg = make_diffcor_config(cfg);
   a.part = s->dc_part.p; a.res = s->dc_res.p; a.sel = s->dc_sel.p; a.cov = s->dc_cov.p; a.qr_work = s->dc_qr.p;
