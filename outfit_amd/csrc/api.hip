@@ -102,7 +102,7 @@ struct outfit_hip_session {
   DevBuf<outfit::GaussResultRec> results;
   DevBuf<int> error_flag;
   // differential correction (allocated by the first run_lsq)
-  DevBuf<double> dc_part, dc_res, dc_cov, dc_qr;
+  DevBuf<double> dc_res, dc_cov, dc_qr;
   DevBuf<unsigned char> dc_sel;
   DevBuf<outfit::GaussResultRec> dc_initial;
   DevBuf<outfit::LsqResultRec> dc_out;
@@ -130,7 +130,7 @@ struct outfit_hip_session {
     psi0.release(); slow_list.release(); slow_count.release();
     heap_id.release(); triplets.release(); queue.release(); n_triplets.release(); flags.release();
     n_win.release(); results.release(); error_flag.release();
-    dc_part.release(); dc_res.release(); dc_cov.release(); dc_qr.release(); dc_sel.release();
+    dc_res.release(); dc_cov.release(); dc_qr.release(); dc_sel.release();
     dc_initial.release(); dc_out.release(); dc_fit.release();
     for (auto& t : timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     timed.clear();
@@ -462,10 +462,9 @@ int session_run_lsq(outfit_hip_session* s, const outfit_diffcor_config_t* cfg,
   if (s->n_traj == 0) return OUTFIT_OK;
   const size_t n_obs = (size_t)s->n_obs, n_traj = (size_t)s->n_traj;
   if (!s->dc_out.p) {
-    HIP_TRY(s->dc_part.alloc(12 * n_obs));
     HIP_TRY(s->dc_res.alloc(6 * n_obs));
     HIP_TRY(s->dc_sel.alloc(n_obs));
-    HIP_TRY(s->dc_cov.alloc(36 * n_traj));
+    HIP_TRY(s->dc_cov.alloc(72 * n_traj));
     HIP_TRY(s->dc_qr.alloc(42 * n_traj));
     HIP_TRY(s->dc_fit.alloc(n_obs));
     HIP_TRY(s->dc_initial.alloc(n_traj));
@@ -494,7 +493,7 @@ int session_run_lsq(outfit_hip_session* s, const outfit_diffcor_config_t* cfg,
   a.iod = s->iod_out ? s->iod_out : s->results.p;
   a.initial = initial ? s->dc_initial.p : nullptr;
   a.cfg = make_diffcor_config(cfg);
-  a.part = s->dc_part.p; a.res = s->dc_res.p; a.sel = s->dc_sel.p; a.cov = s->dc_cov.p; a.qr_work = s->dc_qr.p;
+  a.res = s->dc_res.p; a.sel = s->dc_sel.p; a.cov = s->dc_cov.p; a.qr_work = s->dc_qr.p;
   a.out = s->dc_out.p; a.obs_fit = s->dc_fit.p;
   {
     Stamp stamp(s, st, K_DIFFCOR);

@@ -211,15 +211,69 @@ __device__ __forceinline__ bool cholesky_inverse6(const double* n, double* inv) 
   return true;
 }
 
+// The same factorisation reading the matrix from a strided column n[i * ns] (LDS) and writing the
+// inverse column by column to out[(6*r + c) * os] (global scratch): only L (21 values) and one
+// right-hand side live in registers.
+__device__ __forceinline__ bool cholesky_inverse6_lds(const double* n, unsigned ns, double* out,
+                                                      unsigned long long os) {
+  double m[36];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) m[6 * i + j] = n[(6 * i + j) * ns];
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+#pragma unroll
+    for (int k = 0; k < j; ++k) {
+      const double factor = -m[6 * j + k];
+#pragma unroll
+      for (int i = j; i < 6; ++i) m[6 * i + j] = factor * m[6 * i + k] + m[6 * i + j];
+    }
+    const double diag = m[6 * j + j];
+    if (diag == 0.0 || !(diag >= 0.0)) ok = false;
+    const double denom = sqrt(diag);
+    m[6 * j + j] = denom;
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) m[6 * i + j] /= denom;
+  }
+  if (!ok) return false;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    double b[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) b[i] = i == c ? 1.0 : 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const double coeff = b[i] / m[6 * i + i];
+      b[i] = coeff;
+#pragma unroll
+      for (int r = i + 1; r < 6; ++r) b[r] = (-coeff) * m[6 * r + i] + b[r];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+      double dt = 0.0;
+#pragma unroll
+      for (int r = i + 1; r < 6; ++r) dt += m[6 * r + i] * b[r];
+      b[i] = (b[i] - dt) / m[6 * i + i];
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) out[(unsigned long long)(6 * r + c) * os] = b[r];
+  }
+  return true;
+}
+
 __device__ __forceinline__ double signum(double x) { return (x > 0.0 || (x == 0.0 && !signbit(x))) ? 1.0 : -1.0; }
 
 // nalgebra QR::new(m).try_inverse() (Householder), the fallback of least_square.rs:305-316.
 // Rare (normal matrix not positive definite), so the factorisation runs with rolled loops on a
 // per-lane scratch column in global memory, w[idx * stride], idx < 42 (36 matrix + 6 diagonal):
 // dynamic indexing of a register array would otherwise put the whole kernel on the scratch stack.
-__device__ __forceinline__ bool qr_inverse6(double* w, unsigned long long stride, const double* n, double* inv) {
-#pragma unroll
-  for (int i = 0; i < 36; ++i) w[i * stride] = n[i];
+// Reads the matrix from n[i * ns], writes the inverse to out[(6*r + c) * os].
+__device__ __forceinline__ bool qr_inverse6(double* w, unsigned long long stride, const double* n, unsigned ns,
+                                            double* out, unsigned long long os) {
+#pragma unroll 1
+  for (int i = 0; i < 36; ++i) w[i * stride] = n[i * ns];
 #pragma unroll 1
   for (int c = 0; c < 6; ++c) {
     double sq = 0.0;
@@ -260,7 +314,7 @@ __device__ __forceinline__ bool qr_inverse6(double* w, unsigned long long stride
     w[(36 + c) * stride] = dg;
   }
   bool ok = true;
-#pragma unroll
+#pragma unroll 1
   for (int col = 0; col < 6; ++col) {
     double b[6];
 #pragma unroll
@@ -285,7 +339,7 @@ __device__ __forceinline__ bool qr_inverse6(double* w, unsigned long long stride
       for (int r = 0; r < i; ++r) b[r] = (-coeff) * w[(6 * r + i) * stride] + b[r];
     }
 #pragma unroll
-    for (int r = 0; r < 6; ++r) inv[6 * r + col] = b[r];
+    for (int r = 0; r < 6; ++r) out[(unsigned long long)(6 * r + col) * os] = b[r];
   }
   return ok;
 }

@@ -134,10 +134,9 @@ struct DiffCorArgs {
   const GaussResultRec* iod;       // the session's own IOD results
   const GaussResultRec* initial;   // nullable: caller-provided seeds (status 0 = use)
   DiffCorConfig cfg;
-  double* part;                    // [12][n_obs]
   double* res;                     // [2][3][n_obs]
   unsigned char* sel;              // [n_obs]
-  double* cov;                     // [36][n_traj]
+  double* cov;                     // [2][36][n_traj]
   double* qr_work;                 // [42][n_traj]
   LsqResultRec* out;               // [n_traj]
   ObsFitRec* obs_fit;              // nullable [n_obs]
