@@ -66,5 +66,29 @@ int main() {
       ok += std::holds_alternative<NoFeasibleTriplets>(std::get<TrajError>(r));
     }
   }
-  return ok == 2 ? 0 : 3;
+  // FitLSQ::fit_lsq on the IOD results (differential_orbit_correction/obs_dataset_api.rs:57-99). Three
+  // observations cannot constrain six elements better than the IOD orbit itself: the corrector runs and
+  // the outcome is either a DifferentialCorrection or the IOD orbit it falls back to (mod.rs:109).
+  DifferentialCorrectionConfig cfg;
+  cfg.rms_divergence_ratio = 10.0;  // as tests/test_diff_cor.rs:52-55
+  try {
+    FullLsqResult lsq = FitLSQ::fit_lsq(ds, JPLEphem{}, params, cfg, &res);
+    for (const auto& [id, r] : lsq) {
+      if (auto d = std::get_if<DifferentialCorrectionFit>(&r))
+        std::printf("%s: DifferentialCorrection a=%.12g h=%.12g k=%.12g rms=%.3g iterations=%u sigma_a=%.3g\n",
+                    id.c_str(), d->elements.semi_major_axis, d->elements.eccentricity_sin_lon,
+                    d->elements.eccentricity_cos_lon, d->normalised_rms, d->total_newton_iterations,
+                    d->uncertainty()[0]);
+      else if (std::holds_alternative<FitOrbitResult>(r))
+        std::printf("%s: corrector gave up, IOD orbit kept\n", id.c_str());
+      else
+        std::printf("%s: Err(%s)\n", id.c_str(), FitIOD::describe(std::get<TrajError>(r)).c_str());
+    }
+    ok += lsq.size() == 2 && !std::holds_alternative<TrajError>(lsq.at("K09R05F")) &&
+          std::holds_alternative<TrajError>(lsq.at("too_short"));
+  } catch (const OutfitError& e) {
+    std::fprintf(stderr, "fit_lsq failed: %s\n", e.what());
+    return 1;
+  }
+  return ok == 3 ? 0 : 3;
 }

@@ -12,6 +12,7 @@
 //   OutfitError variants                  outfit_errors.rs:195-250
 #pragma once
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdint>
 #include <map>
@@ -175,6 +176,7 @@ class FitIOD {
   }
 
  private:
+  friend class FitLSQ;
   struct Flat {
     std::vector<TrajId> ids;
     std::vector<std::uint64_t> off;
@@ -239,6 +241,108 @@ class FitIOD {
       default:
         return TrajError{InvalidOrbit{"eccentricity must be > 1 for hyperbolic orbits"}};
     }
+  }
+};
+
+// ---- FitLSQ (differential_orbit_correction/) ---------------------------------------------------
+// DifferentialCorrectionConfig (diff_cor.rs:39-178); defaults = DifferentialCorrectionConfig::default()
+struct DifferentialCorrectionConfig : outfit_diffcor_config_t {
+  DifferentialCorrectionConfig() { outfit_hip_diffcor_config_default(this); }
+};
+struct EquinoctialElements { double reference_epoch, semi_major_axis, eccentricity_sin_lon, eccentricity_cos_lon,
+                                    tan_half_incl_sin_node, tan_half_incl_cos_node, mean_longitude; };
+// FitOrbitResult::DifferentialCorrection((OrbitalElements::Equinoctial{elements, uncertainty, covariance}, Chi2))
+struct DifferentialCorrectionFit {
+  EquinoctialElements elements;
+  std::array<double, 36> covariance;  // row-major, rescaled (least_square.rs:341-362)
+  double normalised_rms;
+  unsigned total_newton_iterations, num_measurements, n_rejected;
+  // EquinoctialUncertainty::from_covariance (orbit_type/uncertainty.rs:261-271)
+  std::array<double, 6> uncertainty() const {
+    std::array<double, 6> u{};
+    for (int j = 0; j < 6; ++j) u[j] = std::sqrt(covariance[7 * j]);
+    return u;
+  }
+  double orbit_quality() const { return normalised_rms; }
+};
+// Ok(DifferentialCorrection) | Ok(the IOD orbit, when the corrector erred: mod.rs:109) | Err
+using LsqTrajResult = std::variant<DifferentialCorrectionFit, FitOrbitResult, TrajError>;
+using FullLsqResult = std::map<TrajId, LsqTrajResult>;
+
+class FitLSQ {
+ public:
+  // fit_lsq (obs_dataset_api.rs:57-99) after the dataset preparation. `initial_orbits`: a previous
+  // FullOrbitResult; trajectories without an Ok entry get the IOD first (obs_dataset_api.rs:118-120).
+  static FullLsqResult fit_lsq(const ObsDataset& ds, const JPLEphem& jpl, const IODParams& iod_params,
+                               const DifferentialCorrectionConfig& config,
+                               const FullOrbitResult* initial_orbits = nullptr,
+                               const std::vector<double>* noise_z = nullptr, int n_devices = 0) {
+    FitIOD::Flat f = FitIOD::flatten(ds);
+    outfit_obs_batch_t b = f.batch();
+    if (noise_z) b.noise_z = noise_z->data();
+    outfit_ephem_t e{};
+    if (!jpl.empty()) e = FitIOD::ephem(jpl);
+    std::vector<outfit_gauss_result_t> init;
+    if (initial_orbits) {
+      init.assign(f.ids.size(), outfit_gauss_result_t{});
+      for (std::size_t i = 0; i < f.ids.size(); ++i) {
+        init[i].status = OUTFIT_TRAJ_NO_VIABLE_ORBIT;  // "no usable entry"
+        auto it = initial_orbits->find(f.ids[i]);
+        if (it == initial_orbits->end()) continue;
+        if (auto ok = std::get_if<FitOrbitResult>(&it->second)) init[i] = to_record(*ok);
+      }
+    }
+    std::vector<outfit_lsq_result_t> out(f.ids.size());
+    const int rc = outfit_hip_fit_lsq(&iod_params, &config, &b, jpl.empty() ? nullptr : &e,
+                                      initial_orbits ? init.data() : nullptr, n_devices, out.data(), nullptr);
+    if (rc == OUTFIT_ERR_INVALID_PARAM) throw InvalidIODParameter(outfit_hip_last_error());
+    if (rc == OUTFIT_ERR_INVALID_BATCH) throw InvalidBatch(outfit_hip_last_error());
+    if (rc != OUTFIT_OK) throw DeviceError(outfit_hip_last_error());
+    FullLsqResult res;
+    for (std::size_t i = 0; i < f.ids.size(); ++i) {
+      const outfit_lsq_result_t& r = out[i];
+      if (r.status == OUTFIT_LSQ_DIFFCOR) {
+        DifferentialCorrectionFit d{};
+        d.elements = {r.epoch, r.elem[0], r.elem[1], r.elem[2], r.elem[3], r.elem[4], r.elem[5]};
+        std::copy(r.covariance, r.covariance + 36, d.covariance.begin());
+        d.normalised_rms = r.normalised_rms;
+        d.total_newton_iterations = r.total_newton_iterations;
+        d.num_measurements = r.num_measurements;
+        d.n_rejected = r.n_rejected;
+        res.emplace(f.ids[i], d);
+      } else if (r.status == OUTFIT_LSQ_CONVERSION_ERROR) {
+        if (r.conv_error == OUTFIT_TRAJ_INVALID_CONVERSION)
+          res.emplace(f.ids[i], TrajError{InvalidConversion{"Parabolic orbit cannot be represented with finite a"}});
+        else
+          res.emplace(f.ids[i], TrajError{InvalidOrbit{"eccentricity must be > 1 for hyperbolic orbits"}});
+      } else {  // IOD_KEPT (Ok(initial_orbit)) or IOD_ERROR: both are what the IOD record says
+        TrajResult t = FitIOD::convert(r.iod, f, i, iod_params);
+        if (auto ok = std::get_if<FitOrbitResult>(&t)) res.emplace(f.ids[i], *ok);
+        else res.emplace(f.ids[i], std::get<TrajError>(t));
+      }
+    }
+    return res;
+  }
+
+ private:
+  static outfit_gauss_result_t to_record(const FitOrbitResult& fit) {
+    outfit_gauss_result_t r{};
+    r.status = OUTFIT_TRAJ_OK;
+    r.stage = fit.gauss.stage == GaussResult::CorrectedOrbit ? OUTFIT_STAGE_CORRECTED : OUTFIT_STAGE_PRELIM;
+    r.rms = fit.rms;
+    if (auto k = std::get_if<KeplerianElements>(&fit.gauss.orbit)) {
+      r.kind = OUTFIT_KIND_KEPLERIAN; r.epoch = k->reference_epoch;
+      const double e[6] = {k->semi_major_axis, k->eccentricity, k->inclination, k->ascending_node_longitude,
+                           k->periapsis_argument, k->mean_anomaly};
+      std::copy(e, e + 6, r.elem);
+    } else {
+      const auto& c = std::get<CometaryElements>(fit.gauss.orbit);
+      r.kind = OUTFIT_KIND_COMETARY; r.epoch = c.reference_epoch;
+      const double e[6] = {c.perihelion_distance, c.eccentricity, c.inclination, c.ascending_node_longitude,
+                           c.periapsis_argument, c.true_anomaly};
+      std::copy(e, e + 6, r.elem);
+    }
+    return r;
   }
 };
 

@@ -80,6 +80,9 @@ void orc_select_rms_interval(const double *mjd, size_t n_obs, const uint32_t idx
   *i_end = e;
 }
 
+/* debug counters: residual terms evaluated with the reference's pruning vs without it */
+uint64_t orc_dbg_rms_terms = 0, orc_dbg_rms_terms_full = 0;
+
 typedef struct {
   const outfit_iod_params_t *ip;
   const outfit_obs_batch_t *b;
@@ -110,9 +113,11 @@ static double rms_orbit_error(const ctx_t *c, uint64_t base, size_t n_obs, const
   double denom = 2.0 * (double)(e - s + 1);
   double cutoff = isfinite(prune) ? prune * prune * denom : INFINITY;
   double acc = 0.0;
+  __atomic_fetch_add(&orc_dbg_rms_terms_full, (uint64_t)(e - s + 1), __ATOMIC_RELAXED);
   for (size_t i = s; i <= e; ++i) {
     uint64_t o = base + i;
     double op[3], term;
+    __atomic_fetch_add(&orc_dbg_rms_terms, 1, __ATOMIC_RELAXED);
     if (observer_pos(c, o, hoist_buf ? hoist_buf + 3 * i : NULL, op)) return prune;
     if (orc_ephemeris_error(eq, b->mjd_tt[o], b->ra[o], b->dec[o], b->sigma_ra[o], b->sigma_dec[o],
                             op, &term))

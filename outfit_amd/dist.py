@@ -9,9 +9,10 @@ records are gathered once at the end (all_gather over xGMI; 96 B per trajectory)
 """
 import numpy as np
 
-from ._abi import RESULT_DTYPE
+from ._abi import LSQ_DTYPE, RESULT_DTYPE
 
 RECORD_BYTES = 96
+LSQ_RECORD_BYTES = 480
 
 
 def partition_by_observations(traj_offset, world):
@@ -36,13 +37,14 @@ def all_gather_records(local, counts, dist):
     import torch
     world = dist.get_world_size()
     n_max = max(counts)
+    width = local.shape[1]  # 96 (outfit_gauss_result_t) or 480 (outfit_lsq_result_t)
     if all(c == n_max for c in counts):
-        out = torch.empty((world * n_max, RECORD_BYTES), dtype=torch.uint8, device=local.device)
+        out = torch.empty((world * n_max, width), dtype=torch.uint8, device=local.device)
         dist.all_gather_into_tensor(out, local.contiguous())
         return out
-    pad = torch.zeros((n_max, RECORD_BYTES), dtype=torch.uint8, device=local.device)
+    pad = torch.zeros((n_max, width), dtype=torch.uint8, device=local.device)
     pad[: local.shape[0]] = local
-    out = torch.empty((world * n_max, RECORD_BYTES), dtype=torch.uint8, device=local.device)
+    out = torch.empty((world * n_max, width), dtype=torch.uint8, device=local.device)
     dist.all_gather_into_tensor(out, pad)
     return torch.cat([out[r * n_max: r * n_max + counts[r]] for r in range(world)], dim=0)
 
@@ -80,3 +82,41 @@ def fit_full_iod_distributed(batch, ephem, params, dist, device_index, compute=N
         recs = compute(sub) if counts[rank] else np.zeros(0, dtype=RESULT_DTYPE)
         local = torch.from_numpy(np.frombuffer(recs.tobytes(), dtype=np.uint8).reshape(-1, RECORD_BYTES).copy())
     return records_from_tensor(all_gather_records(local, counts, dist))
+
+
+def fit_lsq_distributed(batch, ephem, iod_params, diff_cor_config, dist, device_index, initial_orbits=None,
+                        compute=None):
+    """`FitLSQ::fit_lsq` sharded like the IOD (the reference loops over trajectories one by one,
+    differential_orbit_correction/obs_dataset_api.rs:76-96: no exchange between them). Every rank passes
+    the SAME batch (and the same optional seeds) and gets the 480-byte records of ALL trajectories.
+
+    `compute(sub_batch, sub_initial) -> LSQ records` may be injected for the CPU tests."""
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    cuts = partition_by_observations(batch.traj_offset, world)
+    counts = [cuts[r + 1] - cuts[r] for r in range(world)]
+    t0, t1 = cuts[rank], cuts[rank + 1]
+    sub = batch.slice(t0, t1)
+    if batch.noise_z is not None:
+        stride = iod_params.max_triplets * iod_params.n_noise_realizations * 6
+        sub.noise_z = batch.noise_z[t0 * stride: t1 * stride]
+    sub_init = None if initial_orbits is None else np.ascontiguousarray(initial_orbits[t0:t1])
+    if not counts[rank]:
+        recs = np.zeros(0, dtype=LSQ_DTYPE)
+    elif compute is None:
+        from .api import IODSession
+        dev = torch.device("cuda", device_index)
+        s = IODSession(sub, ephem, iod_params, device=device_index)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        if sub_init is None or (sub_init["status"] != 0).any():
+            s.run(stream=stream)
+        s.run_lsq(diff_cor_config, sub_init, stream=stream)
+        recs, _ = s.lsq_results()
+        s.close()
+    else:
+        recs = compute(sub, sub_init)
+    local = torch.from_numpy(np.frombuffer(recs.tobytes(), dtype=np.uint8).reshape(-1, LSQ_RECORD_BYTES).copy())
+    if compute is None:
+        local = local.to(torch.device("cuda", device_index))
+    out = all_gather_records(local, counts, dist)
+    return np.frombuffer(out.cpu().numpy().tobytes(), dtype=LSQ_DTYPE)

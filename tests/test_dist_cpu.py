@@ -52,6 +52,14 @@ def _oracle_compute(ephem, params):
     return compute
 
 
+def _oracle_lsq_compute(ephem, params, cfg):
+    def compute(sub, sub_init):
+        rc, res, _ = O.fit_lsq(params.as_c(), cfg.as_c(), sub.as_c(), ephem.as_c(), sub_init, 2)
+        assert rc == 0
+        return res
+    return compute
+
+
 def _worker(rank, world, port, out_dir):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
     import torch.distributed as dist
@@ -61,6 +69,12 @@ def _worker(rank, world, port, out_dir):
     recs = odist.fit_full_iod_distributed(batch, ephem, params, dist, device_index=0,
                                           compute=_oracle_compute(ephem, params))
     np.save(os.path.join(out_dir, f"rank{rank}.npy"), recs)
+    cfg = outfit_amd.DifferentialCorrectionConfig(rms_divergence_ratio=10.0)
+    seeds = recs.copy()
+    seeds["status"][::3] = 2          # a third of the seeds "missing": the IOD is rerun for them
+    lsq = odist.fit_lsq_distributed(batch, ephem, params, cfg, dist, device_index=0, initial_orbits=seeds,
+                                    compute=_oracle_lsq_compute(ephem, params, cfg))
+    np.save(os.path.join(out_dir, f"lsq_rank{rank}.npy"), lsq)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -88,3 +102,13 @@ def test_two_rank_gloo_gather_equals_single_process(tmp_path):
         assert got.dtype == ref.dtype and got.shape == ref.shape
         assert got.tobytes() == ref.tobytes(), f"rank {rank} gathered records differ from the single-process run"
     assert (ref["status"] == 1).sum() >= 2 and (ref["status"] == 0).sum() >= 10
+    # the differential-correction records (480 B) through the same partition + padded gather
+    cfg = outfit_amd.DifferentialCorrectionConfig(rms_divergence_ratio=10.0)
+    seeds = ref.copy()
+    seeds["status"][::3] = 2
+    lsq_ref = _oracle_lsq_compute(ephem, params, cfg)(batch, seeds)
+    for rank in range(world):
+        got = np.load(os.path.join(tmp_path, f"lsq_rank{rank}.npy"))
+        assert got.dtype == lsq_ref.dtype and got.shape == lsq_ref.shape
+        assert got.tobytes() == lsq_ref.tobytes(), f"rank {rank}: gathered LSQ records differ"
+    assert (lsq_ref["status"] == 0).sum() >= 5
