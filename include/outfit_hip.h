@@ -315,6 +315,32 @@ int outfit_hip_session_run_lsq(outfit_hip_session_t *s, const outfit_diffcor_con
 int outfit_hip_session_lsq_results(outfit_hip_session_t *s, outfit_lsq_result_t *out,
                                    outfit_obs_fit_t *obs_fit /* nullable */);
 
+/* ==== next row: legacy JPL DE binary reader -> outfit_ephem_t =================
+ * Host-side only (no GPU needed). Replaces HorizonData::read_horizon_file
+ * (jpl_ephem/horizon/horizon_data.rs:533-642) for what the path consumes: the header and the
+ * Chebyshev segments of EMB, Moon and Sun (IPT rows 2, 9, 10). Little-endian files
+ * (the "Linux" distribution the reference downloads, horizon_version.rs). */
+typedef struct outfit_de_header {       /* HorizonHeader (horizon_data.rs:130-160) + what sizes the file */
+  double   start_period;                /* SS[0], JD */
+  double   end_period;                  /* SS[1]     */
+  double   period_length;               /* SS[2] (`period_lenght`), days per record */
+  double   earth_moon_mass_ratio;       /* EMRAT     */
+  double   au_km;                       /* AU constant of the header (the reference skips it) */
+  uint32_t ipt[15][3];                  /* [offset (1-based), n_coeffs, n_subintervals]; rows 13/14 = 0 when absent */
+  uint32_t numde;                       /* 440 -> jpl_version "DE440" */
+  int32_t  ncon;
+  uint64_t recsize;                     /* bytes per record (8144 for DE440) */
+  uint64_t n_blocks;                    /* data records in the file */
+} outfit_de_header_t;
+typedef struct outfit_ephem_file outfit_ephem_file_t;
+#define OUTFIT_ERR_EPHEM_FILE -7        /* cannot open / not a DE file / truncated (the reference panics) */
+
+int  outfit_hip_ephem_open(const char *path, outfit_ephem_file_t **out);
+int  outfit_hip_ephem_header(const outfit_ephem_file_t *e, outfit_de_header_t *header);
+/* `view->coef` points into the handle and stays valid until outfit_hip_ephem_close. */
+int  outfit_hip_ephem_view(const outfit_ephem_file_t *e, outfit_ephem_t *view);
+void outfit_hip_ephem_close(outfit_ephem_file_t *e);
+
 /* ---- diagnostics ------------------------------------------------------------ */
 /* Device self-test: the kernels replace some fp64 divisions by cheaper sequences that
  * must give the SAME bits as IEEE division (outfit_amd/csrc/device/fastdiv.hpp); this

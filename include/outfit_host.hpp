@@ -109,6 +109,20 @@ struct JPLEphem {  // legacy-DE subset, layout of outfit_ephem_t; empty = use th
   std::uint32_t ncoef[3] = {13, 13, 11}, nsub[3] = {2, 8, 2};
   std::vector<double> coef;
   bool empty() const { return coef.empty(); }
+  // HorizonData::read_horizon_file (jpl_ephem/horizon/horizon_data.rs:533-642): a little-endian legacy-DE binary
+  static JPLEphem from_file(const std::string& path) {
+    outfit_ephem_file_t* h = nullptr;
+    if (outfit_hip_ephem_open(path.c_str(), &h) != OUTFIT_OK) throw OutfitError(outfit_hip_last_error());
+    outfit_ephem_t v{};
+    outfit_hip_ephem_view(h, &v);
+    JPLEphem e;
+    e.jd_start = v.jd_start; e.jd_end = v.jd_end; e.block_days = v.block_days; e.emrat = v.emrat;
+    std::size_t per = 0;
+    for (int k = 0; k < 3; ++k) { e.ncoef[k] = v.ncoef[k]; e.nsub[k] = v.nsub[k]; per += 3u * v.ncoef[k] * v.nsub[k]; }
+    e.coef.assign(v.coef, v.coef + v.n_blocks * per);
+    outfit_hip_ephem_close(h);
+    return e;
+  }
 };
 
 // ---- results ----------------------------------------------------------------------------

@@ -16,6 +16,7 @@ OUTFIT_ERR_NO_DEVICE = -3
 OUTFIT_ERR_HIP = -4
 OUTFIT_ERR_EPHEM_RANGE = -5
 OUTFIT_ERR_BAD_HANDLE = -6
+OUTFIT_ERR_EPHEM_FILE = -7
 
 TRAJ_OK = 0
 TRAJ_NO_FEASIBLE_TRIPLETS = 1
@@ -199,3 +200,16 @@ LSQ_DTYPE = [
 ]
 OBS_FIT_DTYPE = [("residual_ra", "<f8"), ("residual_dec", "<f8"), ("chi", "<f8"),
                  ("selection", "<i4"), ("_pad", "<i4")]
+
+
+class DeHeaderC(C.Structure):
+    """`outfit_de_header_t` (HorizonHeader, jpl_ephem/horizon/horizon_data.rs:130-160)."""
+    _fields_ = [
+        ("start_period", C.c_double), ("end_period", C.c_double), ("period_length", C.c_double),
+        ("earth_moon_mass_ratio", C.c_double), ("au_km", C.c_double),
+        ("ipt", (C.c_uint32 * 3) * 15), ("numde", C.c_uint32), ("ncon", C.c_int32),
+        ("recsize", C.c_uint64), ("n_blocks", C.c_uint64),
+    ]
+
+
+assert C.sizeof(DeHeaderC) == 40 + 180 + 8 + 16 + 4  # 4 bytes of padding after the 15x3 u32 + numde + ncon

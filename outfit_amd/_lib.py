@@ -7,7 +7,7 @@ import ctypes as C
 import os
 import subprocess
 
-from ._abi import (ABI_VERSION, DiffCorConfigC, EphemC, GaussResultC, IODParamsC, LsqResultC, ObsBatchC,
+from ._abi import (ABI_VERSION, DeHeaderC, DiffCorConfigC, EphemC, GaussResultC, IODParamsC, LsqResultC, ObsBatchC,
                    ObsFitC)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -77,6 +77,11 @@ def lib():
                                      C.POINTER(LsqResultC), C.POINTER(ObsFitC)]
     L.outfit_hip_session_run_lsq.argtypes = [vp, C.POINTER(DiffCorConfigC), C.POINTER(GaussResultC), vp]
     L.outfit_hip_session_lsq_results.argtypes = [vp, C.POINTER(LsqResultC), C.POINTER(ObsFitC)]
+    L.outfit_hip_ephem_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.outfit_hip_ephem_header.argtypes = [vp, C.POINTER(DeHeaderC)]
+    L.outfit_hip_ephem_view.argtypes = [vp, C.POINTER(EphemC)]
+    L.outfit_hip_ephem_close.argtypes = [vp]
+    L.outfit_hip_ephem_close.restype = None
     _lib = L
     return L
 
@@ -89,6 +94,7 @@ EXPORTED_SYMBOLS = [
     "outfit_hip_last_error", "outfit_hip_abi_version", "outfit_hip_device_count",
     "outfit_hip_selftest_division", "outfit_hip_diffcor_config_default", "outfit_hip_diffcor_config_validate",
     "outfit_hip_fit_lsq", "outfit_hip_session_run_lsq", "outfit_hip_session_lsq_results",
+    "outfit_hip_ephem_open", "outfit_hip_ephem_header", "outfit_hip_ephem_view", "outfit_hip_ephem_close",
 ]
 
 

@@ -17,7 +17,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from . import _abi
-from ._abi import (DiffCorConfigC, EphemC, GaussResultC, IODParamsC, LSQ_DTYPE, LsqResultC, OBS_FIT_DTYPE,
+from ._abi import (DeHeaderC, DiffCorConfigC, EphemC, GaussResultC, IODParamsC, LSQ_DTYPE, LsqResultC, OBS_FIT_DTYPE,
                    ObsBatchC, ObsFitC, RESULT_DTYPE)
 from ._lib import NativeLibraryError, last_error, lib
 
@@ -43,6 +43,10 @@ class EphemerisRange(OutfitError):
 
 class HipRuntimeError(OutfitError):
     pass
+
+
+class EphemerisFileError(OutfitError):
+    """The DE file cannot be opened or parsed (the reference panics: horizon_data.rs:546-553)."""
 
 
 @dataclass
@@ -85,6 +89,8 @@ def _raise_rc(rc):
         raise EphemerisRange(msg)
     if rc == _abi.OUTFIT_ERR_NO_DEVICE:
         raise NativeLibraryError(msg)
+    if rc == _abi.OUTFIT_ERR_EPHEM_FILE:
+        raise EphemerisFileError(msg)
     raise HipRuntimeError(f"rc={rc}: {msg}")
 
 
@@ -158,6 +164,31 @@ class Ephemeris:
     def from_dict(cls, d):
         return cls(d["jd_start"], d["jd_end"], d["block_days"], d["emrat"], d["ncoef"], d["nsub"],
                    d["n_blocks"], d["coef"])
+
+    @classmethod
+    def from_file(cls, path):
+        """`HorizonData::read_horizon_file` (horizon_data.rs:533-642) through `outfit_hip_ephem_open`: the
+        EMB / Moon / Sun segments of a little-endian legacy-DE binary. Sets `.header` (dict)."""
+        L = lib()
+        h = C.c_void_p()
+        rc = L.outfit_hip_ephem_open(str(path).encode(), C.byref(h))
+        if rc != 0:
+            _raise_rc(rc)
+        try:
+            view, hd = EphemC(), DeHeaderC()
+            L.outfit_hip_ephem_view(h, C.byref(view))
+            L.outfit_hip_ephem_header(h, C.byref(hd))
+            per = sum(3 * view.ncoef[b] * view.nsub[b] for b in range(3))
+            coef = np.ctypeslib.as_array(view.coef, shape=(view.n_blocks * per,)).copy()
+            e = cls(view.jd_start, view.jd_end, view.block_days, view.emrat, tuple(view.ncoef), tuple(view.nsub),
+                    view.n_blocks, coef)
+            e.header = {"jpl_version": f"DE{hd.numde}", "ipt": [list(r) for r in hd.ipt],
+                        "start_period": hd.start_period, "end_period": hd.end_period,
+                        "period_lenght": hd.period_length, "recsize": hd.recsize,
+                        "earth_moon_mass_ratio": hd.earth_moon_mass_ratio, "ncon": hd.ncon, "n_blocks": hd.n_blocks}
+            return e
+        finally:
+            L.outfit_hip_ephem_close(h)
 
     def as_c(self):
         e = EphemC()

@@ -28,6 +28,12 @@ int fail(int code, const std::string& msg) {
   return code;
 }
 
+}  // namespace
+namespace outfit {
+int set_last_error(int code, const std::string& msg) { return fail(code, msg); }  // for ephem_file.hip
+}
+namespace {
+
 #define HIP_TRY(expr)                                                                         \
   do {                                                                                        \
     hipError_t e__ = (expr);                                                                  \
