@@ -208,6 +208,7 @@ def main():
             # HBM bytes of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
             # separate runs; profiles/), scaled to one launch; null when no profile matches
             traffic = None
+            valu = None
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
                 key = dom.replace("k_orbit_rms_slow", "k_orbit_rms<true>").replace("k_orbit_rms", "k_orbit_rms<false>") \
@@ -215,10 +216,16 @@ def main():
                 key = {"k_triplet_select": "k_triplet_select_lds"}.get(key, key)
                 per_step = pmc["kernels"][key]["hbm_bytes_per_step"] * (n_obj / pmc["objects_per_step"])
                 traffic = per_step * args.steps / launches
+                # the bound that actually limits this path: fp64 VALU issue. Wave-instructions of the kernel
+                # (PMC SQ_INSTS_VALU, committed profile) x ~4.3 clocks per fp64-dominated instruction on
+                # 1024 SIMDs at ~2.1 GHz, against its measured duration
+                instr = pmc["kernels"][key]["valu_wave_instr"] * (n_obj / pmc["objects_per_step"]) * args.steps / launches
+                valu = {"wave_instr_per_launch": instr, "issue_frac": instr / 5.0e11 / (avg_ms * 1e-3),
+                        "peak_wave_instr_per_s": 5.0e11, "source": pmc["source"]}
             except (OSError, KeyError, ValueError):
                 pass
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "valu": valu,
                     "avg_launch_ms": avg_ms, "units_per_launch": units, "algorithmic_bytes_per_object": bytes_per_obj,
                     "all_kernels_avg_ms_per_step": {k: v[0] / args.steps for k, v in ktimes.items()}}
         line = {

@@ -508,6 +508,49 @@ int session_run_lsq(outfit_hip_session* s, const outfit_diffcor_config_t* cfg,
   return OUTFIT_OK;
 }
 
+// Contiguous trajectory ranges balanced by observation count, one host thread per device, no exchange
+// step (all tasks are independent: obs_dataset_api.rs:277-296). `work(device, sub_batch, t0)` runs one shard.
+template <typename Work>
+int run_sharded(const outfit_iod_params_t* params, const outfit_obs_batch_t* batch, int n_devices, Work work) {
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+    return fail(OUTFIT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+  if (n_devices <= 0 || n_devices > n_dev) n_devices = n_dev;
+  if (batch->n_traj == 0) return OUTFIT_OK;
+  n_devices = (int)std::min<uint64_t>((uint64_t)n_devices, batch->n_traj);
+  const uint64_t o0 = batch->traj_offset[0], total = batch->traj_offset[batch->n_traj] - o0;
+  std::vector<uint64_t> cut(n_devices + 1, batch->n_traj);
+  cut[0] = 0;
+  for (int d = 1; d < n_devices; ++d) {
+    const uint64_t target = o0 + total * (uint64_t)d / (uint64_t)n_devices;
+    const uint64_t* lo = std::lower_bound(batch->traj_offset, batch->traj_offset + batch->n_traj, target);
+    cut[d] = std::max<uint64_t>(cut[d - 1], (uint64_t)(lo - batch->traj_offset));
+  }
+  std::vector<int> rc(n_devices, OUTFIT_OK);
+  std::vector<std::string> msg(n_devices);
+  auto shard = [&](int d) {
+    const uint64_t t0 = cut[d], t1 = cut[d + 1];
+    if (t1 <= t0) return;
+    outfit_obs_batch_t sub = *batch;
+    sub.n_traj = t1 - t0;
+    sub.traj_offset = batch->traj_offset + t0;
+    if (batch->noise_z)
+      sub.noise_z = batch->noise_z + (size_t)t0 * params->max_triplets * (size_t)params->n_noise_realizations * 6;
+    rc[d] = work(d, sub, t0);
+    if (rc[d] != OUTFIT_OK) msg[d] = g_last_error;  // thread-local: keep the shard's message
+  };
+  if (n_devices == 1) {
+    shard(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int d = 0; d < n_devices; ++d) th.emplace_back(shard, d);
+    for (auto& t : th) t.join();
+  }
+  for (int d = 0; d < n_devices; ++d)
+    if (rc[d] != OUTFIT_OK) return fail(rc[d], msg[d]);
+  return OUTFIT_OK;
+}
+
 int collect_times(outfit_hip_session* s) {
   for (int k = 0; k < K_COUNT; ++k) { s->kernel_ms[k] = 0.f; s->kernel_launches[k] = 0; }
   for (auto& t : s->timed) {
@@ -631,51 +674,16 @@ int outfit_hip_fit_full_iod(const outfit_iod_params_t* params, const outfit_obs_
   TRY_RC(outfit_hip_iod_params_validate(params));
   TRY_RC(check_batch(params, batch, ephem));
   if (!out && batch->n_traj) return fail(OUTFIT_ERR_INVALID_BATCH, "out is NULL");
-  int n_dev = 0;
-  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
-    return fail(OUTFIT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
-  if (n_devices <= 0 || n_devices > n_dev) n_devices = n_dev;
-  if (batch->n_traj == 0) return OUTFIT_OK;
-  n_devices = (int)std::min<uint64_t>((uint64_t)n_devices, batch->n_traj);
-
-  // contiguous ranges balanced by observation count (all tasks are independent:
-  // obs_dataset_api.rs:277-296), one host thread per device, no exchange step.
-  const uint64_t o0 = batch->traj_offset[0], total = batch->traj_offset[batch->n_traj] - o0;
-  std::vector<uint64_t> cut(n_devices + 1, batch->n_traj);
-  cut[0] = 0;
-  for (int d = 1; d < n_devices; ++d) {
-    const uint64_t target = o0 + total * (uint64_t)d / (uint64_t)n_devices;
-    const uint64_t* lo = std::lower_bound(batch->traj_offset, batch->traj_offset + batch->n_traj, target);
-    cut[d] = std::max<uint64_t>(cut[d - 1], (uint64_t)(lo - batch->traj_offset));
-  }
-  std::vector<int> rc(n_devices, OUTFIT_OK);
-  std::vector<std::string> msg(n_devices);
-  auto work = [&](int d) {
-    const uint64_t t0 = cut[d], t1 = cut[d + 1];
-    if (t1 <= t0) return;
-    outfit_obs_batch_t sub = *batch;
-    sub.n_traj = t1 - t0;
-    sub.traj_offset = batch->traj_offset + t0;
-    if (batch->noise_z)
-      sub.noise_z = batch->noise_z + (size_t)t0 * params->max_triplets * (size_t)params->n_noise_realizations * 6;
+  return run_sharded(params, batch, n_devices, [&](int d, const outfit_obs_batch_t& sub, uint64_t t0) {
     outfit_hip_session_t* s = nullptr;
     int r = outfit_hip_session_create(params, &sub, ephem, d, &s);
     if (r == OUTFIT_OK) r = outfit_hip_session_run(s, nullptr, nullptr);
     if (r == OUTFIT_OK) r = outfit_hip_session_results(s, out + t0);
-    if (r != OUTFIT_OK) msg[d] = g_last_error;
+    const std::string keep = g_last_error;
     outfit_hip_session_destroy(s);
-    rc[d] = r;
-  };
-  if (n_devices == 1) {
-    work(0);
-  } else {
-    std::vector<std::thread> th;
-    for (int d = 0; d < n_devices; ++d) th.emplace_back(work, d);
-    for (auto& t : th) t.join();
-  }
-  for (int d = 0; d < n_devices; ++d)
-    if (rc[d] != OUTFIT_OK) return fail(rc[d], msg[d]);
-  return OUTFIT_OK;
+    g_last_error = keep;
+    return r;
+  });
 }
 
 void outfit_hip_diffcor_config_default(outfit_diffcor_config_t* c) {
@@ -727,54 +735,21 @@ int outfit_hip_fit_lsq(const outfit_iod_params_t* params, const outfit_diffcor_c
   TRY_RC(outfit_hip_diffcor_config_validate(config));
   TRY_RC(check_batch(params, batch, ephem));
   if (!out && batch->n_traj) return fail(OUTFIT_ERR_INVALID_BATCH, "out is NULL");
-  int n_dev = 0;
-  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
-    return fail(OUTFIT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
-  if (n_devices <= 0 || n_devices > n_dev) n_devices = n_dev;
-  if (batch->n_traj == 0) return OUTFIT_OK;
-  n_devices = (int)std::min<uint64_t>((uint64_t)n_devices, batch->n_traj);
-
-  const uint64_t o0 = batch->traj_offset[0], total = batch->traj_offset[batch->n_traj] - o0;
-  std::vector<uint64_t> cut(n_devices + 1, batch->n_traj);
-  cut[0] = 0;
-  for (int d = 1; d < n_devices; ++d) {
-    const uint64_t target = o0 + total * (uint64_t)d / (uint64_t)n_devices;
-    const uint64_t* lo = std::lower_bound(batch->traj_offset, batch->traj_offset + batch->n_traj, target);
-    cut[d] = std::max<uint64_t>(cut[d - 1], (uint64_t)(lo - batch->traj_offset));
-  }
-  std::vector<int> rc(n_devices, OUTFIT_OK);
-  std::vector<std::string> msg(n_devices);
-  auto work = [&](int d) {
-    const uint64_t t0 = cut[d], t1 = cut[d + 1];
-    if (t1 <= t0) return;
-    outfit_obs_batch_t sub = *batch;
-    sub.n_traj = t1 - t0;
-    sub.traj_offset = batch->traj_offset + t0;
-    if (batch->noise_z)
-      sub.noise_z = batch->noise_z + (size_t)t0 * params->max_triplets * (size_t)params->n_noise_realizations * 6;
+  return run_sharded(params, batch, n_devices, [&](int d, const outfit_obs_batch_t& sub, uint64_t t0) {
     // the IOD runs only when some trajectory has no usable seed (obs_dataset_api.rs:118-120, mod.rs:86)
     bool need_iod = initial == nullptr;
-    for (uint64_t t = t0; t < t1 && !need_iod; ++t) need_iod = initial[t].status != OUTFIT_TRAJ_OK;
+    for (uint64_t t = t0; t < t0 + sub.n_traj && !need_iod; ++t) need_iod = initial[t].status != OUTFIT_TRAJ_OK;
     outfit_hip_session_t* s = nullptr;
     int r = outfit_hip_session_create(params, &sub, ephem, d, &s);
     if (r == OUTFIT_OK && need_iod) r = outfit_hip_session_run(s, nullptr, nullptr);
     if (r == OUTFIT_OK) r = outfit_hip_session_run_lsq(s, config, initial ? initial + t0 : nullptr, nullptr);
     if (r == OUTFIT_OK)
       r = outfit_hip_session_lsq_results(s, out + t0, obs_fit ? obs_fit + batch->traj_offset[t0] : nullptr);
-    if (r != OUTFIT_OK) msg[d] = g_last_error;
+    const std::string keep = g_last_error;
     outfit_hip_session_destroy(s);
-    rc[d] = r;
-  };
-  if (n_devices == 1) {
-    work(0);
-  } else {
-    std::vector<std::thread> th;
-    for (int d = 0; d < n_devices; ++d) th.emplace_back(work, d);
-    for (auto& t : th) t.join();
-  }
-  for (int d = 0; d < n_devices; ++d)
-    if (rc[d] != OUTFIT_OK) return fail(rc[d], msg[d]);
-  return OUTFIT_OK;
+    g_last_error = keep;
+    return r;
+  });
 }
 
 int outfit_hip_selftest_division(uint64_t n_pairs, uint64_t seed, uint64_t* mismatches) {

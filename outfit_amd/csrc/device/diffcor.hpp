@@ -74,25 +74,8 @@ __device__ __forceinline__ bool obs_and_partials(const Equinoctial& q, const Par
   const double dt = mjd - q.epoch;
   double lam = principal_angle_fast(q.lambda + F.n * (dt - 0.0));
   if (lam < F.varpi) lam += kTwoPi;
-  constexpr double eps = kEps * 1e2;
-  double x = kPi + F.varpi;
-  double sx, cx;
-  int iter = 0;
-  for (;;) {  // roots::find_root_newton_raphson, at most 25 iterations
-    sincos(x, &sx, &cx);
-    const double f = x - q.k * sx + q.h * cx - lam;
-    const double d = 1.0 - q.k * cx - q.h * sx;
-    if (fabs(f) < eps) break;
-    if (fabs(d) < eps) {
-      if (iter == 0) { x = x + 1.0; iter = 1; continue; }
-      return false;
-    }
-    const double x1 = x - f / d;
-    if (fabs(x - x1) < eps) { x = x1; sincos(x, &sx, &cx); break; }
-    x = x1;
-    iter = iter + 1;
-    if (iter >= 25) return false;
-  }
+  double x, sx, cx;
+  if (!solve_kepler_equation(q, F, lam, x, sx, cx)) return false;
   const double a = q.a;
   const double xe = a * (F.one_bh2 * cx + F.bet * sx - q.k);
   const double ye = a * (F.one_bk2 * sx + F.bet * cx - q.h);
@@ -164,54 +147,9 @@ __device__ __forceinline__ double angular_diff(double a, double b) {
   return d;
 }
 
-// nalgebra Cholesky::new + inverse() on m[6*i+j]; false = not positive definite
-__device__ __forceinline__ bool cholesky_inverse6(const double* n, double* inv) {
-  double m[36];
-#pragma unroll
-  for (int i = 0; i < 36; ++i) m[i] = n[i];
-  bool ok = true;
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {
-#pragma unroll
-    for (int k = 0; k < j; ++k) {
-      const double factor = -m[6 * j + k];
-#pragma unroll
-      for (int i = j; i < 6; ++i) m[6 * i + j] = factor * m[6 * i + k] + m[6 * i + j];
-    }
-    const double diag = m[6 * j + j];
-    if (diag == 0.0 || !(diag >= 0.0)) ok = false;  // later columns are never read when !ok
-    const double denom = sqrt(diag);
-    m[6 * j + j] = denom;
-#pragma unroll
-    for (int i = j + 1; i < 6; ++i) m[6 * i + j] /= denom;
-  }
-  if (!ok) return false;
-#pragma unroll
-  for (int c = 0; c < 6; ++c) {
-    double b[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) b[i] = i == c ? 1.0 : 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const double coeff = b[i] / m[6 * i + i];
-      b[i] = coeff;
-#pragma unroll
-      for (int r = i + 1; r < 6; ++r) b[r] = (-coeff) * m[6 * r + i] + b[r];
-    }
-#pragma unroll
-    for (int i = 5; i >= 0; --i) {
-      double dt = 0.0;
-#pragma unroll
-      for (int r = i + 1; r < 6; ++r) dt += m[6 * r + i] * b[r];
-      b[i] = (b[i] - dt) / m[6 * i + i];
-    }
-#pragma unroll
-    for (int r = 0; r < 6; ++r) inv[6 * r + c] = b[r];
-  }
-  return true;
-}
-
-// The same factorisation reading the matrix from a strided column n[i * ns] (LDS) and writing the
+// nalgebra Cholesky::new + inverse() (linalg/cholesky.rs, column-oriented; forward then adjoint
+// substitution on the identity), operation for operation; false = not positive definite.
+// Reads the matrix from a strided column n[i * ns] (LDS) and writes the
 // inverse column by column to out[(6*r + c) * os] (global scratch): only L (21 values) and one
 // right-hand side live in registers.
 __device__ __forceinline__ bool cholesky_inverse6_lds(const double* n, unsigned ns, double* out,

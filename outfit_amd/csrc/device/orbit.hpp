@@ -182,6 +182,8 @@ __device__ __forceinline__ int to_equinoctial(const Elements& el, Equinoctial& e
 // Candidate-constant part of propagate_twobody, hoisted out of the observation loop.
 struct TwoBodyFrame {
   double n, e2, varpi, beta, bet, one_bh2, one_bk2;
+  double x0, sx0, cx0;  // Newton start pi + varpi (equinoctial_element.rs:337) and its sine / cosine:
+                        // the same for every observation of the candidate, evaluated once
   Vec3 f, g;
 };
 
@@ -200,7 +202,37 @@ __device__ __forceinline__ TwoBodyFrame twobody_frame(const Equinoctial& q) {
   const double cc = 2.0 * q.p * q.q * inv_u;
   F.f = {(1.0 - q.p * q.p + q.q * q.q) * inv_u, cc, -2.0 * q.p * inv_u};
   F.g = {cc, (1.0 + q.p * q.p - q.q * q.q) * inv_u, 2.0 * q.q * inv_u};
+  F.x0 = kPi + F.varpi;
+  sincos(F.x0, &F.sx0, &F.cx0);
   return F;
+}
+
+// equinoctial_element.rs:326-348: roots::find_root_newton_raphson on F - k sin F + h cos F = lambda1 from
+// F0 = pi + varpi, SimpleConvergency{eps: 100*EPSILON, max_iter: 25}; also returns sin F, cos F.
+// false = Err(RootFindingError)
+__device__ __forceinline__ bool solve_kepler_equation(const Equinoctial& q, const TwoBodyFrame& F, double lam,
+                                                      double& x, double& sx, double& cx) {
+  constexpr double eps = kEps * 1e2;
+  x = F.x0; sx = F.sx0; cx = F.cx0;
+  int iter = 0;
+  for (;;) {
+    const double f = x - q.k * sx + q.h * cx - lam;
+    const double d = 1.0 - q.k * cx - q.h * sx;
+    if (fabs(f) < eps) return true;
+    if (fabs(d) < eps) {
+      if (iter != 0) return false;
+      x = x + 1.0;
+      iter = 1;
+    } else {
+      const double x1 = x - f / d;
+      const bool conv = fabs(x - x1) < eps;
+      x = x1;
+      if (conv) { sincos(x, &sx, &cx); return true; }
+      iter = iter + 1;
+      if (iter >= 25) return false;
+    }
+    sincos(x, &sx, &cx);
+  }
 }
 
 // equinoctial_element.rs:809-867 with t0 = 0, t1 = dt ; false = Err(RootFindingError)
@@ -209,25 +241,8 @@ __device__ __forceinline__ bool propagate_twobody(const Equinoctial& q, const Tw
   double lam = principal_angle_fast(q.lambda + F.n * (dt - 0.0));
   if (lam < F.varpi) lam += kTwoPi;
   // roots::find_root_newton_raphson, SimpleConvergency{eps: 100*EPSILON, max_iter: 25}
-  constexpr double eps = kEps * 1e2;
-  double x = kPi + F.varpi;
-  double sx, cx;
-  int iter = 0;
-  for (;;) {
-    sincos(x, &sx, &cx);
-    const double f = x - q.k * sx + q.h * cx - lam;
-    const double d = 1.0 - q.k * cx - q.h * sx;
-    if (fabs(f) < eps) break;
-    if (fabs(d) < eps) {
-      if (iter == 0) { x = x + 1.0; iter = 1; continue; }
-      return false;
-    }
-    const double x1 = x - f / d;
-    if (fabs(x - x1) < eps) { x = x1; sincos(x, &sx, &cx); break; }
-    x = x1;
-    iter = iter + 1;
-    if (iter >= 25) return false;
-  }
+  double x, sx, cx;
+  if (!solve_kepler_equation(q, F, lam, x, sx, cx)) return false;
   const double xe = q.a * (F.one_bh2 * cx + F.bet * sx - q.k);
   const double ye = q.a * (F.one_bk2 * sx + F.bet * cx - q.h);
   pos = {xe * F.f.x + ye * F.g.x, xe * F.f.y + ye * F.g.y, xe * F.f.z + ye * F.g.z};

@@ -523,7 +523,7 @@ __device__ __forceinline__ void select_rms_interval(const double* mjd, unsigned 
 // kSlowList = false: every candidate of the chunk except those marked kFlagSlow (their state is
 // being produced concurrently by the general correction kernel); true: exactly the slow list.
 template <bool kSlowList>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)
 k_orbit_rms(RmsArgs a) {
   const unsigned long long lid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long cid = lid;
