@@ -15,6 +15,14 @@ constexpr double kF64Max = 1.7976931348623157e308;
 __device__ __forceinline__ void lds_add(double* acc, double v) {
   (void)__hip_atomic_fetch_add(acc, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+
+// sum of an integer over the kG consecutive lanes of a group (all of them alive and converged here)
+template <unsigned kG>
+__device__ __forceinline__ unsigned group_sum(unsigned v) {
+#pragma unroll
+  for (unsigned m = 1; m < kG; m <<= 1) v += __shfl_xor(v, m);
+  return v;
+}
 }  // namespace
 
 // Per-observation scratch (global, indexed by observation row o):
@@ -27,13 +35,22 @@ __device__ __forceinline__ void lds_add(double* acc, double v) {
 // in every Newton iteration (measured: -28 % kernel time).
 // Per-trajectory scratch: cov[b][36][n_traj] = OrbitalUncertainty.covariance, double-buffered like `res`
 // (b = cur: inverse of the running iteration, b = cur^1: last accepted iteration).
-__global__ void __launch_bounds__(64, 1)
+//
+// kG lanes share one trajectory (kG = 1, 2, 4, 8): lane `sub` evaluates observations i = sub (mod kG), the
+// group then adds its kG terms to the shared LDS accumulators one lane after the other, in observation
+// order, so every accumulator still sums the observations left to right exactly as the reference's
+// sequential loop does. Everything after the loop (inverse, bookkeeping) is computed redundantly by the
+// kG lanes on identical inputs. The kernel is bound by the serial chain of its slowest trajectory
+// (iterations x observations), not by throughput: kG lanes cut that chain by almost kG.
+template <unsigned kG>
+__global__ void __launch_bounds__(64, 2)
 k_diffcor(DiffCorArgs A) {
-  // normal matrix and right-hand side accumulate in LDS ([entry][lane], conflict-free): 42 doubles per
-  // lane that would otherwise stay live across the whole observation loop
-  __shared__ double sN[42][64];
-  const unsigned lane = threadIdx.x;
-  const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  // normal matrix (36), right-hand side (6) and weighted square sum (1) accumulate in LDS, [entry][slot]
+  constexpr unsigned kSlots = 64 / kG;
+  __shared__ double sN[43][kSlots];
+  const unsigned lane = threadIdx.x / kG;   // LDS slot of this lane's trajectory
+  const unsigned sub = threadIdx.x % kG;
+  const unsigned long long t = (unsigned long long)blockIdx.x * kSlots + lane;
   if (t >= A.n_traj) return;
   const DiffCorConfig& C = A.cfg;
   LsqResultRec* out = A.out + t;
@@ -45,7 +62,6 @@ k_diffcor(DiffCorArgs A) {
     const GaussResultRec given = A.initial[t];
     if (given.status == 0) seed = given;  // Some(Ok(orbit)) ; anything else => run_iod_on_observations
   }
-  out->iod = seed;
   int status = 0, dc_error = 0, conv_error = 0;
   unsigned total_iters = 0, outer_started = 0, last_num_meas = 0, n_rejected = 0;
   double last_rms = kF64Max;
@@ -82,28 +98,48 @@ k_diffcor(DiffCorArgs A) {
         total_iters += 1;
         // ---- single_iteration (single_iteration.rs:158-328) --------------------------------
         const PartialsFrame P = partials_frame(q);
-        double wss = 0.0;
 #pragma unroll
-        for (int i = 0; i < 42; ++i) sN[i][lane] = 0.0;
+        for (int i = 0; i < 43; ++i) sN[i][lane] = 0.0;
         unsigned active = 0;
         double* rc_ = A.res + (unsigned long long)cur * RB;
         const double* ra_ = A.res + (unsigned long long)(cur ^ 1u) * RB;
 #pragma unroll 1
-        for (unsigned i = 0; i < n; ++i) {
+        for (unsigned i0 = 0; i0 < n; i0 += kG) {
+          const unsigned i = i0 + sub;
           const unsigned long long o = base + i;
-          const unsigned char s = sel_written ? A.sel[o] : (unsigned char)0;
           bool eq_active = false;
-          if (s == 0) {
-            ObsPartials ob;
-            const Vec3 op = {A.obs_pos[3 * o], A.obs_pos[3 * o + 1], A.obs_pos[3 * o + 2]};
-            if (obs_and_partials(q, P, A.mjd[o], op, ob)) {
-              eq_active = true;
-              const double sra = A.sra[o], sdec = A.sdec[o];
-              const double rra = angular_diff(A.ra[o] - 0.0, ob.ra);
-              const double rdec = (A.dec[o] - 0.0) - ob.dec;
-              const double ta = rra / sra, td = rdec / sdec;
-              const double chi = sqrt(ta * ta + td * td);
-              const double wa = 1.0 / (sra * sra), wd = 1.0 / (sdec * sdec), wc = 0.0;
+          ObsPartials ob;
+          double rra = 0.0, rdec = 0.0, wa = 0.0, wd = 0.0;
+          if (i < n) {
+            const unsigned char s = sel_written ? A.sel[o] : (unsigned char)0;
+            if (s == 0) {
+              const Vec3 op = {A.obs_pos[3 * o], A.obs_pos[3 * o + 1], A.obs_pos[3 * o + 2]};
+              if (obs_and_partials(q, P, A.mjd[o], op, ob)) {
+                eq_active = true;
+                const double sra = A.sra[o], sdec = A.sdec[o];
+                rra = angular_diff(A.ra[o] - 0.0, ob.ra);
+                rdec = (A.dec[o] - 0.0) - ob.dec;
+                const double ta = rra / sra, td = rdec / sdec;
+                const double chi = sqrt(ta * ta + td * td);
+                wa = 1.0 / (sra * sra);
+                wd = 1.0 / (sdec * sdec);
+                active += 1;
+                rc_[o] = rra;
+                rc_[A.n_obs + o] = rdec;
+                rc_[2 * A.n_obs + o] = chi;
+              }
+            }
+            if (!eq_active) {  // fit_data.clone(): the accepted residuals carry over
+              rc_[o] = have_accepted ? ra_[o] : 0.0;
+              rc_[A.n_obs + o] = have_accepted ? ra_[A.n_obs + o] : 0.0;
+              rc_[2 * A.n_obs + o] = have_accepted ? ra_[2 * A.n_obs + o] : 0.0;
+            }
+          }
+          // ordered accumulation: observation i0 first, then i0 + 1, ... (one lane of the group at a time)
+#pragma unroll 1
+          for (unsigned turn = 0; turn < kG; ++turn) {
+            if (turn == sub && eq_active) {
+              constexpr double wc = 0.0;
 #pragma unroll
               for (int j = 0; j < 6; ++j) {
 #pragma unroll
@@ -112,19 +148,12 @@ k_diffcor(DiffCorArgs A) {
                                                     wc * (ob.gd[j] * ob.ga[k] + ob.ga[j] * ob.gd[k]));
                 lds_add(&sN[36 + j][lane], (ob.ga[j] * wa + ob.gd[j] * wc) * rra + (ob.ga[j] * wc + ob.gd[j] * wd) * rdec);
               }
-              wss += wa * rra * rra + wd * rdec * rdec + 2.0 * wc * rra * rdec;
-              active += 1;
-              rc_[o] = rra;
-              rc_[A.n_obs + o] = rdec;
-              rc_[2 * A.n_obs + o] = chi;
+              lds_add(&sN[42][lane], wa * rra * rra + wd * rdec * rdec + 2.0 * wc * rra * rdec);
             }
           }
-          if (!eq_active) {  // fit_data.clone(): the accepted residuals carry over
-            rc_[o] = have_accepted ? ra_[o] : 0.0;
-            rc_[A.n_obs + o] = have_accepted ? ra_[A.n_obs + o] : 0.0;
-            rc_[2 * A.n_obs + o] = have_accepted ? ra_[2 * A.n_obs + o] : 0.0;
-          }
         }
+        active = group_sum<kG>(active);
+        const double wss = sN[42][lane];
         // ---- solve_weighted_least_squares (least_square.rs:211-303) ---------------------------
         const unsigned num_meas = active * 2;
 #pragma unroll
@@ -138,8 +167,9 @@ k_diffcor(DiffCorArgs A) {
         }
         // the inverse goes column by column into the staging half of the covariance scratch
         double* cov_new = A.cov + (unsigned long long)cur * 36ull * A.n_traj + t;
-        bool inv_ok = cholesky_inverse6_lds(&sN[0][lane], 64, cov_new, A.n_traj);
-        if (!inv_ok) inv_ok = qr_inverse6(A.qr_work + t, A.n_traj, &sN[0][lane], 64, cov_new, A.n_traj);
+        bool inv_ok = cholesky_inverse6_lds(&sN[0][lane], kSlots, cov_new, A.n_traj);
+        if (!inv_ok)  // every lane of the group works on its own scratch column
+          inv_ok = qr_inverse6(A.qr_work + t * kG + sub, A.n_traj * kG, &sN[0][lane], kSlots, cov_new, A.n_traj);
         if (!inv_ok) { dc_error = 1; done = true; break; }  // DifferentialCorrectionFailed
         double dx[6], cdx[6], rhs[6];
 #pragma unroll
@@ -201,7 +231,7 @@ k_diffcor(DiffCorArgs A) {
       const PartialsFrame Pin = partials_frame(q_in);
       unsigned changes = 0;
 #pragma unroll 1
-      for (unsigned i = 0; i < n; ++i) {
+      for (unsigned i = sub; i < n; i += kG) {
         const unsigned long long o = base + i;
         const unsigned char s = sel_written ? A.sel[o] : (unsigned char)0;
         if (!sel_written) A.sel[o] = 0;
@@ -241,19 +271,39 @@ k_diffcor(DiffCorArgs A) {
         else if (s == 1 && chi2 <= C.chi2_recover) { A.sel[o] = 0; changes += 1; }
       }
       sel_written = true;
+      changes = group_sum<kG>(changes);
       if (changes == 0) break;
     }
     if (dc_error) status = 1;  // OUTFIT_LSQ_IOD_KEPT: Err(_) => Ok(initial_orbit)
   }
 
   // ---- output --------------------------------------------------------------------------------------
+  const double* ra_ = A.res + (unsigned long long)(cur ^ 1u) * RB;
+  const bool ok = status == 0;
+  for (unsigned i = sub; i < n; i += kG) {
+    const unsigned long long o = base + i;
+    const unsigned char s = (ok && sel_written) ? A.sel[o] : (unsigned char)0;
+    n_rejected += s != 0;
+    if (A.obs_fit) {
+      ObsFitRec f;
+      const bool have = ok && have_accepted;
+      f.residual_ra = have ? ra_[o] : 0.0;
+      f.residual_dec = have ? ra_[A.n_obs + o] : 0.0;
+      f.chi = have ? ra_[2 * A.n_obs + o] : 0.0;
+      f.selection = s;
+      f.pad = 0;
+      A.obs_fit[o] = f;
+    }
+  }
+  n_rejected = group_sum<kG>(n_rejected);
+  if (sub != 0) return;  // one lane of the group writes the trajectory's record
+  out->iod = seed;
   out->status = status;
   out->dc_error = dc_error;
   out->conv_error = conv_error;
   out->total_newton_iterations = total_iters;
   out->outer_passes = outer_started;
   out->pad = 0;
-  const bool ok = status == 0;
   out->epoch = (status == 0 || status == 1) ? q.epoch : 0.0;
   out->elem[0] = ok ? q.a : 0.0; out->elem[1] = ok ? q.h : 0.0; out->elem[2] = ok ? q.k : 0.0;
   out->elem[3] = ok ? q.p : 0.0; out->elem[4] = ok ? q.q : 0.0; out->elem[5] = ok ? q.lambda : 0.0;
@@ -272,29 +322,20 @@ k_diffcor(DiffCorArgs A) {
 #pragma unroll
   for (int i = 0; i < 36; ++i)
     out->covariance[i] = ok ? A.cov[((unsigned long long)(cur ^ 1u) * 36ull + i) * A.n_traj + t] * mu2 : 0.0;
-  const double* ra_ = A.res + (unsigned long long)(cur ^ 1u) * RB;
-  for (unsigned i = 0; i < n; ++i) {
-    const unsigned long long o = base + i;
-    const unsigned char s = (ok && sel_written) ? A.sel[o] : (unsigned char)0;
-    n_rejected += s != 0;
-    if (A.obs_fit) {
-      ObsFitRec f;
-      const bool have = ok && have_accepted;
-      f.residual_ra = have ? ra_[o] : 0.0;
-      f.residual_dec = have ? ra_[A.n_obs + o] : 0.0;
-      f.chi = have ? ra_[2 * A.n_obs + o] : 0.0;
-      f.selection = s;
-      f.pad = 0;
-      A.obs_fit[o] = f;
-    }
-  }
   out->n_rejected = n_rejected;
 }
 
-hipError_t launch_diffcor(const DiffCorArgs& a, hipStream_t s) {
+hipError_t launch_diffcor(const DiffCorArgs& a, unsigned group, hipStream_t s) {
   if (a.n_traj == 0) return hipSuccess;
-  const unsigned grid = (unsigned)((a.n_traj + 63) / 64);
-  hipLaunchKernelGGL(k_diffcor, dim3(grid), dim3(64), 0, s, a);
+  const unsigned slots = 64 / group;
+  const unsigned grid = (unsigned)((a.n_traj + slots - 1) / slots);
+  switch (group) {
+    case 1: hipLaunchKernelGGL(k_diffcor<1>, dim3(grid), dim3(64), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(k_diffcor<2>, dim3(grid), dim3(64), 0, s, a); break;
+    case 4: hipLaunchKernelGGL(k_diffcor<4>, dim3(grid), dim3(64), 0, s, a); break;
+    case 8: hipLaunchKernelGGL(k_diffcor<8>, dim3(grid), dim3(64), 0, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 

@@ -137,7 +137,7 @@ struct DiffCorArgs {
   double* res;                     // [2][3][n_obs]
   unsigned char* sel;              // [n_obs]
   double* cov;                     // [2][36][n_traj]
-  double* qr_work;                 // [42][n_traj]
+  double* qr_work;                 // [42][n_traj * group]
   LsqResultRec* out;               // [n_traj]
   ObsFitRec* obs_fit;              // nullable [n_obs]
 };
@@ -150,7 +150,8 @@ hipError_t launch_gauss_correct_fast(const CorrectArgs& a, unsigned n_cu, hipStr
 hipError_t launch_gauss_correct(const CorrectArgs& a, unsigned n_cu, hipStream_t s);
 hipError_t launch_orbit_rms(const RmsArgs& a, bool slow_list, hipStream_t s);
 hipError_t launch_select_best(const SelectArgs& a, hipStream_t s);
-hipError_t launch_diffcor(const DiffCorArgs& a, hipStream_t s);
+constexpr unsigned kDiffcorMaxGroup = 8;  // lanes that may share one trajectory in k_diffcor
+hipError_t launch_diffcor(const DiffCorArgs& a, unsigned group, hipStream_t s);
 hipError_t launch_selftest_division(unsigned long long n_threads, unsigned long long n_per_thread,
                                     unsigned long long seed, unsigned long long* d_mismatches, hipStream_t s);
 hipError_t launch_propagate_universal(unsigned long long n, const double* rv, const double* t0,

@@ -231,6 +231,34 @@ def test_lsq_session_and_errors(ephem_dict):
         outfit_amd.fit_lsq_records(wild, ephem, params, cfg)
 
 
+def test_lane_group_size_does_not_change_a_bit(ephem_dict, monkeypatch):
+    """k_diffcor<kG>: kG lanes share a trajectory and add their terms to the LDS accumulators in observation
+    order, so 1, 2, 4 or 8 lanes per trajectory must give byte-identical records (ragged lengths included)."""
+    ds, batch, ephem = make(300, ephem_dict, seed=17)
+    off = batch.traj_offset.astype(np.int64)
+    keep = np.ones(int(off[-1]), dtype=bool)
+    for t in range(0, 300, 7):
+        keep[off[t] + 3 + (t % 11):off[t + 1]] = False        # arcs of 3 .. 13 observations
+    new_off = np.concatenate([[0], np.cumsum([keep[off[t]:off[t + 1]].sum() for t in range(300)])])
+    b2 = outfit_amd.ObsBatch(new_off, batch.mjd_tt[keep], batch.ra[keep], batch.dec[keep], batch.sigma_ra[keep],
+                             batch.sigma_dec[keep], batch.obs_helio_equ.reshape(-1, 3)[keep],
+                             batch.obs_geo_ecl.reshape(-1, 3)[keep])
+    params = synth.bench_params(outfit_amd.IODParams())
+    seeds = oracle_iod(params, b2, ephem)
+    cfg = outfit_amd.DifferentialCorrectionConfig(rms_divergence_ratio=1e300, convergence_before_rejection_threshold=0.0,
+                                                  chi_squared_rejection_threshold=6.0)
+    outs = []
+    for g in ("1", "2", "4", "8"):
+        monkeypatch.setenv("OUTFIT_DIFFCOR_GROUP", g)
+        outs.append(outfit_amd.fit_lsq_records(b2, ephem, params, cfg, seeds, n_devices=1))
+    for rec, obs in outs[1:]:
+        assert rec.tobytes() == outs[0][0].tobytes() and obs.tobytes() == outs[0][1].tobytes()
+    monkeypatch.delenv("OUTFIT_DIFFCOR_GROUP")
+    ref, ref_obs = oracle_lsq(params, cfg, b2, ephem, seeds)
+    compare_lsq(outs[0][0], outs[0][1], ref, ref_obs, b2, allow_flips=1)
+    assert (ref["n_rejected"] > 0).sum() > 10
+
+
 def _times(s, cfg):
     s.set_profiling(True)
     s.run_lsq(cfg)
