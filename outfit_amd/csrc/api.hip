@@ -256,6 +256,10 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
   // chunking: bound the candidate scratch (256 B per candidate) and the heap scratch
   uint64_t chunk = 131072;
   if (s->cand_per_traj) chunk = std::min<uint64_t>(chunk, std::max<uint64_t>(1, (10ull << 20) / s->cand_per_traj));
+  if (const char* e = std::getenv("OUTFIT_IOD_CHUNK")) {  // testing aid: force the multi-chunk path on small batches
+    const long long c = std::atoll(e);
+    if (c > 0) chunk = std::min<uint64_t>(chunk, (uint64_t)c);
+  }
   chunk = std::max<uint64_t>(1, std::min<uint64_t>(chunk, s->n_traj));
   s->chunk = chunk;
   const size_t n_cand = (size_t)chunk * s->cand_per_traj;

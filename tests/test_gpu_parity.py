@@ -264,6 +264,24 @@ def test_full_size_properties(ephem_dict):
         compare(a[i:i + 1], oracle(params, sub, ephem))
 
 
+def test_multi_chunk_path_gives_the_same_bytes(ephem_dict, monkeypatch):
+    """Sessions process trajectories in chunks that bound the candidate scratch (one chunk up to ~10^5
+    objects at 100 triplets); BASELINE configs 4-5 (10^6 objects) need several. A forced small chunk must
+    not change a byte, including the K0/K2a sub-slices on the second stream and the differential corrector."""
+    ds = synth.make_dataset(2500, seed=77, ephem=ephem_dict)
+    batch = outfit_amd.ObsBatch.from_dict(ds)
+    ephem = outfit_amd.Ephemeris.from_dict(ephem_dict)
+    params = synth.bench_params(outfit_amd.IODParams())
+    cfg = outfit_amd.DifferentialCorrectionConfig(rms_divergence_ratio=10.0)
+    ref = outfit_amd.fit_full_iod_records(batch, ephem, params, 1)
+    ref_lsq, ref_obs = outfit_amd.fit_lsq_records(batch, ephem, params, cfg, None, 1)
+    for chunk in ("1000", "333", "64"):
+        monkeypatch.setenv("OUTFIT_IOD_CHUNK", chunk)
+        assert outfit_amd.fit_full_iod_records(batch, ephem, params, 1).tobytes() == ref.tobytes(), chunk
+        lsq, obs = outfit_amd.fit_lsq_records(batch, ephem, params, cfg, None, 1)
+        assert lsq.tobytes() == ref_lsq.tobytes() and obs.tobytes() == ref_obs.tobytes(), chunk
+
+
 def test_cpp_host_example_config1():
     """BASELINE config 1 (plumbing): examples/run_full_iod.cpp through include/outfit_host.hpp —
     builder validation, fit_full_iod, FullOrbitResult with an Ok and an Err entry; the Ok orbit is the
