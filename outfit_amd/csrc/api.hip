@@ -100,7 +100,7 @@ struct outfit_hip_session {
   uint64_t chunk = 0;
 
   DevBuf<unsigned long long> traj_offset;
-  DevBuf<double> mjd, ra, dec, sra, sdec, helio, geo, obs_pos, cos_dec, noise, coef;
+  DevBuf<double> mjd, ra, dec, sra, sdec, helio, geo, obs_pos, cos_dec, unit, noise, coef;
   DevBuf<double> heap_w, sum, el, dirS, roots, state, psi0;
   DevBuf<unsigned long long> heap_id, triplets, queue, slow_list, slow_count;
   DevBuf<unsigned> n_triplets, flags, n_win;
@@ -132,7 +132,7 @@ struct outfit_hip_session {
 
   void free_all() {
     traj_offset.release(); mjd.release(); ra.release(); dec.release(); sra.release(); sdec.release();
-    helio.release(); geo.release(); obs_pos.release(); cos_dec.release(); noise.release(); coef.release();
+    helio.release(); geo.release(); obs_pos.release(); cos_dec.release(); unit.release(); noise.release(); coef.release();
     heap_w.release(); sum.release(); el.release(); dirS.release(); roots.release(); state.release();
     psi0.release(); slow_list.release(); slow_count.release();
     heap_id.release(); triplets.release(); queue.release(); n_triplets.release(); flags.release();
@@ -225,6 +225,7 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
   TRY_RC(upload(s->sdec, n ? b->sigma_dec + o0 : nullptr, n));
   TRY_RC(upload(s->helio, n ? b->obs_helio_equ + 3 * o0 : nullptr, 3 * n));
   HIP_TRY(s->cos_dec.alloc(n));
+  HIP_TRY(s->unit.alloc(3 * n));
   if (s->has_ephem && s->has_geo) {
     TRY_RC(upload(s->geo, n ? b->obs_geo_ecl + 3 * o0 : nullptr, 3 * n));
     HIP_TRY(s->obs_pos.alloc(3 * n));
@@ -341,7 +342,7 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
   {
     outfit::PrepassArgs pa{};
     pa.n_obs = s->n_obs; pa.mjd = s->mjd.p; pa.dec = s->dec.p; pa.geo_ecl = s->geo.p; pa.obs_pos = s->obs_pos.p;
-    pa.cos_dec = s->cos_dec.p; pa.has_table = on_device_earth;
+    pa.cos_dec = s->cos_dec.p; pa.unit = s->unit.p; pa.ra = s->ra.p; pa.has_table = on_device_earth;
     pa.T = s->table; pa.error_flag = s->error_flag.p;
     Stamp stamp(s, st, K_PREPASS);
     HIP_TRY(outfit::launch_observer_prepass(pa, st));
@@ -366,6 +367,7 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
     ci.n_triplets = s->n_triplets.p; ci.triplets = s->triplets.p;
     ci.mjd = s->mjd.p; ci.ra = s->ra.p; ci.dec = s->dec.p; ci.sra = s->sra.p; ci.sdec = s->sdec.p;
     ci.helio = s->helio.p; ci.noise_z = s->noise.p; ci.noise_scale = s->params.noise_scale;
+    ci.unit = s->unit.p; ci.n_obs_total = s->n_obs;
     outfit::CandidateScratch w{};
     w.flags = s->flags.p; w.S = s->dirS.p; w.roots = s->roots.p; w.state = s->state.p; w.el = s->el.p;
     w.sum = s->sum.p; w.n_win = s->n_win.p; w.psi0 = s->psi0.p; w.slow_list = s->slow_list.p;
@@ -485,7 +487,7 @@ int session_run_lsq(outfit_hip_session* s, const outfit_diffcor_config_t* cfg,
   if (!s->prepass_done) {
     outfit::PrepassArgs pa{};
     pa.n_obs = s->n_obs; pa.mjd = s->mjd.p; pa.dec = s->dec.p; pa.geo_ecl = s->geo.p; pa.obs_pos = s->obs_pos.p;
-    pa.cos_dec = s->cos_dec.p; pa.has_table = on_device_earth;
+    pa.cos_dec = s->cos_dec.p; pa.unit = s->unit.p; pa.ra = s->ra.p; pa.has_table = on_device_earth;
     pa.T = s->table; pa.error_flag = s->error_flag.p;
     Stamp stamp(s, st, K_PREPASS);
     HIP_TRY(outfit::launch_observer_prepass(pa, st));

@@ -49,10 +49,12 @@ struct TripletArgs {
 struct PrepassArgs {
   unsigned long long n_obs;
   const double* mjd;
+  const double* ra;
   const double* dec;
   const double* geo_ecl;
   double* obs_pos;
   double* cos_dec;
+  double* unit;    // [3][n_obs] direction cosines of the (noise-free) observations
   bool has_table;  // false: only cos(dec) is produced, the residuals use obs_helio_equ
   EphemTable T;
   int* error_flag;
@@ -67,6 +69,8 @@ struct CandidateIndex {
   const unsigned long long* triplets;
   const double *mjd, *ra, *dec, *sra, *sdec, *helio, *noise_z;
   double noise_scale;
+  const double* unit;                 // [3][n_obs_total], written by K1
+  unsigned long long n_obs_total;
 };
 
 // candidate-level scratch, structure-of-arrays over the candidates of one chunk

@@ -81,7 +81,18 @@ k_observer_prepass(PrepassArgs a) {
   const unsigned long long o = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = o < a.n_obs;
   // cos(dec_obs) of ephemeris_error (observation_ephemeris.rs:411) depends on the observation only
-  if (live) a.cos_dec[o] = cos(a.dec[o]);
+  if (live) {
+    a.cos_dec[o] = cos(a.dec[o]);
+    // Column of unit_matrix (gauss.rs:488-502) for the noise-free observation, with the correctly-rounded
+    // functions: every noise-free candidate that uses this observation (~15 triplets each) reads the
+    // three direction cosines instead of re-evaluating two double-double sincos
+    double sr, cr, sd, cd;
+    crm::sincos(a.ra[o], sr, cr);
+    crm::sincos(a.dec[o], sd, cd);
+    a.unit[o] = cr * cd;
+    a.unit[a.n_obs + o] = sr * cd;
+    a.unit[2 * a.n_obs + o] = sd;
+  }
   if (!a.has_table) return;
   if (threadIdx.x == 0) { s_min = ~0ull; s_max = 0ull; s_bad = 0; }
   __syncthreads();
@@ -188,8 +199,19 @@ k_gauss_roots(RootsArgs a) {
 
   double ra[3], dec[3], t[3];
   Mat3 obs, Sinv;
-  gather_angles(a.I, c, ra, dec);
-  const Mat3 S = unit_matrix(ra, dec);
+  Mat3 S;
+  if (c.r == 0) {  // noise-free realisation: the columns were evaluated once per observation by K1
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const unsigned long long o = c.base + c.idx[k];
+      S.m[0][k] = a.I.unit[o];
+      S.m[1][k] = a.I.unit[a.I.n_obs_total + o];
+      S.m[2][k] = a.I.unit[2 * a.I.n_obs_total + o];
+    }
+  } else {
+    gather_angles(a.I, c, ra, dec);
+    S = unit_matrix(ra, dec);
+  }
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
