@@ -102,8 +102,8 @@ struct outfit_hip_session {
   DevBuf<unsigned long long> traj_offset;
   DevBuf<double> mjd, ra, dec, sra, sdec, helio, geo, obs_pos, cos_dec, unit, noise, coef;
   DevBuf<double> heap_w, sum, el, dirS, roots, state, psi0;
-  DevBuf<unsigned long long> heap_id, triplets, queue, slow_list, slow_count;
-  DevBuf<unsigned> n_triplets, flags, n_win;
+  DevBuf<unsigned long long> heap_id, triplets[2], queue, slow_list, slow_count;
+  DevBuf<unsigned> n_triplets[2], flags, n_win;
   unsigned n_cu = 256;
   bool triplet_lds = false;  // K0 keeps its heap in LDS (small k_cap, <= 1024 reduced observations)
   DevBuf<outfit::GaussResultRec> results;
@@ -121,8 +121,12 @@ struct outfit_hip_session {
   outfit::TripletParams tp{};
 
   hipStream_t own_stream = nullptr;
-  hipStream_t aux_stream = nullptr;  // runs K0 one chunk ahead of the candidate kernels
-  hipEvent_t ev_start = nullptr, ev_fast = nullptr, ev_general = nullptr, ev_sub[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t aux_stream = nullptr;  // general correction kernel, beside K2c
+  hipStream_t k0_stream = nullptr;   // triplet selection, ahead of the candidate kernels (and of the previous run's tail)
+  hipEvent_t ev_k3[2] = {nullptr, nullptr};  // last consumer of triplet buffer b has finished
+  bool k3_recorded[2] = {false, false};
+  unsigned long long chunk_seq = 0;
+  hipEvent_t ev_fast = nullptr, ev_general = nullptr, ev_sub[4] = {nullptr, nullptr, nullptr, nullptr};
   hipStream_t last_stream = nullptr;
   bool profiling = false;
   struct Timed { int id; hipEvent_t a, b; };
@@ -135,7 +139,8 @@ struct outfit_hip_session {
     helio.release(); geo.release(); obs_pos.release(); cos_dec.release(); unit.release(); noise.release(); coef.release();
     heap_w.release(); sum.release(); el.release(); dirS.release(); roots.release(); state.release();
     psi0.release(); slow_list.release(); slow_count.release();
-    heap_id.release(); triplets.release(); queue.release(); n_triplets.release(); flags.release();
+    heap_id.release(); triplets[0].release(); triplets[1].release(); queue.release();
+    n_triplets[0].release(); n_triplets[1].release(); flags.release();
     n_win.release(); results.release(); error_flag.release();
     dc_res.release(); dc_cov.release(); dc_qr.release(); dc_sel.release();
     dc_initial.release(); dc_out.release(); dc_fit.release();
@@ -144,7 +149,13 @@ struct outfit_hip_session {
     if (own_stream) (void)hipStreamDestroy(own_stream);
     if (aux_stream) (void)hipStreamDestroy(aux_stream);
     aux_stream = nullptr;
-    for (hipEvent_t* e : {&ev_start, &ev_fast, &ev_general, &ev_sub[0], &ev_sub[1], &ev_sub[2], &ev_sub[3]}) {
+    if (k0_stream) (void)hipStreamDestroy(k0_stream);
+    k0_stream = nullptr;
+    for (hipEvent_t& e : ev_k3) {
+      if (e) (void)hipEventDestroy(e);
+      e = nullptr;
+    }
+    for (hipEvent_t* e : {&ev_fast, &ev_general, &ev_sub[0], &ev_sub[1], &ev_sub[2], &ev_sub[3]}) {
       if (*e) (void)hipEventDestroy(*e);
       *e = nullptr;
     }
@@ -201,7 +212,9 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&s->aux_stream, hipStreamNonBlocking));
-  for (hipEvent_t* e : {&s->ev_start, &s->ev_fast, &s->ev_general, &s->ev_sub[0], &s->ev_sub[1], &s->ev_sub[2], &s->ev_sub[3]})
+  HIP_TRY(hipStreamCreateWithFlags(&s->k0_stream, hipStreamNonBlocking));
+  for (hipEvent_t& e : s->ev_k3) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (hipEvent_t* e : {&s->ev_fast, &s->ev_general, &s->ev_sub[0], &s->ev_sub[1], &s->ev_sub[2], &s->ev_sub[3]})
     HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
   s->params = *params;
   s->n_traj = b->n_traj;
@@ -267,8 +280,10 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
   const size_t heap_stride = (size_t)((chunk + 63) / 64 * 64);
   HIP_TRY(s->heap_w.alloc(heap_stride * s->k_cap));
   HIP_TRY(s->heap_id.alloc(heap_stride * s->k_cap));
-  HIP_TRY(s->triplets.alloc((size_t)chunk * s->k_cap));
-  HIP_TRY(s->n_triplets.alloc((size_t)chunk));
+  for (int b = 0; b < 2; ++b) {  // double-buffered: K0 of the next chunk / run may run ahead
+    HIP_TRY(s->triplets[b].alloc((size_t)chunk * s->k_cap));
+    HIP_TRY(s->n_triplets[b].alloc((size_t)chunk));
+  }
   HIP_TRY(s->flags.alloc(n_cand));
   HIP_TRY(s->n_win.alloc(n_cand));
   HIP_TRY(s->sum.alloc(n_cand));
@@ -348,12 +363,14 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
     HIP_TRY(outfit::launch_observer_prepass(pa, st));
     s->prepass_done = true;
   }
-  // Two latency-bound kernels run on a second stream in the shadow of VALU-bound ones:
-  //   * K0 (sequential heap per lane) in kSub slices, each one slice ahead of the K2a slice that
-  //     consumes its triplets;
-  //   * the general correction kernel (few items, long serial chains) beside K2c, which first
+  // Two latency-bound kernels run on their own streams in the shadow of VALU-bound ones:
+  //   * K0 (sequential heap per lane) in kSub slices on k0_stream, each one slice ahead of the K2a slice
+  //     that consumes its triplets. K0 reads only resident inputs and writes a double-buffered triplet
+  //     table, so when runs are enqueued back to back it also runs under the tail of the previous run;
+  //   * the general correction kernel (few items, long serial chains) on aux beside K2c, which first
   //     handles every regular candidate and then the slow list.
-  //     aux :  K0(0) K0(1) K0(2) K0(3)                      general
+  //     k0  :  K0(0) K0(1) K0(2) K0(3)
+  //     aux :                                               general
   //     main:        K2a(0) K2a(1) K2a(2) K2a(3) prelim fast         rms(regular) rms(slow) select
   constexpr unsigned kSub = 4;
   for (uint64_t t0 = 0; t0 < s->n_traj; t0 += s->chunk) {
@@ -364,7 +381,8 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
     outfit::CandidateIndex ci{};
     ci.n_cand = n_cand; ci.traj0 = t0; ci.cand_per_traj = s->cand_per_traj; ci.n_real = s->n_real;
     ci.k_cap = s->k_cap; ci.traj_offset = s->traj_offset.p;
-    ci.n_triplets = s->n_triplets.p; ci.triplets = s->triplets.p;
+    const unsigned tb = (unsigned)(s->chunk_seq++ & 1u);  // triplet buffer of this chunk
+    ci.n_triplets = s->n_triplets[tb].p; ci.triplets = s->triplets[tb].p;
     ci.mjd = s->mjd.p; ci.ra = s->ra.p; ci.dec = s->dec.p; ci.sra = s->sra.p; ci.sdec = s->sdec.p;
     ci.helio = s->helio.p; ci.noise_z = s->noise.p; ci.noise_scale = s->params.noise_scale;
     ci.unit = s->unit.p; ci.n_obs_total = s->n_obs;
@@ -373,21 +391,22 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
     w.sum = s->sum.p; w.n_win = s->n_win.p; w.psi0 = s->psi0.p; w.slow_list = s->slow_list.p;
     w.slow_count = s->slow_count.p;
 
-    // aux waits for everything enqueued on the caller's stream so far (previous chunk included)
-    HIP_TRY(hipEventRecord(s->ev_start, st));
-    HIP_TRY(hipStreamWaitEvent(aux, s->ev_start, 0));
+    // K0 reads only the resident inputs: it may start as soon as the last consumer of its triplet
+    // buffer (K3 two chunks / runs ago) has finished — i.e. under the tail of the previous run
+    hipStream_t k0 = s->k0_stream;
+    if (s->k3_recorded[tb]) HIP_TRY(hipStreamWaitEvent(k0, s->ev_k3[tb], 0));
     for (unsigned i = 0; i < n_sub; ++i) {
       const uint64_t a0 = nt * i / n_sub, a1 = nt * (i + 1) / n_sub;
       outfit::TripletArgs ta{};
       ta.n_traj = a1 - a0; ta.traj0 = t0 + a0; ta.traj_offset = s->traj_offset.p; ta.mjd = s->mjd.p; ta.P = s->tp;
       ta.heap_w = s->heap_w.p; ta.heap_id = s->heap_id.p;
       ta.heap_stride = (unsigned long long)((s->chunk + 63) / 64 * 64);
-      ta.n_triplets = s->n_triplets.p + a0; ta.triplets = s->triplets.p + a0 * s->k_cap;
+      ta.n_triplets = s->n_triplets[tb].p + a0; ta.triplets = s->triplets[tb].p + a0 * s->k_cap;
       {
-        Stamp stamp(s, aux, K_TRIPLETS);
-        HIP_TRY(outfit::launch_triplet_select(ta, s->triplet_lds, aux));
+        Stamp stamp(s, k0, K_TRIPLETS);
+        HIP_TRY(outfit::launch_triplet_select(ta, s->triplet_lds, k0));
       }
-      HIP_TRY(hipEventRecord(s->ev_sub[i], aux));
+      HIP_TRY(hipEventRecord(s->ev_sub[i], k0));
     }
     for (unsigned i = 0; i < n_sub; ++i) {
       const uint64_t a0 = nt * i / n_sub, a1 = nt * (i + 1) / n_sub;
@@ -426,12 +445,14 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
     }
     outfit::SelectArgs sa{};
     sa.n_traj = nt; sa.traj0 = t0; sa.n_cand = n_cand; sa.cand_per_traj = s->cand_per_traj;
-    sa.n_real = s->n_real; sa.n_triplets = s->n_triplets.p; sa.W = w;
+    sa.n_real = s->n_real; sa.n_triplets = s->n_triplets[tb].p; sa.W = w;
     sa.out = d_out ? d_out : s->results.p;
     {
       Stamp stamp(s, st, K_SELECT);
       HIP_TRY(outfit::launch_select_best(sa, st));
     }
+    HIP_TRY(hipEventRecord(s->ev_k3[tb], st));
+    s->k3_recorded[tb] = true;
   }
   return OUTFIT_OK;
 }
