@@ -347,6 +347,11 @@ void outfit_hip_ephem_close(outfit_ephem_file_t *e);
  * compares them with `/` on n_pairs pseudo-random operand pairs and returns the number
  * of differing results (must be 0). No counterpart in the reference. */
 int outfit_hip_selftest_division(uint64_t n_pairs, uint64_t seed, uint64_t *mismatches);
+/* Device self-test of the correctly-rounded sin/cos/acos (outfit_amd/csrc/device/crmath.hpp): the fast
+ * path (table + rounding test) against the full double-double evaluation on n_args pseudo-random
+ * arguments. counts[0] = sin/cos arguments with differing bits, counts[1] = acos arguments with differing
+ * bits (both must be 0), counts[2] = sin/cos arguments that needed the full evaluation, counts[3] = 0. */
+int outfit_hip_selftest_crmath(uint64_t n_args, uint64_t seed, uint64_t *counts /* [4] */);
 const char *outfit_hip_last_error(void); /* thread-local, never NULL */
 int         outfit_hip_abi_version(void);
 int         outfit_hip_device_count(void);

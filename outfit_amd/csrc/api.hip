@@ -788,6 +788,25 @@ int outfit_hip_fit_lsq(const outfit_iod_params_t* params, const outfit_diffcor_c
   });
 }
 
+int outfit_hip_selftest_crmath(uint64_t n_args, uint64_t seed, uint64_t* counts) {
+  if (!counts) return fail(OUTFIT_ERR_INVALID_BATCH, "NULL argument");
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+    return fail(OUTFIT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+  DevBuf<unsigned long long> d;
+  HIP_TRY(d.alloc(4));
+  hipError_t e = hipMemset(d.p, 0, 4 * sizeof(unsigned long long));
+  const unsigned long long threads = 1ull << 18, per = (n_args + threads - 1) / threads;
+  if (e == hipSuccess) e = outfit::launch_selftest_crmath(threads, per, seed, d.p, nullptr);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  unsigned long long h[4] = {0, 0, 0, 0};
+  if (e == hipSuccess) e = hipMemcpy(h, d.p, sizeof h, hipMemcpyDeviceToHost);
+  d.release();
+  if (e != hipSuccess) return fail(OUTFIT_ERR_HIP, hipGetErrorString(e));
+  for (int i = 0; i < 4; ++i) counts[i] = h[i];
+  return OUTFIT_OK;
+}
+
 int outfit_hip_selftest_division(uint64_t n_pairs, uint64_t seed, uint64_t* mismatches) {
   if (!mismatches) return fail(OUTFIT_ERR_INVALID_BATCH, "NULL argument");
   int n_dev = 0;

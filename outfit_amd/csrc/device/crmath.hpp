@@ -17,6 +17,7 @@
 // Constants: tools/gen_crmath_constants.py (mpmath).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "crmath_table.hpp"
 
 namespace outfit {
 namespace crm {
@@ -150,8 +151,74 @@ __device__ __forceinline__ void sincos_dd(double x, dd& s, dd& c) {
   else { s = neg(cr); c = sr; }
 }
 
+// ---- fast path (Ziv's strategy) ---------------------------------------------------------------
+// sin/cos of the reduced argument from a 102-entry double-double table at j/128 and short polynomials
+// in the remainder |d| <= 2^-8:
+//   sin(a + d) = S + [S (cos d - 1) + C sin d],   cos(a + d) = C + [C (cos d - 1) - S sin d]
+// with S, C double-double, the O(d) product exact (two_prod) and everything of relative size
+// <= 2^-17 in plain double. Error of the double-double result: < 2^-67 relative (largest contribution:
+// the rounding of S (cos d - 1), 2^-53 * 2^-17.5). The result is accepted only when adding that bound to
+// the low word cannot change the rounded high word; otherwise (probability ~2^-12 per call) the full
+// double-double Taylor evaluation below decides. Either way the returned double is the correctly
+// rounded value, so the two paths — and the oracle's (oracle/crmath.c) — agree bit for bit;
+// outfit_hip_selftest_crmath checks this on the device for ~10^9 arguments.
+constexpr double kFastRelErr = 0x1p-66;  // 2x the derived bound
+
+// double-double sin and cos of r = rh + rl, |r| <= pi/4 + 2^-9; relative error < 2^-67
+__device__ __forceinline__ void sincos_fast_dd(dd r, dd& s, dd& c) {
+  const double kf = rint(r.hi * 128.0);
+  const int k = (int)kf;
+  const int j = k < 0 ? -k : k;
+  const double sgn = k < 0 ? -1.0 : 1.0;
+  const double sh = sgn * kSinCosTab[j][0], sl = sgn * kSinCosTab[j][1];
+  const double ch = kSinCosTab[j][2], cl = kSinCosTab[j][3];
+  const dd d = fast_two_sum(r.hi - kf * 0.0078125, r.lo);  // r.hi - k/128 is exact
+  const double d2 = d.hi * d.hi;
+  // sin d = d.hi + d.lo + ps ; cos d - 1 = pc
+  const double ps = d.hi * d2 * (-0.16666666666666666 + d2 * (0.008333333333333333 + d2 * -0.0001984126984126984));
+  const double pc = d2 * (-0.5 + d2 * (0.041666666666666664 + d2 * -0.001388888888888889)) - d.hi * d.lo;
+  {
+    const dd p = two_prod(ch, d.hi);
+    const double rest = ((sl + p.lo) + (ch * d.lo + cl * d.hi)) + (sh * pc + ch * ps);
+    dd t = two_sum(sh, p.hi);
+    t.lo += rest;
+    s = fast_two_sum(t.hi, t.lo);
+  }
+  {
+    const dd p = two_prod(sh, d.hi);
+    const double rest = ((cl - p.lo) - (sh * d.lo + sl * d.hi)) + (ch * pc - sh * ps);
+    dd t = two_sum(ch, -p.hi);
+    t.lo += rest;
+    c = fast_two_sum(t.hi, t.lo);
+  }
+}
+
+// true when the high word of v is the correctly rounded value given an absolute error bound e on v
+__device__ __forceinline__ bool rounds_safely(dd v, double e) { return v.hi + (v.lo + copysign(e, v.lo)) == v.hi; }
+
+__device__ __forceinline__ void apply_quadrant(int q, dd sr, dd cr, dd& s, dd& c) {
+  if (q == 0) { s = sr; c = cr; }
+  else if (q == 1) { s = cr; c = neg(sr); }
+  else if (q == 2) { s = neg(sr); c = neg(cr); }
+  else { s = neg(cr); c = sr; }
+}
+
 // correctly-rounded sin and cos
 __device__ __forceinline__ void sincos(double x, double& s, double& c) {
+  if (!(fabs(x) < 1048576.0)) { ::sincos(x, &s, &c); return; }
+  if (x == 0.0) { s = x; c = 1.0; return; }
+  int q;
+  const dd r = reduce_pio2(x, q);
+  dd sr, cr, sd, cd;
+  sincos_fast_dd(r, sr, cr);
+  if (!(rounds_safely(sr, kFastRelErr * fabs(sr.hi)) && rounds_safely(cr, kFastRelErr * fabs(cr.hi))))
+    sincos_kernel(r, sr, cr);
+  apply_quadrant(q, sr, cr, sd, cd);
+  s = sd.hi;
+  c = cd.hi;
+}
+// the full-precision evaluation alone (reference for the self-test)
+__device__ __forceinline__ void sincos_slow(double x, double& s, double& c) {
   if (!(fabs(x) < 1048576.0)) { ::sincos(x, &s, &c); return; }
   if (x == 0.0) { s = x; c = 1.0; return; }
   dd sd, cd;
@@ -160,8 +227,8 @@ __device__ __forceinline__ void sincos(double x, double& s, double& c) {
   c = cd.hi;
 }
 
-// correctly-rounded acos for |x| <= 1 (callers guard the domain)
-__device__ __forceinline__ double acos(double x) {
+// correctly-rounded acos for |x| <= 1 (callers guard the domain): one Newton step on cos(y) = x
+__device__ __forceinline__ double acos_slow(double x) {
   if (!(fabs(x) <= 1.0)) return ::acos(x);
   if (x == 1.0) return 0.0;
   if (x == -1.0) return kPiHi;
@@ -170,6 +237,26 @@ __device__ __forceinline__ double acos(double x) {
   sincos_dd(y0, sd, cd);
   const dd q = div(add_d(cd, -x), sd);
   return add_d(q, y0).hi;
+}
+__device__ __forceinline__ double acos(double x) {
+  if (!(fabs(x) <= 1.0)) return ::acos(x);
+  if (x == 1.0) return 0.0;
+  if (x == -1.0) return kPiHi;
+  const double y0 = ::acos(x);  // within a few ulp; y0 in (0, pi)
+  int q;
+  const dd r = reduce_pio2(y0, q);
+  dd sr, cr, sd, cd;
+  sincos_fast_dd(r, sr, cr);
+  apply_quadrant(q, sr, cr, sd, cd);
+  // y = y0 + (cos y0 - x) / sin y0 ; cos y0 - x is a few ulp of x: the high parts cancel exactly
+  const double num = (cd.hi - x) + cd.lo;
+  const double corr = num / sd.hi;
+  const dd y = fast_two_sum(y0, corr);
+  // error of the correction: the 2^-66 absolute error of cos y0 (|cos| <= 1) divided by sin y0, plus the
+  // relative error of the quotient and the neglected second-order Newton term (corr^2 cot(y0) / 2)
+  const double e = (0x1p-66 + corr * corr) / fabs(sd.hi) + 0x1p-50 * fabs(corr);
+  if (rounds_safely(y, e)) return y.hi;
+  return acos_slow(x);
 }
 
 // Aberth's initial-guess directions: theta_k = fma(2pi/8, k, (pi/2)/8), correctly rounded

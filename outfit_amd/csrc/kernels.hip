@@ -729,9 +729,60 @@ k_selftest_division(unsigned long long n_per_thread, unsigned long long seed, un
   if (bad) atomicAdd(mismatches, bad);
 }
 
+// Self-test of the correctly-rounded functions: the fast (table + rounding test) path against the full
+// double-double evaluation, bit for bit. out[0] = arguments whose sin or cos differ, out[1] = arguments whose
+// acos differs, out[2] = sin/cos arguments that needed the full evaluation, out[3] = same for acos.
+__global__ void __launch_bounds__(256)
+k_selftest_crmath(unsigned long long n_per_thread, unsigned long long seed, unsigned long long* out) {
+  unsigned long long s = seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x + 1);
+  unsigned long long bad_sc = 0, bad_ac = 0, slow_sc = 0, slow_ac = 0;
+  for (unsigned long long it = 0; it < n_per_thread; ++it) {
+    double x;
+    const unsigned mode = (unsigned)(it & 7);
+    const double u = (double)(splitmix64(s) >> 11) * 0x1p-53;  // [0, 1)
+    if (mode < 3) x = (u - 0.5) * 64.0;                                         // the angles the path sees
+    else if (mode == 3) x = random_double(s, 19);                               // all magnitudes below 2^20
+    else if (mode == 4) x = random_double(s, 30) * 0x1p-25;                     // small arguments
+    else if (mode == 5) x = (double)((long long)(u * 4096.0) - 2048) * 1.5707963267948966 + random_double(s, 20) * 0x1p-40;
+    else if (mode == 6) x = (double)((long long)(u * 256.0) - 128) * 0.0078125 + random_double(s, 20) * 0x1p-45;
+    else x = (u - 0.5) * 2.0e5;
+    double s1, c1, s2, c2;
+    crm::sincos(x, s1, c1);
+    crm::sincos_slow(x, s2, c2);
+    bad_sc += (__double_as_longlong(s1) != __double_as_longlong(s2)) || (__double_as_longlong(c1) != __double_as_longlong(c2));
+    if (fabs(x) < 1048576.0 && x != 0.0) {
+      int q;
+      const crm::dd r = crm::reduce_pio2(x, q);
+      crm::dd sr, cr;
+      crm::sincos_fast_dd(r, sr, cr);
+      slow_sc += !(crm::rounds_safely(sr, crm::kFastRelErr * fabs(sr.hi)) &&
+                   crm::rounds_safely(cr, crm::kFastRelErr * fabs(cr.hi)));
+    }
+    double y;
+    if (mode < 4) y = 2.0 * u - 1.0;
+    else if (mode == 4) y = copysign(1.0 - random_double(s, 10) * random_double(s, 10) * 0x1p-40, u - 0.5);  // near +-1
+    else if (mode == 5) y = random_double(s, 25) * 0x1p-30;                                                   // near 0
+    else y = cos((u - 0.5) * 6.0);
+    if (fabs(y) <= 1.0) {
+      const double a1 = crm::acos(y), a2 = crm::acos_slow(y);
+      bad_ac += __double_as_longlong(a1) != __double_as_longlong(a2);
+    }
+  }
+  if (bad_sc) atomicAdd(out, bad_sc);
+  if (bad_ac) atomicAdd(out + 1, bad_ac);
+  if (slow_sc) atomicAdd(out + 2, slow_sc);
+  (void)slow_ac;
+}
+
 // ------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------
+hipError_t launch_selftest_crmath(unsigned long long n_threads, unsigned long long n_per_thread,
+                                  unsigned long long seed, unsigned long long* d_out, hipStream_t s) {
+  const unsigned grid = (unsigned)((n_threads + 255) / 256);
+  hipLaunchKernelGGL(k_selftest_crmath, dim3(grid), dim3(256), 0, s, n_per_thread, seed, d_out);
+  return hipGetLastError();
+}
 hipError_t launch_selftest_division(unsigned long long n_threads, unsigned long long n_per_thread,
                                     unsigned long long seed, unsigned long long* d_mismatches, hipStream_t s) {
   const unsigned grid = (unsigned)((n_threads + 255) / 256);

@@ -73,6 +73,18 @@ def test_fast_division_is_exact():
     assert bad.value == 0
 
 
+def test_correctly_rounded_fast_path_equals_full_evaluation():
+    """crmath.hpp: table + rounding-test fast path vs the double-double Taylor evaluation, 2^30 arguments
+    (the angles the path sees, all magnitudes below 2^20, neighbourhoods of k*pi/2 and of the table nodes,
+    acos near 0 and near +-1): not one differing bit; the fast path settles all but ~2^-12 of the calls."""
+    from outfit_amd import _lib
+    counts = (C.c_uint64 * 4)()
+    n = 1 << 30
+    assert _lib.lib().outfit_hip_selftest_crmath(n, 20261003, counts) == 0
+    assert counts[0] == 0 and counts[1] == 0, list(counts)
+    assert counts[2] < n / 1000, list(counts)
+
+
 def test_config2_1000_objects(ephem_dict):
     """BASELINE config 2: 1000 synthetic objects x 20 obs, 100 triplets each, fp64."""
     ds = synth.make_dataset(1000, ephem=ephem_dict)
