@@ -64,7 +64,7 @@ total_valu = 0.0
 for k in kernels:
     r = per_step[k]
     fb, wb = r["FETCH_SIZE"] * 1024, r["WRITE_SIZE"] * 1024
-    total_valu += r["SQ_INSTS_VALU"] if k != "k_diffcor" else 0.0
+    total_valu += r["SQ_INSTS_VALU"] if not k.startswith("k_diffcor") else 0.0
     derived.append("%-24s VALU wave-instr %.3e  per wave %9.0f  VALU-active/wave-cycles %.2f  fetch %8.1f MB  write %8.1f MB"
                    % (k, r["SQ_INSTS_VALU"], r["SQ_INSTS_VALU"] / max(1.0, r["SQ_WAVES"]),
                       r["SQ_ACTIVE_INST_VALU"] / max(1.0, r["SQ_WAVE_CYCLES"]), fb / 1e6, wb / 1e6))
