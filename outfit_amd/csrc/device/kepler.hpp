@@ -63,7 +63,7 @@ __device__ __forceinline__ Stumpff s_funct(double psi, double alpha) {
     // term j divides by the integer constants (2j+1)(2j+2) and (2j+2)(2j+3): exact quotient
     // from the tabulated correctly-rounded reciprocal (fastdiv.hpp), same bits as `/`
     const bool fast = fdiv::in_window(beta);
-    for (int j = 1; j <= 70; ++j) {
+    auto term = [&](int j) -> bool {  // adds term j; true = the series has converged (or overflowed)
       const double d2 = fdiv::kSeries.d2[j], d3 = fdiv::kSeries.d3[j];
       double x2, x3;
       if (fast) {
@@ -80,7 +80,22 @@ __device__ __forceinline__ Stumpff s_funct(double psi, double alpha) {
       t3 *= x3;
       s3 += t3;
       const double a2 = fabs(t2), a3 = fabs(t3);
-      if ((a2 < tol && a3 < tol) || a2 > ovf || a3 > ovf) break;
+      return (a2 < tol && a3 < tol) || a2 > ovf || a3 > ovf;
+    };
+    // The first terms are unrolled so that their four constants are literals: inside a rolled loop each
+    // term paid two scalar table loads (address arithmetic + memory latency) for six arithmetic
+    // instructions. The orbit-sized arguments of this path converge within 5-6 terms.
+    constexpr int kUnrolled = 8;
+    bool done = false;
+#pragma unroll
+    for (int j = 1; j <= kUnrolled; ++j) {
+      if (!done) done = term(j);
+    }
+    if (!done) {
+#pragma unroll 1
+      for (int j = kUnrolled + 1; j <= 70; ++j) {
+        if (term(j)) break;
+      }
     }
     return {1.0 + alpha * s2, psi + alpha * s3, s2, s3};
   }
