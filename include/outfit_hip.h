@@ -347,6 +347,11 @@ void outfit_hip_ephem_close(outfit_ephem_file_t *e);
  * compares them with `/` on n_pairs pseudo-random operand pairs and returns the number
  * of differing results (must be 0). No counterpart in the reference. */
 int outfit_hip_selftest_division(uint64_t n_pairs, uint64_t seed, uint64_t *mismatches);
+/* Device self-test of the Aberth sweep that shares one refined reciprocal between the two components of
+ * every complex division (outfit_amd/csrc/device/gauss.hpp) against the plain divisions, on n_polys random
+ * sparse octics: counts[0] = polynomials whose return code or iterates differ in any bit (must be 0),
+ * counts[1] = polynomials on which the range guard sent the solver back to the plain divisions. */
+int outfit_hip_selftest_aberth(uint64_t n_polys, uint64_t seed, uint64_t *counts /* [2] */);
 /* Device self-test of the correctly-rounded sin/cos/acos (outfit_amd/csrc/device/crmath.hpp): the fast
  * path (table + rounding test) against the full double-double evaluation on n_args pseudo-random
  * arguments. counts[0] = sin/cos arguments with differing bits, counts[1] = acos arguments with differing

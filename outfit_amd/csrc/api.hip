@@ -788,6 +788,26 @@ int outfit_hip_fit_lsq(const outfit_iod_params_t* params, const outfit_diffcor_c
   });
 }
 
+int outfit_hip_selftest_aberth(uint64_t n_polys, uint64_t seed, uint64_t* counts) {
+  if (!counts) return fail(OUTFIT_ERR_INVALID_BATCH, "NULL argument");
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+    return fail(OUTFIT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+  DevBuf<unsigned long long> d;
+  HIP_TRY(d.alloc(2));
+  hipError_t e = hipMemset(d.p, 0, 2 * sizeof(unsigned long long));
+  const unsigned long long threads = 1ull << 16, per = (n_polys + threads - 1) / threads;
+  if (e == hipSuccess) e = outfit::launch_selftest_aberth(threads, per, seed, d.p, nullptr);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  unsigned long long h[2] = {0, 0};
+  if (e == hipSuccess) e = hipMemcpy(h, d.p, sizeof h, hipMemcpyDeviceToHost);
+  d.release();
+  if (e != hipSuccess) return fail(OUTFIT_ERR_HIP, hipGetErrorString(e));
+  counts[0] = h[0];
+  counts[1] = h[1];
+  return OUTFIT_OK;
+}
+
 int outfit_hip_selftest_crmath(uint64_t n_args, uint64_t seed, uint64_t* counts) {
   if (!counts) return fail(OUTFIT_ERR_INVALID_BATCH, "NULL argument");
   int n_dev = 0;

@@ -76,6 +76,17 @@ __device__ __forceinline__ Cx cdiv(Cx a, Cx b) {
   const double n = b.re * b.re + b.im * b.im;
   return {(a.re * b.re + a.im * b.im) / n, (a.im * b.re - a.re * b.im) / n};
 }
+// The same quotient with ONE refined reciprocal of |b|^2 shared by the two components — bit-identical to
+// cdiv as long as |b|^2 (and with it both numerators, bounded by |a| |b|) stays far from the exponent limits,
+// where the compiler's division would rescale (fastdiv.hpp; device self-test on 2^27 operand pairs).
+// `lo` / `hi` collect the range of |b|^2 seen so that the caller can verify that condition afterwards.
+__device__ __forceinline__ Cx cdiv_shared(Cx a, Cx b, double& lo, double& hi) {
+  const double n = b.re * b.re + b.im * b.im;
+  lo = fmin(lo, n);
+  hi = fmax(hi, n);
+  const double y = fdiv::refined_rcp(n);
+  return {fdiv::div_with_rcp(a.re * b.re + a.im * b.im, n, y), fdiv::div_with_rcp(a.im * b.re - a.re * b.im, n, y)};
+}
 // Complex::mul_add with a real addend: (a*b) + c, fused where num-complex fuses
 __device__ __forceinline__ Cx cmul_add_real(Cx a, Cx b, double c) {
   return {fma(a.re, b.re, c) - (a.im * b.im), fma(a.re, b.im, fma(a.im, b.re, 0.0))};
@@ -91,6 +102,12 @@ __device__ __forceinline__ Cx cmul_add_real(Cx a, Cx b, double c) {
 // of num-complex's division), 28 reciprocals suffice. The sums are accumulated in the
 // crate's order (k ascending) so every partial sum is bit-identical.
 // Returns 0 converged / 1 max-iteration / 2 failed (NaN or Inf iterate).
+//
+// kSharedRcp: the 36 complex divisions of a sweep use cdiv_shared (11 instead of 22 division
+// instructions each). Its precondition is checked per sweep on the collected range of |denominator|^2;
+// if it ever fails (two iterates closer than 1e-100 or farther than 1e100 apart: not seen on any input)
+// the function returns 3 and the caller restarts with kSharedRcp = false, the plain divisions.
+template <bool kSharedRcp>
 __device__ __forceinline__ int aberth_deg8(double c0, double c3, double c6, unsigned max_iter, double eps,
                                            Cx (&z)[8]) {
   // initial guesses: the polynomial is monic with c7 = 0, so the centre is -0.0 and the
@@ -119,6 +136,7 @@ __device__ __forceinline__ int aberth_deg8(double c0, double c3, double c6, unsi
   }
   const double c6x6 = 6.0 * c6, c3x3 = 3.0 * c3;
   for (unsigned it = 1; it <= max_iter; ++it) {
+    double n_lo = 1.0, n_hi = 1.0;
     Cx sum[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) sum[i] = {0.0, 0.0};
@@ -126,7 +144,8 @@ __device__ __forceinline__ int aberth_deg8(double c0, double c3, double c6, unsi
     for (int i = 0; i < 8; ++i) {
 #pragma unroll
       for (int k = i + 1; k < 8; ++k) {
-        const Cx w = cdiv({1.0, 0.0}, csub(z[i], z[k]));  // 1/(z_i - z_k)
+        const Cx w = kSharedRcp ? cdiv_shared({1.0, 0.0}, csub(z[i], z[k]), n_lo, n_hi)
+                                : cdiv({1.0, 0.0}, csub(z[i], z[k]));  // 1/(z_i - z_k)
         sum[i] = cadd(sum[i], w);
         sum[k] = cadd(sum[k], {-w.re, -w.im});             // 1/(z_k - z_i), exactly
       }
@@ -154,7 +173,8 @@ __device__ __forceinline__ int aberth_deg8(double c0, double c3, double c6, unsi
       dp = cmul_add_real(dp, zi, c3x3);
       dp = cmul_add_real(dp, zi, 0.0);
       dp = cmul_add_real(dp, zi, 0.0);
-      const Cx zn = cadd(zi, cdiv(p, csub(cmul(p, sum[i]), dp)));
+      const Cx den = csub(cmul(p, sum[i]), dp);
+      const Cx zn = cadd(zi, kSharedRcp ? cdiv_shared(p, den, n_lo, n_hi) : cdiv(p, den));
       z[i] = zn;  // in place: the old z_i is no longer needed by any other root
       if (!failed) {
         // the crate returns Failed at the FIRST non-finite iterate; nothing after it matters
@@ -162,6 +182,9 @@ __device__ __forceinline__ int aberth_deg8(double c0, double c3, double c6, unsi
         else if (!(fabs(zn.re - zi.re) < eps && fabs(zn.im - zi.im) < eps)) converged = false;
       }
     }
+    // outside the window nothing of this sweep is trusted (coincident iterates, |d|^2 = 0, land here too and
+    // are then reported as failed by the plain divisions)
+    if (kSharedRcp && !(n_lo > 1e-200 && n_hi < 1e200)) return 3;
     if (failed) return 2;
     if (converged) return 0;
   }

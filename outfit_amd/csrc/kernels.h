@@ -156,6 +156,8 @@ hipError_t launch_orbit_rms(const RmsArgs& a, bool slow_list, hipStream_t s);
 hipError_t launch_select_best(const SelectArgs& a, hipStream_t s);
 constexpr unsigned kDiffcorMaxGroup = 8;  // lanes that may share one trajectory in k_diffcor
 hipError_t launch_diffcor(const DiffCorArgs& a, unsigned group, hipStream_t s);
+hipError_t launch_selftest_aberth(unsigned long long n_threads, unsigned long long n_per_thread,
+                                  unsigned long long seed, unsigned long long* d_out, hipStream_t s);
 hipError_t launch_selftest_crmath(unsigned long long n_threads, unsigned long long n_per_thread,
                                   unsigned long long seed, unsigned long long* d_out, hipStream_t s);
 hipError_t launch_selftest_division(unsigned long long n_threads, unsigned long long n_per_thread,

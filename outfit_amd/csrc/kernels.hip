@@ -224,7 +224,9 @@ k_gauss_roots(RootsArgs a) {
   if (descartes_upper_bound(c0, c3, c6) == 0) { a.W.flags[cid] = (unsigned)kCauseNoRoots; return; }
 
   Cx z[8];
-  if (aberth_deg8(c0, c3, c6, a.P.aberth_max_iter, a.P.aberth_eps, z) == 2) {
+  int ab = aberth_deg8<true>(c0, c3, c6, a.P.aberth_max_iter, a.P.aberth_eps, z);
+  if (ab == 3) ab = aberth_deg8<false>(c0, c3, c6, a.P.aberth_max_iter, a.P.aberth_eps, z);
+  if (ab == 2) {
     a.W.flags[cid] = (unsigned)kCauseRootFinding;
     return;
   }
@@ -729,6 +731,34 @@ k_selftest_division(unsigned long long n_per_thread, unsigned long long seed, un
   if (bad) atomicAdd(mismatches, bad);
 }
 
+// Self-test of the shared-reciprocal Aberth sweep against the plain divisions: same return code and the same
+// bits in all 8 iterates, on random sparse octics x^8 + c6 x^6 + c3 x^3 + c0 (the sign pattern and size of the
+// Gauss polynomial, gauss.rs:585-614, plus arbitrary signs). out[0] = polynomials that differ, out[1] = guard trips.
+__global__ void __launch_bounds__(256)
+k_selftest_aberth(unsigned long long n_per_thread, unsigned long long seed, unsigned long long* out) {
+  unsigned long long s = seed + 0xA24BAED4963EE407ull * ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x + 1);
+  unsigned long long bad = 0, trips = 0;
+  for (unsigned long long it = 0; it < n_per_thread; ++it) {
+    const int er = (it & 3) == 3 ? 12 : 3;
+    double c6 = random_double(s, er), c3 = random_double(s, er), c0 = random_double(s, er);
+    if ((it & 1) == 0) { c6 = -fabs(c6); c0 = -fabs(c0); }  // physical case: c6 < 0, c0 < 0
+    Cx za[8], zb[8];
+    const int ra = aberth_deg8<true>(c0, c3, c6, 50u, 1e-6, za);
+    const int rb = aberth_deg8<false>(c0, c3, c6, 50u, 1e-6, zb);
+    if (ra == 3) { trips += 1; continue; }
+    bool same = ra == rb;
+    if (ra != 2) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        same = same && __double_as_longlong(za[k].re) == __double_as_longlong(zb[k].re) &&
+               __double_as_longlong(za[k].im) == __double_as_longlong(zb[k].im);
+    }
+    bad += !same;
+  }
+  if (bad) atomicAdd(out, bad);
+  if (trips) atomicAdd(out + 1, trips);
+}
+
 // Self-test of the correctly-rounded functions: the fast (table + rounding test) path against the full
 // double-double evaluation, bit for bit. out[0] = arguments whose sin or cos differ, out[1] = arguments whose
 // acos differs, out[2] = sin/cos arguments that needed the full evaluation, out[3] = same for acos.
@@ -777,6 +807,12 @@ k_selftest_crmath(unsigned long long n_per_thread, unsigned long long seed, unsi
 // ------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------
+hipError_t launch_selftest_aberth(unsigned long long n_threads, unsigned long long n_per_thread,
+                                  unsigned long long seed, unsigned long long* d_out, hipStream_t s) {
+  const unsigned grid = (unsigned)((n_threads + 255) / 256);
+  hipLaunchKernelGGL(k_selftest_aberth, dim3(grid), dim3(256), 0, s, n_per_thread, seed, d_out);
+  return hipGetLastError();
+}
 hipError_t launch_selftest_crmath(unsigned long long n_threads, unsigned long long n_per_thread,
                                   unsigned long long seed, unsigned long long* d_out, hipStream_t s) {
   const unsigned grid = (unsigned)((n_threads + 255) / 256);

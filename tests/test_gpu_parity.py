@@ -73,6 +73,16 @@ def test_fast_division_is_exact():
     assert bad.value == 0
 
 
+def test_shared_reciprocal_aberth_equals_plain_divisions():
+    """gauss.hpp aberth_deg8<true> (one refined reciprocal per complex division) vs <false> (`/`):
+    identical return codes and iterates on 2^24 random sparse octics, half of them with the Gauss signs."""
+    from outfit_amd import _lib
+    counts = (C.c_uint64 * 2)()
+    assert _lib.lib().outfit_hip_selftest_aberth(1 << 24, 99, counts) == 0
+    assert counts[0] == 0, list(counts)
+    assert counts[1] < (1 << 24) / 100, list(counts)
+
+
 def test_correctly_rounded_fast_path_equals_full_evaluation():
     """crmath.hpp: table + rounding-test fast path vs the double-double Taylor evaluation, 2^30 arguments
     (the angles the path sees, all magnitudes below 2^20, neighbourhoods of k*pi/2 and of the table nodes,
