@@ -100,7 +100,7 @@ struct outfit_hip_session {
   uint64_t chunk = 0;
 
   DevBuf<unsigned long long> traj_offset;
-  DevBuf<double> mjd, ra, dec, sra, sdec, helio, geo, obs_pos, cos_dec, unit, noise, coef;
+  DevBuf<double> mjd, ra, dec, sra, sdec, helio, geo, obs_pos, cos_dec, unit[2], noise, coef;
   DevBuf<double> heap_w, sum, el, dirS, roots, state, psi0;
   DevBuf<unsigned long long> heap_id, triplets[2], queue, slow_list, slow_count;
   DevBuf<unsigned> n_triplets[2], flags, n_win;
@@ -125,8 +125,10 @@ struct outfit_hip_session {
   hipStream_t k0_stream = nullptr;   // triplet selection, ahead of the candidate kernels (and of the previous run's tail)
   hipEvent_t ev_k3[2] = {nullptr, nullptr};  // last consumer of triplet buffer b has finished
   bool k3_recorded[2] = {false, false};
-  unsigned long long chunk_seq = 0;
-  hipEvent_t ev_fast = nullptr, ev_general = nullptr, ev_sub[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_unit_free[2] = {nullptr, nullptr};  // last K2a reading unit buffer b has finished
+  bool unit_free_recorded[2] = {false, false};
+  unsigned long long chunk_seq = 0, run_seq = 0;
+  hipEvent_t ev_start = nullptr, ev_prepass = nullptr, ev_fast = nullptr, ev_general = nullptr, ev_sub[4] = {nullptr, nullptr, nullptr, nullptr};
   hipStream_t last_stream = nullptr;
   bool profiling = false;
   struct Timed { int id; hipEvent_t a, b; };
@@ -136,7 +138,7 @@ struct outfit_hip_session {
 
   void free_all() {
     traj_offset.release(); mjd.release(); ra.release(); dec.release(); sra.release(); sdec.release();
-    helio.release(); geo.release(); obs_pos.release(); cos_dec.release(); unit.release(); noise.release(); coef.release();
+    helio.release(); geo.release(); obs_pos.release(); cos_dec.release(); unit[0].release(); unit[1].release(); noise.release(); coef.release();
     heap_w.release(); sum.release(); el.release(); dirS.release(); roots.release(); state.release();
     psi0.release(); slow_list.release(); slow_count.release();
     heap_id.release(); triplets[0].release(); triplets[1].release(); queue.release();
@@ -151,11 +153,12 @@ struct outfit_hip_session {
     aux_stream = nullptr;
     if (k0_stream) (void)hipStreamDestroy(k0_stream);
     k0_stream = nullptr;
-    for (hipEvent_t& e : ev_k3) {
-      if (e) (void)hipEventDestroy(e);
-      e = nullptr;
-    }
-    for (hipEvent_t* e : {&ev_fast, &ev_general, &ev_sub[0], &ev_sub[1], &ev_sub[2], &ev_sub[3]}) {
+    for (hipEvent_t* arr : {ev_k3, ev_unit_free})
+      for (int b = 0; b < 2; ++b) {
+        if (arr[b]) (void)hipEventDestroy(arr[b]);
+        arr[b] = nullptr;
+      }
+    for (hipEvent_t* e : {&ev_start, &ev_prepass, &ev_fast, &ev_general, &ev_sub[0], &ev_sub[1], &ev_sub[2], &ev_sub[3]}) {
       if (*e) (void)hipEventDestroy(*e);
       *e = nullptr;
     }
@@ -214,7 +217,8 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
   HIP_TRY(hipStreamCreateWithFlags(&s->aux_stream, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&s->k0_stream, hipStreamNonBlocking));
   for (hipEvent_t& e : s->ev_k3) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  for (hipEvent_t* e : {&s->ev_fast, &s->ev_general, &s->ev_sub[0], &s->ev_sub[1], &s->ev_sub[2], &s->ev_sub[3]})
+  for (hipEvent_t& e : s->ev_unit_free) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (hipEvent_t* e : {&s->ev_start, &s->ev_prepass, &s->ev_fast, &s->ev_general, &s->ev_sub[0], &s->ev_sub[1], &s->ev_sub[2], &s->ev_sub[3]})
     HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
   s->params = *params;
   s->n_traj = b->n_traj;
@@ -238,7 +242,7 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
   TRY_RC(upload(s->sdec, n ? b->sigma_dec + o0 : nullptr, n));
   TRY_RC(upload(s->helio, n ? b->obs_helio_equ + 3 * o0 : nullptr, 3 * n));
   HIP_TRY(s->cos_dec.alloc(n));
-  HIP_TRY(s->unit.alloc(3 * n));
+  for (int b = 0; b < 2; ++b) HIP_TRY(s->unit[b].alloc(3 * n));  // double-buffered: written ahead on k0_stream
   if (s->has_ephem && s->has_geo) {
     TRY_RC(upload(s->geo, n ? b->obs_geo_ecl + 3 * o0 : nullptr, 3 * n));
     HIP_TRY(s->obs_pos.alloc(3 * n));
@@ -354,13 +358,29 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
 
   const bool on_device_earth = s->has_ephem && s->has_geo;
   const double* obs_pos = on_device_earth ? s->obs_pos.p : s->helio.p;
+  // K1 in two halves. The direction cosines feed K2a: evaluated on k0_stream ahead of the K0 slices, into the
+  // unit buffer of this run (the previous run's K2a may still be reading the other one). Observer positions
+  // and cos(dec) are first read by K2c: evaluated on aux beside K2a, once everything enqueued on the caller's
+  // stream so far (previous run's K2c and corrector, which read them) has finished.
+  const unsigned ub = (unsigned)(s->run_seq++ & 1u);
+  outfit::PrepassArgs pa{};
+  pa.n_obs = s->n_obs; pa.mjd = s->mjd.p; pa.dec = s->dec.p; pa.geo_ecl = s->geo.p; pa.obs_pos = s->obs_pos.p;
+  pa.cos_dec = s->cos_dec.p; pa.unit = s->unit[ub].p; pa.ra = s->ra.p; pa.has_table = on_device_earth;
+  pa.T = s->table; pa.error_flag = s->error_flag.p;
   {
-    outfit::PrepassArgs pa{};
-    pa.n_obs = s->n_obs; pa.mjd = s->mjd.p; pa.dec = s->dec.p; pa.geo_ecl = s->geo.p; pa.obs_pos = s->obs_pos.p;
-    pa.cos_dec = s->cos_dec.p; pa.unit = s->unit.p; pa.ra = s->ra.p; pa.has_table = on_device_earth;
-    pa.T = s->table; pa.error_flag = s->error_flag.p;
-    Stamp stamp(s, st, K_PREPASS);
-    HIP_TRY(outfit::launch_observer_prepass(pa, st));
+    // the buffer's previous readers: the K2a launches of the run before the previous one
+    if (s->unit_free_recorded[ub]) HIP_TRY(hipStreamWaitEvent(s->k0_stream, s->ev_unit_free[ub], 0));
+    pa.parts = outfit::kPrepassUnit;
+    Stamp stamp(s, s->k0_stream, K_PREPASS);
+    HIP_TRY(outfit::launch_observer_prepass(pa, s->k0_stream));
+  }
+  {
+    HIP_TRY(hipEventRecord(s->ev_start, st));
+    HIP_TRY(hipStreamWaitEvent(aux, s->ev_start, 0));
+    pa.parts = outfit::kPrepassObserver;
+    Stamp stamp(s, aux, K_PREPASS);
+    HIP_TRY(outfit::launch_observer_prepass(pa, aux));
+    HIP_TRY(hipEventRecord(s->ev_prepass, aux));
     s->prepass_done = true;
   }
   // Two latency-bound kernels run on their own streams in the shadow of VALU-bound ones:
@@ -385,7 +405,7 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
     ci.n_triplets = s->n_triplets[tb].p; ci.triplets = s->triplets[tb].p;
     ci.mjd = s->mjd.p; ci.ra = s->ra.p; ci.dec = s->dec.p; ci.sra = s->sra.p; ci.sdec = s->sdec.p;
     ci.helio = s->helio.p; ci.noise_z = s->noise.p; ci.noise_scale = s->params.noise_scale;
-    ci.unit = s->unit.p; ci.n_obs_total = s->n_obs;
+    ci.unit = s->unit[ub].p; ci.n_obs_total = s->n_obs;
     outfit::CandidateScratch w{};
     w.flags = s->flags.p; w.S = s->dirS.p; w.roots = s->roots.p; w.state = s->state.p; w.el = s->el.p;
     w.sum = s->sum.p; w.n_win = s->n_win.p; w.psi0 = s->psi0.p; w.slow_list = s->slow_list.p;
@@ -415,6 +435,8 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
       Stamp stamp(s, st, K_ROOTS);
       HIP_TRY(outfit::launch_gauss_roots(ra, st));
     }
+    HIP_TRY(hipEventRecord(s->ev_unit_free[ub], st));  // last K2a of this run so far: unit[ub] may be rewritten after it
+    s->unit_free_recorded[ub] = true;
     const outfit::CorrectArgs ca{ci, w, s->gp, s->queue.p};
     {
       Stamp stamp(s, st, K_PRELIM);
@@ -434,6 +456,7 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
     }
     HIP_TRY(hipEventRecord(s->ev_general, aux));
     const outfit::RmsArgs rm{ci, w, obs_pos, s->cos_dec.p, s->params.extf, s->params.dtmax};
+    HIP_TRY(hipStreamWaitEvent(st, s->ev_prepass, 0));
     {
       Stamp stamp(s, st, K_RMS);
       HIP_TRY(outfit::launch_orbit_rms(rm, /*slow_list=*/false, st));
@@ -508,7 +531,8 @@ int session_run_lsq(outfit_hip_session* s, const outfit_diffcor_config_t* cfg,
   if (!s->prepass_done) {
     outfit::PrepassArgs pa{};
     pa.n_obs = s->n_obs; pa.mjd = s->mjd.p; pa.dec = s->dec.p; pa.geo_ecl = s->geo.p; pa.obs_pos = s->obs_pos.p;
-    pa.cos_dec = s->cos_dec.p; pa.unit = s->unit.p; pa.ra = s->ra.p; pa.has_table = on_device_earth;
+    pa.cos_dec = s->cos_dec.p; pa.unit = s->unit[0].p; pa.ra = s->ra.p; pa.has_table = on_device_earth;
+    pa.parts = outfit::kPrepassObserver;  // the corrector reads obs_pos only
     pa.T = s->table; pa.error_flag = s->error_flag.p;
     Stamp stamp(s, st, K_PREPASS);
     HIP_TRY(outfit::launch_observer_prepass(pa, st));

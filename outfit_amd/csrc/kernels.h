@@ -46,8 +46,13 @@ struct TripletArgs {
   unsigned long long* triplets;         // [n_traj][k_cap] packed (i,j,k)
 };
 
+// the two halves of K1 (they run on different streams: the direction cosines ahead of K2a, the observer
+// positions and cos(dec) beside K2a, first needed by K2c)
+constexpr unsigned kPrepassUnit = 1u, kPrepassObserver = 2u;
+
 struct PrepassArgs {
   unsigned long long n_obs;
+  unsigned parts;  // kPrepassUnit | kPrepassObserver
   const double* mjd;
   const double* ra;
   const double* dec;

@@ -80,9 +80,7 @@ k_observer_prepass(PrepassArgs a) {
   __shared__ int s_bad;
   const unsigned long long o = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = o < a.n_obs;
-  // cos(dec_obs) of ephemeris_error (observation_ephemeris.rs:411) depends on the observation only
-  if (live) {
-    a.cos_dec[o] = cos(a.dec[o]);
+  if (live && (a.parts & kPrepassUnit)) {
     // Column of unit_matrix (gauss.rs:488-502) for the noise-free observation, with the correctly-rounded
     // functions: every noise-free candidate that uses this observation (~15 triplets each) reads the
     // three direction cosines instead of re-evaluating two double-double sincos
@@ -93,6 +91,9 @@ k_observer_prepass(PrepassArgs a) {
     a.unit[a.n_obs + o] = sr * cd;
     a.unit[2 * a.n_obs + o] = sd;
   }
+  if (!(a.parts & kPrepassObserver)) return;
+  // cos(dec_obs) of ephemeris_error (observation_ephemeris.rs:411) depends on the observation only
+  if (live) a.cos_dec[o] = cos(a.dec[o]);
   if (!a.has_table) return;
   if (threadIdx.x == 0) { s_min = ~0ull; s_max = 0ull; s_bad = 0; }
   __syncthreads();
