@@ -609,22 +609,26 @@ k_orbit_rms(RmsArgs a) {
 // K3: replay of the sequential loop of estimate_best_orbit over the candidates of
 // one trajectory, in (triplet, realisation) order.
 // ------------------------------------------------------------------------------
+// One wave = 64 trajectories; their candidates are contiguous in the scratch arrays, so the wave stages
+// them through LDS in tiles of kSelTile candidates per trajectory (two rows of 32 contiguous words per load
+// instruction) instead of 64 lanes each walking its own row (one cache line per lane and load).
+constexpr unsigned kSelTile = 32;
 __global__ void __launch_bounds__(64)
 k_select_best(SelectArgs a) {
-  const unsigned long long lt = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (lt >= a.n_traj) return;
+  __shared__ double s_sum[64][kSelTile + 1];
+  __shared__ unsigned s_flags[64][kSelTile + 1];
+  __shared__ unsigned s_nwin[64][kSelTile + 1];
+  const unsigned tl = threadIdx.x;
+  const unsigned long long blk0 = (unsigned long long)blockIdx.x * 64;
+  const unsigned long long lt = blk0 + tl;
+  const bool live = lt < a.n_traj;
   GaussResultRec out;
   out.status = 0; out.cause = 0; out.stage = 0; out.kind = 0;
   out.attempts = 0; out.best_triplet = 0; out.best_realization = 0;
   out.epoch = 0.0; out.rms = 0.0;
   for (int k = 0; k < 6; ++k) out.elem[k] = 0.0;
-  const unsigned nt = a.n_triplets[lt];
+  const unsigned nt = live ? a.n_triplets[lt] : 0u;
   out.n_triplets = nt;
-  if (nt == 0) {
-    out.status = 1;  // NoFeasibleTriplets (trajectory.rs:439-451)
-    a.out[a.traj0 + lt] = out;
-    return;
-  }
   double best = INFINITY;
   long long best_c = -1;
   int last_error = 0;
@@ -632,25 +636,49 @@ k_select_best(SelectArgs a) {
   bool aborted = false;
   const unsigned long long c0 = lt * a.cand_per_traj;
   const unsigned n_c = nt * a.n_real;
-  for (unsigned c = 0; c < n_c; ++c) {
-    const unsigned long long cid = c0 + c;
-    const unsigned f = a.W.flags[cid];
-    attempts += 1;
-    if (!(f & kFlagOk)) { last_error = (int)(f & 0xFu); continue; }  // prelim_orbit Err
-    const unsigned conv = (f >> kFlagConvShift) & 0x7u;
-    if (conv) { out.status = (int)conv; aborted = true; break; }      // to_equinoctial()? (quirk Q2)
-    // rms_orbit_error with prune_if_rms_ge = Some(best): the partial sums are
-    // non-decreasing, so "some partial sum >= cutoff" == "final sum >= cutoff".
-    const double denom = 2.0 * (double)a.W.n_win[cid];
-    const double cutoff = isfinite(best) ? best * best * denom : INFINITY;
-    double rms;
-    if (f & kFlagRmsErr) rms = best;
-    else {
-      const double s = a.W.sum[cid];
-      rms = (s >= cutoff) ? best : sqrt(s / denom);
+  for (unsigned cb = 0; cb < a.cand_per_traj; cb += kSelTile) {
+    // does any trajectory of this wave still need candidates from this tile on?
+    const bool want = live && !aborted && cb < n_c;
+    if (__ballot(want) == 0ull) break;
+    for (unsigned idx = tl; idx < 64u * kSelTile; idx += 64u) {
+      const unsigned row = idx / kSelTile, cc = idx % kSelTile;
+      const unsigned long long g = (blk0 + row) * a.cand_per_traj + cb + cc;
+      const bool in = (blk0 + row) < a.n_traj && cb + cc < a.cand_per_traj;
+      s_flags[row][cc] = in ? a.W.flags[g] : kFlagEmpty;
+      s_nwin[row][cc] = in ? a.W.n_win[g] : 0u;
+      s_sum[row][cc] = in ? a.W.sum[g] : 0.0;
     }
-    if (!isfinite(rms)) { last_error = 4; continue; }  // NonFiniteScore
-    if (rms < best) { best = rms; best_c = (long long)c; }
+    __syncthreads();
+    if (want) {
+      const unsigned hi = n_c - cb < kSelTile ? n_c - cb : kSelTile;
+      for (unsigned cc = 0; cc < hi; ++cc) {
+        const unsigned c = cb + cc;
+        const unsigned f = s_flags[tl][cc];
+        attempts += 1;
+        if (!(f & kFlagOk)) { last_error = (int)(f & 0xFu); continue; }  // prelim_orbit Err
+        const unsigned conv = (f >> kFlagConvShift) & 0x7u;
+        if (conv) { out.status = (int)conv; aborted = true; break; }      // to_equinoctial()? (quirk Q2)
+        // rms_orbit_error with prune_if_rms_ge = Some(best): the partial sums are
+        // non-decreasing, so "some partial sum >= cutoff" == "final sum >= cutoff".
+        const double denom = 2.0 * (double)s_nwin[tl][cc];
+        const double cutoff = isfinite(best) ? best * best * denom : INFINITY;
+        double rms;
+        if (f & kFlagRmsErr) rms = best;
+        else {
+          const double sm = s_sum[tl][cc];
+          rms = (sm >= cutoff) ? best : sqrt(sm / denom);
+        }
+        if (!isfinite(rms)) { last_error = 4; continue; }  // NonFiniteScore
+        if (rms < best) { best = rms; best_c = (long long)c; }
+      }
+    }
+    __syncthreads();
+  }
+  if (!live) return;
+  if (nt == 0) {
+    out.status = 1;  // NoFeasibleTriplets (trajectory.rs:439-451)
+    a.out[a.traj0 + lt] = out;
+    return;
   }
   out.attempts = attempts;
   if (!aborted) {
