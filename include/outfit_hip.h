@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define OUTFIT_HIP_ABI_VERSION 2
+#define OUTFIT_HIP_ABI_VERSION 3
 
 /* ---- whole-call return codes --------------------------------------------- */
 #define OUTFIT_OK                 0
@@ -113,8 +113,18 @@ typedef struct outfit_obs_batch {
                                     NULL => the RMS stage uses obs_helio_equ directly              */
   const double   *noise_z;       /* NULL or, per trajectory, max_triplets*n_noise*6 standard
                                     normals in (triplet, realisation, ra0 ra1 ra2 dec0 dec1 dec2)
-                                    order (gauss.rs:341-386); required when n_noise_realizations>0 */
+                                    order (gauss.rs:341-386); required when n_noise_realizations>0
+                                    and noise_source == OUTFIT_NOISE_HOST                          */
+  /* -- device-side draws (statistical parity only, see device/noise.hpp) -- */
+  uint32_t        noise_source;  /* OUTFIT_NOISE_HOST (0) or OUTFIT_NOISE_DEVICE                   */
+  uint32_t        _pad0;
+  uint64_t        noise_seed;    /* the `base_seed` of obs_dataset_api.rs:272 (Philox key)         */
+  const uint64_t *traj_key;      /* NULL or one key per trajectory (TrajId::stable_hash(),
+                                    obs_dataset_api.rs:285); NULL => traj_key_base + index          */
+  uint64_t        traj_key_base;
 } outfit_obs_batch_t;
+#define OUTFIT_NOISE_HOST   0
+#define OUTFIT_NOISE_DEVICE 1
 
 /* Legacy-DE ("horizon") Chebyshev table, restricted to what
  * `HorizonData::ephemeris(Earth, Sun, ..)` reads (horizon_data.rs:810-849):
@@ -340,6 +350,12 @@ int  outfit_hip_ephem_header(const outfit_ephem_file_t *e, outfit_de_header_t *h
 /* `view->coef` points into the handle and stays valid until outfit_hip_ephem_close. */
 int  outfit_hip_ephem_view(const outfit_ephem_file_t *e, outfit_ephem_t *view);
 void outfit_hip_ephem_close(outfit_ephem_file_t *e);
+
+/* The standard normals the device generator yields for OUTFIT_NOISE_DEVICE, in the layout of `noise_z`
+ * (n_traj * max_triplets * n_noise * 6 doubles): what a host needs to replay a device-noise run through
+ * the host-normal mode (or through a CPU implementation). traj_key may be NULL (traj_key_base + index). */
+int outfit_hip_device_normals(uint64_t noise_seed, const uint64_t *traj_key, uint64_t traj_key_base,
+                              uint64_t n_traj, uint32_t max_triplets, uint64_t n_noise, double *out);
 
 /* ---- diagnostics ------------------------------------------------------------ */
 /* Device self-test: the kernels replace some fp64 divisions by cheaper sequences that

@@ -7,7 +7,7 @@ src/initial_orbit_determination/obs_dataset_api.rs:145-296).
 """
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OUTFIT_OK = 0
 OUTFIT_ERR_INVALID_PARAM = -1
@@ -79,6 +79,11 @@ class ObsBatchC(C.Structure):
         ("obs_helio_equ", _dp),
         ("obs_geo_ecl", _dp),
         ("noise_z", _dp),
+        ("noise_source", C.c_uint32),
+        ("_pad0", C.c_uint32),
+        ("noise_seed", C.c_uint64),
+        ("traj_key", C.POINTER(C.c_uint64)),
+        ("traj_key_base", C.c_uint64),
     ]
 
 
@@ -135,6 +140,8 @@ DC_DIVERGED = 3
 OBS_ACTIVE = 0
 OBS_REJECTED = 1
 OBS_FORCED_OUT = 2
+NOISE_HOST = 0
+NOISE_DEVICE = 1
 
 
 class DiffCorConfigC(C.Structure):

@@ -207,13 +207,17 @@ class ObsBatch:
     `traj_ids` are the caller's trajectory identifiers (the keys of `FullOrbitResult`)."""
 
     def __init__(self, traj_offset, mjd_tt, ra, dec, sigma_ra, sigma_dec, obs_helio_equ,
-                 obs_geo_ecl=None, noise_z=None, traj_ids=None):
+                 obs_geo_ecl=None, noise_z=None, traj_ids=None, noise_seed=None, traj_key=None, traj_key_base=0):
         self.traj_offset = np.ascontiguousarray(traj_offset, dtype=np.uint64)
         self.mjd_tt, self.ra, self.dec = _f64(mjd_tt), _f64(ra), _f64(dec)
         self.sigma_ra, self.sigma_dec = _f64(sigma_ra), _f64(sigma_dec)
         self.obs_helio_equ = _f64(obs_helio_equ)
         self.obs_geo_ecl = None if obs_geo_ecl is None else _f64(obs_geo_ecl)
         self.noise_z = None if noise_z is None else _f64(noise_z)
+        # device-side draws (device/noise.hpp): noise_seed set => OUTFIT_NOISE_DEVICE, keyed per trajectory
+        self.noise_seed = noise_seed
+        self.traj_key = None if traj_key is None else np.ascontiguousarray(traj_key, dtype=np.uint64)
+        self.traj_key_base = int(traj_key_base)
         self.n_traj = len(self.traj_offset) - 1
         self.traj_ids = list(range(self.n_traj)) if traj_ids is None else list(traj_ids)
 
@@ -228,7 +232,10 @@ class ObsBatch:
         geo = None if self.obs_geo_ecl is None else self.obs_geo_ecl[3 * o0:3 * o1]
         return ObsBatch(self.traj_offset[t0:t1 + 1] - np.uint64(o0), self.mjd_tt[o0:o1], self.ra[o0:o1],
                         self.dec[o0:o1], self.sigma_ra[o0:o1], self.sigma_dec[o0:o1],
-                        self.obs_helio_equ[3 * o0:3 * o1], geo, None, self.traj_ids[t0:t1])
+                        self.obs_helio_equ[3 * o0:3 * o1], geo, None, self.traj_ids[t0:t1],
+                        noise_seed=self.noise_seed,
+                        traj_key=None if self.traj_key is None else self.traj_key[t0:t1],
+                        traj_key_base=self.traj_key_base + (0 if self.traj_key is not None else t0))
 
     def as_c(self):
         b = ObsBatchC()
@@ -240,6 +247,12 @@ class ObsBatch:
             b.obs_geo_ecl = self.obs_geo_ecl.ctypes.data_as(_dp)
         if self.noise_z is not None:
             b.noise_z = self.noise_z.ctypes.data_as(_dp)
+        if self.noise_seed is not None:
+            b.noise_source = _abi.NOISE_DEVICE
+            b.noise_seed = int(self.noise_seed) & 0xFFFFFFFFFFFFFFFF
+        if self.traj_key is not None:
+            b.traj_key = self.traj_key.ctypes.data_as(C.POINTER(C.c_uint64))
+        b.traj_key_base = self.traj_key_base
         return b
 
 
@@ -524,6 +537,20 @@ def _session_lsq_results(self):
 
 IODSession.run_lsq = _session_run_lsq
 IODSession.lsq_results = _session_lsq_results
+
+
+def device_normals(noise_seed, n_traj, max_triplets, n_noise, traj_key=None, traj_key_base=0):
+    """`outfit_hip_device_normals`: the standard normals the device generator (Philox4x32-10 + Box-Muller,
+    device/noise.hpp) yields, in the layout of `ObsBatch.noise_z`."""
+    out = np.empty(int(n_traj) * int(max_triplets) * int(n_noise) * 6, dtype=np.float64)
+    keys = None if traj_key is None else np.ascontiguousarray(traj_key, dtype=np.uint64)
+    rc = lib().outfit_hip_device_normals(int(noise_seed) & 0xFFFFFFFFFFFFFFFF,
+                                         None if keys is None else keys.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                         int(traj_key_base), int(n_traj), int(max_triplets), int(n_noise),
+                                         out.ctypes.data_as(_dp))
+    if rc != 0:
+        _raise_rc(rc)
+    return out
 
 
 def propagate_universal(r, v, t0, t1, convergency=100 * 2.220446049250313e-16):

@@ -99,7 +99,9 @@ struct outfit_hip_session {
   unsigned n_real = 1, k_cap = 0, cand_per_traj = 0;
   uint64_t chunk = 0;
 
-  DevBuf<unsigned long long> traj_offset;
+  DevBuf<unsigned long long> traj_offset, traj_key;
+  bool noise_device = false;
+  unsigned long long noise_seed = 0, traj_key_base = 0;
   DevBuf<double> mjd, ra, dec, sra, sdec, helio, geo, obs_pos, cos_dec, unit[2], noise, coef;
   DevBuf<double> heap_w, sum, el, dirS, roots, state, psi0;
   DevBuf<unsigned long long> heap_id, triplets[2], queue, slow_list, slow_count;
@@ -137,7 +139,7 @@ struct outfit_hip_session {
   int kernel_launches[K_COUNT] = {};
 
   void free_all() {
-    traj_offset.release(); mjd.release(); ra.release(); dec.release(); sra.release(); sdec.release();
+    traj_offset.release(); traj_key.release(); mjd.release(); ra.release(); dec.release(); sra.release(); sdec.release();
     helio.release(); geo.release(); obs_pos.release(); cos_dec.release(); unit[0].release(); unit[1].release(); noise.release(); coef.release();
     heap_w.release(); sum.release(); el.release(); dirS.release(); roots.release(); state.release();
     psi0.release(); slow_list.release(); slow_count.release();
@@ -182,8 +184,11 @@ int check_batch(const outfit_iod_params_t* params, const outfit_obs_batch_t* b, 
   const uint64_t n_obs = b->traj_offset[b->n_traj] - o0;
   if (n_obs > 0 && (!b->mjd_tt || !b->ra || !b->dec || !b->sigma_ra || !b->sigma_dec || !b->obs_helio_equ))
     return fail(OUTFIT_ERR_INVALID_BATCH, "an observation array is NULL");
-  if (params->n_noise_realizations > 0 && !b->noise_z)
-    return fail(OUTFIT_ERR_INVALID_BATCH, "noise_z is required when n_noise_realizations > 0");
+  if (b->noise_source != OUTFIT_NOISE_HOST && b->noise_source != OUTFIT_NOISE_DEVICE)
+    return fail(OUTFIT_ERR_INVALID_BATCH, "noise_source must be OUTFIT_NOISE_HOST or OUTFIT_NOISE_DEVICE");
+  if (params->n_noise_realizations > 0 && b->noise_source == OUTFIT_NOISE_HOST && !b->noise_z)
+    return fail(OUTFIT_ERR_INVALID_BATCH,
+                "noise_z is required when n_noise_realizations > 0 (or set noise_source = OUTFIT_NOISE_DEVICE)");
   const uint64_t cpt = (uint64_t)params->max_triplets * (1 + params->n_noise_realizations);
   if (params->n_noise_realizations >= (1ull << 31) || cpt >= (1ull << 31))
     return fail(OUTFIT_ERR_INVALID_PARAM, "max_triplets * (1 + n_noise_realizations) must be < 2^31");
@@ -260,9 +265,15 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
     TRY_RC(upload(s->coef, eph->coef, (size_t)eph->n_blocks * per_block));
     s->table.coef = s->coef.p;
   }
-  if (params->n_noise_realizations > 0)
+  s->noise_device = params->n_noise_realizations > 0 && b->noise_source == OUTFIT_NOISE_DEVICE;
+  s->noise_seed = b->noise_seed;
+  s->traj_key_base = b->traj_key_base;
+  if (s->noise_device) {
+    if (b->traj_key) TRY_RC(upload(s->traj_key, reinterpret_cast<const unsigned long long*>(b->traj_key), (size_t)s->n_traj));
+  } else if (params->n_noise_realizations > 0) {
     TRY_RC(upload(s->noise, b->noise_z,
                   (size_t)s->n_traj * s->k_cap * (size_t)params->n_noise_realizations * 6));
+  }
   HIP_TRY(s->results.alloc((size_t)s->n_traj));
   // status -1 until an IOD run fills the records (outfit_hip_session_run_lsq reads them as "no seed")
   if (s->n_traj) HIP_TRY(hipMemset(s->results.p, 0xFF, (size_t)s->n_traj * sizeof(outfit::GaussResultRec)));
@@ -406,6 +417,8 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
     ci.mjd = s->mjd.p; ci.ra = s->ra.p; ci.dec = s->dec.p; ci.sra = s->sra.p; ci.sdec = s->sdec.p;
     ci.helio = s->helio.p; ci.noise_z = s->noise.p; ci.noise_scale = s->params.noise_scale;
     ci.unit = s->unit[ub].p; ci.n_obs_total = s->n_obs;
+    ci.noise_device = s->noise_device; ci.noise_seed = s->noise_seed; ci.traj_key_base = s->traj_key_base;
+    ci.traj_key = s->traj_key.p;
     outfit::CandidateScratch w{};
     w.flags = s->flags.p; w.S = s->dirS.p; w.roots = s->roots.p; w.state = s->state.p; w.el = s->el.p;
     w.sum = s->sum.p; w.n_win = s->n_win.p; w.psi0 = s->psi0.p; w.slow_list = s->slow_list.p;
@@ -596,6 +609,8 @@ int run_sharded(const outfit_iod_params_t* params, const outfit_obs_batch_t* bat
     sub.traj_offset = batch->traj_offset + t0;
     if (batch->noise_z)
       sub.noise_z = batch->noise_z + (size_t)t0 * params->max_triplets * (size_t)params->n_noise_realizations * 6;
+    if (batch->traj_key) sub.traj_key = batch->traj_key + t0;
+    else sub.traj_key_base = batch->traj_key_base + t0;
     rc[d] = work(d, sub, t0);
     if (rc[d] != OUTFIT_OK) msg[d] = g_last_error;  // thread-local: keep the shard's message
   };
@@ -810,6 +825,33 @@ int outfit_hip_fit_lsq(const outfit_iod_params_t* params, const outfit_diffcor_c
     g_last_error = keep;
     return r;
   });
+}
+
+int outfit_hip_device_normals(uint64_t noise_seed, const uint64_t* traj_key, uint64_t traj_key_base, uint64_t n_traj,
+                              uint32_t max_triplets, uint64_t n_noise, double* out) {
+  const uint64_t n = n_traj * max_triplets * n_noise * 6;
+  if (n == 0) return OUTFIT_OK;
+  if (!out) return fail(OUTFIT_ERR_INVALID_BATCH, "out is NULL");
+  if (n_noise >= (1ull << 30)) return fail(OUTFIT_ERR_INVALID_PARAM, "n_noise too large");
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+    return fail(OUTFIT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+  DevBuf<double> d;
+  DevBuf<unsigned long long> k;
+  HIP_TRY(d.alloc((size_t)n));
+  hipError_t e = hipSuccess;
+  if (traj_key) {
+    e = k.alloc((size_t)n_traj);
+    if (e == hipSuccess) e = hipMemcpy(k.p, traj_key, (size_t)n_traj * sizeof(uint64_t), hipMemcpyHostToDevice);
+  }
+  if (e == hipSuccess)
+    e = outfit::launch_device_normals(noise_seed, k.p, traj_key_base, n_traj, max_triplets, (unsigned)n_noise, d.p, nullptr);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(out, d.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+  d.release();
+  k.release();
+  if (e != hipSuccess) return fail(OUTFIT_ERR_HIP, hipGetErrorString(e));
+  return OUTFIT_OK;
 }
 
 int outfit_hip_selftest_aberth(uint64_t n_polys, uint64_t seed, uint64_t* counts) {

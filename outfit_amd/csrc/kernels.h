@@ -6,6 +6,7 @@
 #include "device/gauss.hpp"
 #include "device/triplets.hpp"
 #include "device/diffcor.hpp"
+#include "device/noise.hpp"
 
 namespace outfit {
 
@@ -76,6 +77,10 @@ struct CandidateIndex {
   double noise_scale;
   const double* unit;                 // [3][n_obs_total], written by K1
   unsigned long long n_obs_total;
+  // device-side noise (noise.hpp): used instead of noise_z when noise_device is set
+  bool noise_device;
+  unsigned long long noise_seed, traj_key_base;
+  const unsigned long long* traj_key;  // nullable
 };
 
 // candidate-level scratch, structure-of-arrays over the candidates of one chunk
@@ -161,6 +166,9 @@ hipError_t launch_orbit_rms(const RmsArgs& a, bool slow_list, hipStream_t s);
 hipError_t launch_select_best(const SelectArgs& a, hipStream_t s);
 constexpr unsigned kDiffcorMaxGroup = 8;  // lanes that may share one trajectory in k_diffcor
 hipError_t launch_diffcor(const DiffCorArgs& a, unsigned group, hipStream_t s);
+hipError_t launch_device_normals(unsigned long long seed, const unsigned long long* traj_key,
+                                 unsigned long long key_base, unsigned long long n_traj, unsigned k_cap,
+                                 unsigned n_noise, double* out, hipStream_t s);
 hipError_t launch_selftest_aberth(unsigned long long n_threads, unsigned long long n_per_thread,
                                   unsigned long long seed, unsigned long long* d_out, hipStream_t s);
 hipError_t launch_selftest_crmath(unsigned long long n_threads, unsigned long long n_per_thread,

@@ -165,7 +165,14 @@ __device__ __forceinline__ void gather_angles(const CandidateIndex& I, const Can
   }
   if (c.r > 0) {
     const unsigned long long traj = I.traj0 + c.lt;
-    const double* z = I.noise_z + ((traj * I.k_cap + c.t) * (unsigned long long)(I.n_real - 1) + (c.r - 1)) * 6;
+    double zd[6];
+    const double* z = zd;
+    if (I.noise_device) {
+      const unsigned long long key = I.traj_key ? I.traj_key[traj] : I.traj_key_base + traj;
+      noise::normals6(I.noise_seed, key, c.t, c.r, zd);
+    } else {
+      z = I.noise_z + ((traj * I.k_cap + c.t) * (unsigned long long)(I.n_real - 1) + (c.r - 1)) * 6;
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const unsigned long long o = c.base + c.idx[k];
@@ -760,6 +767,22 @@ k_selftest_division(unsigned long long n_per_thread, unsigned long long seed, un
   if (bad) atomicAdd(mismatches, bad);
 }
 
+// outfit_hip_device_normals: the generator's output in the noise_z layout
+__global__ void __launch_bounds__(256)
+k_device_normals(unsigned long long seed, const unsigned long long* traj_key, unsigned long long key_base,
+                 unsigned long long n_traj, unsigned k_cap, unsigned n_noise, double* out) {
+  const unsigned long long id = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long per_traj = (unsigned long long)k_cap * n_noise;
+  if (id >= n_traj * per_traj) return;
+  const unsigned long long traj = id / per_traj;
+  const unsigned within = (unsigned)(id % per_traj);
+  const unsigned t = within / n_noise, r = within % n_noise + 1;
+  double z[6];
+  noise::normals6(seed, traj_key ? traj_key[traj] : key_base + traj, t, r, z);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) out[id * 6 + k] = z[k];
+}
+
 // Self-test of the shared-reciprocal Aberth sweep against the plain divisions: same return code and the same
 // bits in all 8 iterates, on random sparse octics x^8 + c6 x^6 + c3 x^3 + c0 (the sign pattern and size of the
 // Gauss polynomial, gauss.rs:585-614, plus arbitrary signs). out[0] = polynomials that differ, out[1] = guard trips.
@@ -836,6 +859,15 @@ k_selftest_crmath(unsigned long long n_per_thread, unsigned long long seed, unsi
 // ------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------
+hipError_t launch_device_normals(unsigned long long seed, const unsigned long long* traj_key,
+                                 unsigned long long key_base, unsigned long long n_traj, unsigned k_cap,
+                                 unsigned n_noise, double* out, hipStream_t s) {
+  const unsigned long long n = n_traj * k_cap * n_noise;
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_device_normals, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, seed, traj_key, key_base,
+                     n_traj, k_cap, n_noise, out);
+  return hipGetLastError();
+}
 hipError_t launch_selftest_aberth(unsigned long long n_threads, unsigned long long n_per_thread,
                                   unsigned long long seed, unsigned long long* d_out, hipStream_t s) {
   const unsigned grid = (unsigned)((n_threads + 255) / 256);
