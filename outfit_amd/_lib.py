@@ -39,6 +39,15 @@ def lib():
         raise NativeLibraryError(
             f"{LIB_PATH} is missing: build it with `make -C {CSRC}` "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch ships its own libamdhip64 and cannot enumerate the GPU once the
+    # system copy has been initialised by this library (observed: "No HIP GPUs are available"). When torch is
+    # already imported, let it load its runtime first; the loader then resolves ours to the same SONAME.
+    import sys
+    if "torch" in sys.modules:
+        try:
+            sys.modules["torch"].cuda.is_available()
+        except Exception:  # torch without GPU support: nothing to order
+            pass
     try:
         L = C.CDLL(LIB_PATH)
     except OSError as e:  # e.g. libamdhip64 not found

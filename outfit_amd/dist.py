@@ -106,6 +106,7 @@ def fit_lsq_distributed(batch, ephem, iod_params, diff_cor_config, dist, device_
     elif compute is None:
         from .api import IODSession
         dev = torch.device("cuda", device_index)
+        torch.cuda.current_stream(dev)  # torch's HIP runtime first (see _lib.lib)
         s = IODSession(sub, ephem, iod_params, device=device_index)
         stream = torch.cuda.current_stream(dev).cuda_stream
         if sub_init is None or (sub_init["status"] != 0).any():
