@@ -39,6 +39,38 @@ def test_struct_layouts_match_the_header():
     assert np.dtype(_abi.RESULT_DTYPE).itemsize == 96
 
 
+def test_ctypes_mirror_matches_the_compiled_header(tmp_path):
+    """sizeof / offsetof of every struct of include/outfit_hip.h as the C compiler lays them out, against the
+    ctypes mirror the tests and bench.py go through."""
+    import subprocess
+    src = tmp_path / "layout.c"
+    probes = [("outfit_iod_params_t", "IODParamsC", ["max_triplets", "gap_max", "aberth_eps", "root_imag_eps"]),
+              ("outfit_obs_batch_t", "ObsBatchC", ["noise_z", "noise_source", "noise_seed", "traj_key", "traj_key_base"]),
+              ("outfit_ephem_t", "EphemC", ["ncoef", "nsub", "n_blocks", "coef"]),
+              ("outfit_gauss_result_t", "GaussResultC", ["attempts", "epoch", "elem", "rms"]),
+              ("outfit_diffcor_config_t", "DiffCorConfigC", ["max_stagnation_iterations", "propagator",
+                                                             "eccentricity_limit", "free_elements"]),
+              ("outfit_lsq_result_t", "LsqResultC", ["total_newton_iterations", "epoch", "covariance", "iod"]),
+              ("outfit_obs_fit_t", "ObsFitC", ["chi", "selection"]),
+              ("outfit_de_header_t", "DeHeaderC", ["ipt", "numde", "ncon", "recsize", "n_blocks"])]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{ROOT}/include/outfit_hip.h"', "int main(void) {"]
+    for cname, _, fields in probes:
+        lines.append(f'  printf("{cname} %zu", sizeof({cname}));')
+        for f in fields:
+            lines.append(f'  printf(" %zu", offsetof({cname}, {f}));')
+        lines.append('  printf("\\n");')
+    lines += ["  return 0;", "}"]
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    for line, (cname, pyname, fields) in zip(out, probes):
+        got = [int(x) for x in line.split()[1:]]
+        cls = getattr(_abi, pyname)
+        want = [C.sizeof(cls)] + [getattr(cls, f).offset for f in fields]
+        assert got == want, (cname, got, want)
+
+
 def test_params_default_matches_reference_defaults(L):
     """IODParams::default() (mod.rs:308-344), and product == oracle restatement."""
     p = outfit_amd.IODParams()
