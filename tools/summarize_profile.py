@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, name = sys.argv[1], sys.argv[2]
 n_obj = int(sys.argv[3]) if len(sys.argv) > 3 else 100000
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
-LAUNCHES_PER_STEP = {"k_gauss_roots": 4, "k_triplet_select_lds": 4, "k_triplet_select": 4}
+LAUNCHES_PER_STEP = {"k_gauss_roots": 4, "k_triplet_select_lds": 4, "k_triplet_select": 4, "k_observer_prepass": 2}
 
 
 def short(k):
@@ -71,8 +71,8 @@ for k in kernels:
 out = os.path.join(ROOT, "profiles", f"{name}_rocprof_summary.md")
 with open(out, "w") as f:
     f.write(f"# {name} profile — bench.py ({n_obj} objects/step, 1x MI355X), rocprofv3; commands in tools/profile_gpu.sh\n\n")
-    f.write("Kernels on the session's second stream (k_triplet_select_lds, k_gauss_correct) run concurrently with the\n"
-            "main-stream kernels named in DESIGN.md §3. k_diffcor is the differential-correction stage measured after the\n"
+    f.write("Kernels on the session's side streams (k_triplet_select_lds, k_observer_prepass, k_gauss_correct) run\n"
+            "concurrently with the main-stream kernels named in DESIGN.md §3 (their durations include waiting for free CUs). k_diffcor is the differential-correction stage measured after the\n"
             "headline region (bench.py `fit_lsq`).\n\n")
     f.write("## rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline\n```\n")
     f.write(open(stats).read())
