@@ -234,6 +234,21 @@ int    orc_fit_lsq(const outfit_iod_params_t *ip, const outfit_diffcor_config_t 
                    const outfit_gauss_result_t *initial, int n_threads, outfit_lsq_result_t *out,
                    outfit_obs_fit_t *obs_fit);
 
+/* ---- observer-position pre-pass: earthrot.c ------------------------------ */
+typedef struct { int kind; /* 0 Equm, 1 Equt, 2 Eclm */ int j2000; double date; } orc_ref_system;
+double orc_obleq(double tjm);
+void   orc_nutn80(double tjm, double *dpsi_arcsec, double *deps_arcsec);
+void   orc_rotmt(double alpha, int k, double m[3][3]);
+void   orc_rnut80(double tjm, double m[3][3]);
+double orc_equequ(double tjm);
+void   orc_prec(double tjm, double m[3][3]);
+int    orc_rotpn(const orc_ref_system *src, const orc_ref_system *dst, double rot[3][3]);
+double orc_gmst(double tjm);
+void   orc_pvobs(double tt, double tut, const double dxbf[3], double out[3]);
+void   orc_helio_position(const double earth_equ[3], const double geo_ecl[3], double out[3]);
+int    orc_observer_prepass(const outfit_ephem_t *eph, double tt, double tut, const double dxbf[3],
+                            double geo_ecl[3], double helio_equ[3]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,10 @@ M63 = (C.c_double * 3) * 6
 M66 = (C.c_double * 6) * 6
 
 
+class RefSystem(C.Structure):
+    _fields_ = [("kind", C.c_int), ("j2000", C.c_int), ("date", C.c_double)]
+
+
 class ObsEquation(C.Structure):
     _fields_ = [("d_ra", D6), ("d_dec", D6), ("residual_ra", C.c_double), ("residual_dec", C.c_double),
                 ("weight_ra", C.c_double), ("weight_dec", C.c_double), ("weight_cross", C.c_double),
@@ -163,6 +167,20 @@ def lib():
         L.orc_run_differential_correction.argtypes = [C.POINTER(Equinoctial), _dp, _dp, _dp, _dp, C.c_size_t,
                                                       C.POINTER(ObsFit), C.POINTER(DiffCorConfigC),
                                                       C.POINTER(DiffCorOutput)]
+        L.orc_obleq.restype = C.c_double
+        L.orc_obleq.argtypes = [C.c_double]
+        L.orc_nutn80.argtypes = [C.c_double, _dp, _dp]
+        L.orc_rnut80.argtypes = [C.c_double, M33]
+        L.orc_equequ.restype = C.c_double
+        L.orc_equequ.argtypes = [C.c_double]
+        L.orc_prec.argtypes = [C.c_double, M33]
+        L.orc_rotmt.argtypes = [C.c_double, C.c_int, M33]
+        L.orc_rotpn.argtypes = [C.POINTER(RefSystem), C.POINTER(RefSystem), M33]
+        L.orc_gmst.restype = C.c_double
+        L.orc_gmst.argtypes = [C.c_double]
+        L.orc_pvobs.argtypes = [C.c_double, C.c_double, D3, D3]
+        L.orc_helio_position.argtypes = [D3, D3, D3]
+        L.orc_observer_prepass.argtypes = [C.POINTER(EphemC), C.c_double, C.c_double, D3, D3, D3]
         L.orc_fit_lsq.argtypes = [C.POINTER(IODParamsC), C.POINTER(DiffCorConfigC), C.POINTER(ObsBatchC),
                                   C.POINTER(EphemC), C.POINTER(GaussResultC), C.c_int,
                                   C.POINTER(LsqResultC), C.POINTER(ObsFitC)]
