@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define OUTFIT_HIP_ABI_VERSION 3
+#define OUTFIT_HIP_ABI_VERSION 4
 
 /* ---- whole-call return codes --------------------------------------------- */
 #define OUTFIT_OK                 0
@@ -122,6 +122,12 @@ typedef struct outfit_obs_batch {
   const uint64_t *traj_key;      /* NULL or one key per trajectory (TrajId::stable_hash(),
                                     obs_dataset_api.rs:285); NULL => traj_key_base + index          */
   uint64_t        traj_key_base;
+  /* -- observer positions on the device (needs `ephem`) --
+   * When both are given, obs_helio_equ and obs_geo_ecl are ignored (may be NULL) and what
+   * OutfitCache::build would have put there (Observer::pvobs + helio_position,
+   * observer_extension.rs:180-237) is evaluated on the device. */
+  const double   *obs_body_fixed; /* 3/obs, AU: Observer::earth_fixed_position (observer_extension.rs:156-170)   */
+  const double   *mjd_ut1;        /* per obs: `epoch.to_ut1(provider).to_mjd_tai_days()` (observer_extension.rs:191-192) */
 } outfit_obs_batch_t;
 #define OUTFIT_NOISE_HOST   0
 #define OUTFIT_NOISE_DEVICE 1
@@ -350,6 +356,13 @@ int  outfit_hip_ephem_header(const outfit_ephem_file_t *e, outfit_de_header_t *h
 /* `view->coef` points into the handle and stays valid until outfit_hip_ephem_close. */
 int  outfit_hip_ephem_view(const outfit_ephem_file_t *e, outfit_ephem_t *view);
 void outfit_hip_ephem_close(outfit_ephem_file_t *e);
+
+/* Observer::pvobs + helio_position for n observations: geocentric position in the ecliptic
+ * J2000 frame and heliocentric position in the equatorial J2000 frame, AU, 3 doubles per observation each —
+ * the two vectors OutfitCache::build stores (cache/observer_centric_cache.rs:80-110). */
+int outfit_hip_observer_positions(const outfit_ephem_t *ephem, uint64_t n, const double *mjd_tt,
+                                  const double *mjd_ut1, const double *obs_body_fixed /* 3n */,
+                                  double *geo_ecl /* 3n */, double *helio_equ /* 3n */);
 
 /* The standard normals the device generator yields for OUTFIT_NOISE_DEVICE, in the layout of `noise_z`
  * (n_traj * max_triplets * n_noise * 6 doubles): what a host needs to replay a device-noise run through

@@ -93,12 +93,17 @@ struct Observation {
   double mjd_tt, ra, dec, ra_error, dec_error;
   double helio_equ[3];  // cache.get_helio_position
   double geo_ecl[3];    // cache.get_observer_geocentric_position
+  // ABI v4: with ObsDataset::positions_on_device the two vectors above are ignored and the library runs the
+  // observer pre-pass itself (Observer::pvobs / helio_position, src/observer_extension.rs:180-237) from these:
+  double body_fixed[3] = {0, 0, 0};  // Observer::earth_fixed_position, AU
+  double mjd_ut1 = 0;                // the observation epoch on the UT1 scale
 };
 
 class ObsDataset {
   std::map<TrajId, std::vector<Observation>> traj_;
 
  public:
+  bool positions_on_device = false;  // hand over (body_fixed, mjd_ut1) instead of cached observer positions
   void push(const TrajId& id, const Observation& o) { traj_[id].push_back(o); }
   std::size_t n_trajectories() const { return traj_.size(); }
   const std::map<TrajId, std::vector<Observation>>& trajectories() const { return traj_; }
@@ -194,18 +199,21 @@ class FitIOD {
   struct Flat {
     std::vector<TrajId> ids;
     std::vector<std::uint64_t> off;
-    std::vector<double> t, ra, dec, sra, sdec, helio, geo;
+    std::vector<double> t, ra, dec, sra, sdec, helio, geo, fixed, ut1;
+    bool on_device = false;
     outfit_obs_batch_t batch() const {
       outfit_obs_batch_t b{};
       b.n_traj = ids.size(); b.traj_offset = off.data();
       b.mjd_tt = t.data(); b.ra = ra.data(); b.dec = dec.data(); b.sigma_ra = sra.data(); b.sigma_dec = sdec.data();
-      b.obs_helio_equ = helio.data(); b.obs_geo_ecl = geo.data();
+      if (on_device) { b.obs_body_fixed = fixed.data(); b.mjd_ut1 = ut1.data(); }
+      else { b.obs_helio_equ = helio.data(); b.obs_geo_ecl = geo.data(); }
       return b;
     }
   };
   // materialize_trajectory + sort by mjd_tt (fit_single_traj, obs_dataset_api.rs:218-223; stable like sort_by)
   static Flat flatten(const ObsDataset& ds) {
     Flat f;
+    f.on_device = ds.positions_on_device;
     for (const auto& [id, obs_in] : ds.trajectories()) {
       std::vector<Observation> obs = obs_in;
       std::stable_sort(obs.begin(), obs.end(), [](const Observation& a, const Observation& b) { return a.mjd_tt < b.mjd_tt; });
@@ -216,6 +224,8 @@ class FitIOD {
         f.sra.push_back(o.ra_error); f.sdec.push_back(o.dec_error);
         f.helio.insert(f.helio.end(), o.helio_equ, o.helio_equ + 3);
         f.geo.insert(f.geo.end(), o.geo_ecl, o.geo_ecl + 3);
+        f.fixed.insert(f.fixed.end(), o.body_fixed, o.body_fixed + 3);
+        f.ut1.push_back(o.mjd_ut1);
       }
     }
     f.off.push_back(f.t.size());

@@ -203,3 +203,17 @@ int orc_observer_prepass(const outfit_ephem_t *eph, double tt, double tut, const
   orc_helio_position(earth, geo_ecl, helio_equ);
   return 0;
 }
+
+/* the pre-pass over a batch, in the layout of outfit_hip_observer_positions (the checker of that entry point) */
+int orc_observer_positions(const outfit_ephem_t *eph, uint64_t n, const double *tt, const double *tut,
+                           const double *dxbf, double *geo_ecl, double *helio_equ) {
+  int rc = 0;
+  for (uint64_t o = 0; o < n; ++o) {
+    int r = orc_observer_prepass(eph, tt[o], tut[o], dxbf + 3 * o, geo_ecl + 3 * o, helio_equ + 3 * o);
+    if (r) {
+      rc = r;
+      for (int k = 0; k < 3; ++k) helio_equ[3 * o + k] = NAN;
+    }
+  }
+  return rc;
+}

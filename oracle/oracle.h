@@ -248,6 +248,8 @@ void   orc_pvobs(double tt, double tut, const double dxbf[3], double out[3]);
 void   orc_helio_position(const double earth_equ[3], const double geo_ecl[3], double out[3]);
 int    orc_observer_prepass(const outfit_ephem_t *eph, double tt, double tut, const double dxbf[3],
                             double geo_ecl[3], double helio_equ[3]);
+int    orc_observer_positions(const outfit_ephem_t *eph, uint64_t n, const double *tt, const double *tut,
+                              const double *dxbf, double *geo_ecl, double *helio_equ);
 
 #ifdef __cplusplus
 }

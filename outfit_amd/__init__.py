@@ -6,7 +6,7 @@ hand-written HIP kernels for gfx950 behind a C ABI (include/outfit_hip.h).
 """
 from .api import (  # noqa: F401
     DifferentialCorrection, DifferentialCorrectionConfig, EquinoctialElements, fit_lsq, fit_lsq_records,
-    device_normals, lsq_record_to_result, Ephemeris, EphemerisFileError, GaussResult, IODGauss, IODParams, IODParamsBuilder, IODSession, InvalidBatch,
+    device_normals, observer_positions, lsq_record_to_result, Ephemeris, EphemerisFileError, GaussResult, IODGauss, IODParams, IODParamsBuilder, IODSession, InvalidBatch,
     InvalidConversion, InvalidIODParameter, InvalidOrbit, NoFeasibleTriplets, NoViableOrbit, ObsBatch,
     OrbitalElements, OutfitError, fit_full_iod, fit_full_iod_records, fit_iod, propagate_universal,
 )

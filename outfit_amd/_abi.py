@@ -7,7 +7,7 @@ src/initial_orbit_determination/obs_dataset_api.rs:145-296).
 """
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 OUTFIT_OK = 0
 OUTFIT_ERR_INVALID_PARAM = -1
@@ -84,6 +84,8 @@ class ObsBatchC(C.Structure):
         ("noise_seed", C.c_uint64),
         ("traj_key", C.POINTER(C.c_uint64)),
         ("traj_key_base", C.c_uint64),
+        ("obs_body_fixed", _dp),
+        ("mjd_ut1", _dp),
     ]
 
 

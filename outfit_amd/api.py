@@ -207,11 +207,15 @@ class ObsBatch:
     `traj_ids` are the caller's trajectory identifiers (the keys of `FullOrbitResult`)."""
 
     def __init__(self, traj_offset, mjd_tt, ra, dec, sigma_ra, sigma_dec, obs_helio_equ,
-                 obs_geo_ecl=None, noise_z=None, traj_ids=None, noise_seed=None, traj_key=None, traj_key_base=0):
+                 obs_geo_ecl=None, noise_z=None, traj_ids=None, noise_seed=None, traj_key=None, traj_key_base=0,
+                 obs_body_fixed=None, mjd_ut1=None):
         self.traj_offset = np.ascontiguousarray(traj_offset, dtype=np.uint64)
         self.mjd_tt, self.ra, self.dec = _f64(mjd_tt), _f64(ra), _f64(dec)
         self.sigma_ra, self.sigma_dec = _f64(sigma_ra), _f64(sigma_dec)
-        self.obs_helio_equ = _f64(obs_helio_equ)
+        self.obs_helio_equ = None if obs_helio_equ is None else _f64(obs_helio_equ)
+        # device-side observer positions (row n2): Earth-fixed site vectors + UT1 epochs instead of the two cached vectors
+        self.obs_body_fixed = None if obs_body_fixed is None else _f64(obs_body_fixed)
+        self.mjd_ut1 = None if mjd_ut1 is None else _f64(mjd_ut1)
         self.obs_geo_ecl = None if obs_geo_ecl is None else _f64(obs_geo_ecl)
         self.noise_z = None if noise_z is None else _f64(noise_z)
         # device-side draws (device/noise.hpp): noise_seed set => OUTFIT_NOISE_DEVICE, keyed per trajectory
@@ -222,7 +226,12 @@ class ObsBatch:
         self.traj_ids = list(range(self.n_traj)) if traj_ids is None else list(traj_ids)
 
     @classmethod
-    def from_dict(cls, d, with_geo=True):
+    def from_dict(cls, d, with_geo=True, device_geometry=False):
+        """`device_geometry=True` hands over the sites (obs_body_fixed + mjd_ut1) instead of observer positions:
+        the library then runs the observer pre-pass itself (row n2)."""
+        if device_geometry:
+            return cls(d["traj_offset"], d["mjd_tt"], d["ra"], d["dec"], d["sigma_ra"], d["sigma_dec"], None, None,
+                       d.get("noise_z"), obs_body_fixed=d["obs_body_fixed"], mjd_ut1=d["mjd_ut1"])
         return cls(d["traj_offset"], d["mjd_tt"], d["ra"], d["dec"], d["sigma_ra"], d["sigma_dec"],
                    d["obs_helio_equ"], d.get("obs_geo_ecl") if with_geo else None, d.get("noise_z"))
 
@@ -232,7 +241,10 @@ class ObsBatch:
         geo = None if self.obs_geo_ecl is None else self.obs_geo_ecl[3 * o0:3 * o1]
         return ObsBatch(self.traj_offset[t0:t1 + 1] - np.uint64(o0), self.mjd_tt[o0:o1], self.ra[o0:o1],
                         self.dec[o0:o1], self.sigma_ra[o0:o1], self.sigma_dec[o0:o1],
-                        self.obs_helio_equ[3 * o0:3 * o1], geo, None, self.traj_ids[t0:t1],
+                        None if self.obs_helio_equ is None else self.obs_helio_equ[3 * o0:3 * o1], geo, None,
+                        self.traj_ids[t0:t1],
+                        obs_body_fixed=None if self.obs_body_fixed is None else self.obs_body_fixed[3 * o0:3 * o1],
+                        mjd_ut1=None if self.mjd_ut1 is None else self.mjd_ut1[o0:o1],
                         noise_seed=self.noise_seed,
                         traj_key=None if self.traj_key is None else self.traj_key[t0:t1],
                         traj_key_base=self.traj_key_base + (0 if self.traj_key is not None else t0))
@@ -241,8 +253,9 @@ class ObsBatch:
         b = ObsBatchC()
         b.n_traj = self.n_traj
         b.traj_offset = self.traj_offset.ctypes.data_as(C.POINTER(C.c_uint64))
-        for k in ("mjd_tt", "ra", "dec", "sigma_ra", "sigma_dec", "obs_helio_equ"):
-            setattr(b, k, getattr(self, k).ctypes.data_as(_dp))
+        for k in ("mjd_tt", "ra", "dec", "sigma_ra", "sigma_dec", "obs_helio_equ", "obs_body_fixed", "mjd_ut1"):
+            if getattr(self, k) is not None:
+                setattr(b, k, getattr(self, k).ctypes.data_as(_dp))
         if self.obs_geo_ecl is not None:
             b.obs_geo_ecl = self.obs_geo_ecl.ctypes.data_as(_dp)
         if self.noise_z is not None:
@@ -537,6 +550,20 @@ def _session_lsq_results(self):
 
 IODSession.run_lsq = _session_run_lsq
 IODSession.lsq_results = _session_lsq_results
+
+
+def observer_positions(ephem, mjd_tt, mjd_ut1, obs_body_fixed):
+    """`outfit_hip_observer_positions`: what `OutfitCache::build` stores per observation (Observer::pvobs and
+    helio_position, observer_extension.rs:180-237): (geocentric ecliptic J2000 [n,3], heliocentric equatorial J2000 [n,3])."""
+    tt, ut1, fx = _f64(mjd_tt), _f64(mjd_ut1), _f64(obs_body_fixed).reshape(-1)
+    n = tt.shape[0]
+    geo, hel = np.empty(3 * n), np.empty(3 * n)
+    ec = ephem.as_c()
+    rc = lib().outfit_hip_observer_positions(C.byref(ec), n, tt.ctypes.data_as(_dp), ut1.ctypes.data_as(_dp),
+                                             fx.ctypes.data_as(_dp), geo.ctypes.data_as(_dp), hel.ctypes.data_as(_dp))
+    if rc != 0:
+        _raise_rc(rc)
+    return geo.reshape(n, 3), hel.reshape(n, 3)
 
 
 def device_normals(noise_seed, n_traj, max_triplets, n_noise, traj_key=None, traj_key_base=0):

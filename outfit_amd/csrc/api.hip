@@ -182,7 +182,11 @@ int check_batch(const outfit_iod_params_t* params, const outfit_obs_batch_t* b, 
       return fail(OUTFIT_ERR_INVALID_BATCH, "a trajectory has 2^21 or more observations");
   }
   const uint64_t n_obs = b->traj_offset[b->n_traj] - o0;
-  if (n_obs > 0 && (!b->mjd_tt || !b->ra || !b->dec || !b->sigma_ra || !b->sigma_dec || !b->obs_helio_equ))
+  const bool device_geometry = b->obs_body_fixed != nullptr || b->mjd_ut1 != nullptr;
+  if (device_geometry && (!b->obs_body_fixed || !b->mjd_ut1 || !eph))
+    return fail(OUTFIT_ERR_INVALID_BATCH, "obs_body_fixed, mjd_ut1 and an ephemeris are needed together");
+  if (n_obs > 0 && (!b->mjd_tt || !b->ra || !b->dec || !b->sigma_ra || !b->sigma_dec ||
+                    (!b->obs_helio_equ && !device_geometry)))
     return fail(OUTFIT_ERR_INVALID_BATCH, "an observation array is NULL");
   if (b->noise_source != OUTFIT_NOISE_HOST && b->noise_source != OUTFIT_NOISE_DEVICE)
     return fail(OUTFIT_ERR_INVALID_BATCH, "noise_source must be OUTFIT_NOISE_HOST or OUTFIT_NOISE_DEVICE");
@@ -233,7 +237,7 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
   s->k_cap = params->max_triplets;
   s->cand_per_traj = s->k_cap * s->n_real;
   s->has_ephem = eph != nullptr;
-  s->has_geo = b->obs_geo_ecl != nullptr;
+  s->has_geo = b->obs_geo_ecl != nullptr || (b->obs_body_fixed && b->mjd_ut1 && eph);
 
   // rebased offsets
   std::vector<unsigned long long> off(s->n_traj + 1, 0ull);
@@ -245,11 +249,14 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
   TRY_RC(upload(s->dec, n ? b->dec + o0 : nullptr, n));
   TRY_RC(upload(s->sra, n ? b->sigma_ra + o0 : nullptr, n));
   TRY_RC(upload(s->sdec, n ? b->sigma_dec + o0 : nullptr, n));
-  TRY_RC(upload(s->helio, n ? b->obs_helio_equ + 3 * o0 : nullptr, 3 * n));
+  const bool device_geometry = b->obs_body_fixed && b->mjd_ut1 && eph;
+  if (device_geometry) HIP_TRY(s->helio.alloc(3 * n));
+  else TRY_RC(upload(s->helio, n ? b->obs_helio_equ + 3 * o0 : nullptr, 3 * n));
   HIP_TRY(s->cos_dec.alloc(n));
   for (int b = 0; b < 2; ++b) HIP_TRY(s->unit[b].alloc(3 * n));  // double-buffered: written ahead on k0_stream
   if (s->has_ephem && s->has_geo) {
-    TRY_RC(upload(s->geo, n ? b->obs_geo_ecl + 3 * o0 : nullptr, 3 * n));
+    if (device_geometry) HIP_TRY(s->geo.alloc(3 * n));
+    else TRY_RC(upload(s->geo, n ? b->obs_geo_ecl + 3 * o0 : nullptr, 3 * n));
     HIP_TRY(s->obs_pos.alloc(3 * n));
     unsigned per_block = 0;
     for (int k = 0; k < 3; ++k) {
@@ -281,6 +288,20 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
     if (!(std::fabs(b->ra[o0 + i]) <= 1.0e3) || !std::isfinite(b->dec[o0 + i])) { s->ra_bounded = false; break; }
   HIP_TRY(s->error_flag.alloc(1));
   HIP_TRY(hipMemset(s->error_flag.p, 0, sizeof(int)));
+  if (device_geometry && n) {
+    // row n2: what OutfitCache::build computes per observation, once per session (inputs are resident)
+    DevBuf<double> ut1, fixed;
+    TRY_RC(upload(ut1, b->mjd_ut1 + o0, n));
+    TRY_RC(upload(fixed, b->obs_body_fixed + 3 * o0, 3 * n));
+    outfit::GeometryArgs ga{};
+    ga.n_obs = s->n_obs; ga.mjd_tt = s->mjd.p; ga.mjd_ut1 = ut1.p; ga.body_fixed = fixed.p; ga.T = s->table;
+    ga.geo_ecl = s->geo.p; ga.helio_equ = s->helio.p; ga.error_flag = s->error_flag.p;
+    hipError_t e = outfit::launch_observer_geometry(ga, s->own_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->own_stream);
+    ut1.release();
+    fixed.release();
+    if (e != hipSuccess) return fail(OUTFIT_ERR_HIP, hipGetErrorString(e));
+  }
 
   // chunking: bound the candidate scratch (256 B per candidate) and the heap scratch
   uint64_t chunk = 131072;
@@ -825,6 +846,56 @@ int outfit_hip_fit_lsq(const outfit_iod_params_t* params, const outfit_diffcor_c
     g_last_error = keep;
     return r;
   });
+}
+
+int outfit_hip_observer_positions(const outfit_ephem_t* eph, uint64_t n, const double* mjd_tt, const double* mjd_ut1,
+                                  const double* body_fixed, double* geo_ecl, double* helio_equ) {
+  if (n == 0) return OUTFIT_OK;
+  if (!eph || !mjd_tt || !mjd_ut1 || !body_fixed || !geo_ecl || !helio_equ)
+    return fail(OUTFIT_ERR_INVALID_BATCH, "NULL argument");
+  if (!eph->coef || eph->n_blocks == 0 || !(eph->block_days > 0.0))
+    return fail(OUTFIT_ERR_INVALID_BATCH, "ephemeris table is empty");
+  for (int k = 0; k < 3; ++k)
+    if (eph->ncoef[k] < 2 || eph->ncoef[k] > 32 || eph->nsub[k] < 1)
+      return fail(OUTFIT_ERR_INVALID_BATCH, "ephemeris ncoef must be in [2,32] and nsub >= 1");
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+    return fail(OUTFIT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+  DevBuf<double> tt, ut1, fx, geo, hel, coef;
+  DevBuf<int> flag;
+  outfit::GeometryArgs ga{};
+  unsigned per_block = 0;
+  for (int k = 0; k < 3; ++k) {
+    ga.T.ncoef[k] = eph->ncoef[k]; ga.T.nsub[k] = eph->nsub[k]; ga.T.off[k] = per_block;
+    per_block += 3u * eph->ncoef[k] * eph->nsub[k];
+  }
+  ga.T.per_block = per_block; ga.T.jd_start = eph->jd_start; ga.T.jd_end = eph->jd_end;
+  ga.T.block_days = eph->block_days; ga.T.emrat = eph->emrat; ga.T.n_blocks = eph->n_blocks;
+  auto cleanup = [&]() { tt.release(); ut1.release(); fx.release(); geo.release(); hel.release(); coef.release(); flag.release(); };
+  int rc = upload(tt, mjd_tt, (size_t)n);
+  if (rc == OUTFIT_OK) rc = upload(ut1, mjd_ut1, (size_t)n);
+  if (rc == OUTFIT_OK) rc = upload(fx, body_fixed, (size_t)(3 * n));
+  if (rc == OUTFIT_OK) rc = upload(coef, eph->coef, (size_t)eph->n_blocks * per_block);
+  hipError_t e = hipSuccess;
+  if (rc == OUTFIT_OK) {
+    e = geo.alloc((size_t)(3 * n));
+    if (e == hipSuccess) e = hel.alloc((size_t)(3 * n));
+    if (e == hipSuccess) e = flag.alloc(1);
+    if (e == hipSuccess) e = hipMemset(flag.p, 0, sizeof(int));
+    ga.n_obs = n; ga.mjd_tt = tt.p; ga.mjd_ut1 = ut1.p; ga.body_fixed = fx.p; ga.T.coef = coef.p;
+    ga.geo_ecl = geo.p; ga.helio_equ = hel.p; ga.error_flag = flag.p;
+    if (e == hipSuccess) e = outfit::launch_observer_geometry(ga, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    int f = 0;
+    if (e == hipSuccess) e = hipMemcpy(&f, flag.p, sizeof f, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(geo_ecl, geo.p, (size_t)(3 * n) * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(helio_equ, hel.p, (size_t)(3 * n) * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && f) { cleanup(); return fail(OUTFIT_ERR_EPHEM_RANGE, "an observation epoch lies outside the ephemeris table"); }
+  }
+  cleanup();
+  if (rc != OUTFIT_OK) return rc;
+  if (e != hipSuccess) return fail(OUTFIT_ERR_HIP, hipGetErrorString(e));
+  return OUTFIT_OK;
 }
 
 int outfit_hip_device_normals(uint64_t noise_seed, const uint64_t* traj_key, uint64_t traj_key_base, uint64_t n_traj,

@@ -66,6 +66,14 @@ struct PrepassArgs {
   int* error_flag;
 };
 
+struct GeometryArgs {
+  unsigned long long n_obs;
+  const double *mjd_tt, *mjd_ut1, *body_fixed;  // body_fixed: 3 per observation, AU, Earth-fixed
+  EphemTable T;
+  double *geo_ecl, *helio_equ;                  // 3 per observation each
+  int* error_flag;
+};
+
 // Inputs every candidate-level kernel needs to find its triplet
 struct CandidateIndex {
   unsigned long long n_cand, traj0;
@@ -166,6 +174,7 @@ hipError_t launch_orbit_rms(const RmsArgs& a, bool slow_list, hipStream_t s);
 hipError_t launch_select_best(const SelectArgs& a, hipStream_t s);
 constexpr unsigned kDiffcorMaxGroup = 8;  // lanes that may share one trajectory in k_diffcor
 hipError_t launch_diffcor(const DiffCorArgs& a, unsigned group, hipStream_t s);
+hipError_t launch_observer_geometry(const GeometryArgs& a, hipStream_t s);
 hipError_t launch_device_normals(unsigned long long seed, const unsigned long long* traj_key,
                                  unsigned long long key_base, unsigned long long n_traj, unsigned k_cap,
                                  unsigned n_noise, double* out, hipStream_t s);

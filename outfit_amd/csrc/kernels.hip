@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include "kernels.h"
 #include "device/ephem.hpp"
+#include "device/earthrot.hpp"
 #include "device/gauss.hpp"
 #include "device/orbit.hpp"
 #include "device/triplets.hpp"
@@ -767,6 +768,23 @@ k_selftest_division(unsigned long long n_per_thread, unsigned long long seed, un
   if (bad) atomicAdd(mismatches, bad);
 }
 
+// Row n2: observer geocentric (ecliptic J2000) and heliocentric (equatorial J2000) positions from the
+// Earth-fixed site vector and the two time scales, one lane per observation (pvobs + helio_position).
+__global__ void __launch_bounds__(256)
+k_observer_geometry(GeometryArgs a) {
+  const unsigned long long o = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= a.n_obs) return;
+  const double tt = a.mjd_tt[o];
+  const Vec3 geo = erot::pvobs(tt, a.mjd_ut1[o], {a.body_fixed[3 * o], a.body_fixed[3 * o + 1], a.body_fixed[3 * o + 2]});
+  a.geo_ecl[3 * o] = geo.x; a.geo_ecl[3 * o + 1] = geo.y; a.geo_ecl[3 * o + 2] = geo.z;
+  unsigned long long nr;
+  double tau;
+  Vec3 h = {nan(""), nan(""), nan("")};
+  if (record_index(a.T, tt, nr, tau)) h = erot::helio_position(earth_from_block(a.T, a.T.coef + nr * a.T.per_block, tau), geo);
+  else atomicExch(a.error_flag, 1);
+  a.helio_equ[3 * o] = h.x; a.helio_equ[3 * o + 1] = h.y; a.helio_equ[3 * o + 2] = h.z;
+}
+
 // outfit_hip_device_normals: the generator's output in the noise_z layout
 __global__ void __launch_bounds__(256)
 k_device_normals(unsigned long long seed, const unsigned long long* traj_key, unsigned long long key_base,
@@ -859,6 +877,11 @@ k_selftest_crmath(unsigned long long n_per_thread, unsigned long long seed, unsi
 // ------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------
+hipError_t launch_observer_geometry(const GeometryArgs& a, hipStream_t s) {
+  if (a.n_obs == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_observer_geometry, dim3((unsigned)((a.n_obs + 255) / 256)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
 hipError_t launch_device_normals(unsigned long long seed, const unsigned long long* traj_key,
                                  unsigned long long key_base, unsigned long long n_traj, unsigned k_cap,
                                  unsigned n_noise, double* out, hipStream_t s) {

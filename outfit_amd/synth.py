@@ -255,6 +255,37 @@ def make_dataset(n_obj, seed=DEFAULT_SEED, ephem=None, topocentric=False, n_nigh
     }
 
 
+# (longitude deg east, rho cos phi', rho sin phi') — MPC-style parallax constants of a few real sites
+SITES = np.array([
+    [203.74409, 0.936241, 0.351543],   # Haleakala
+    [289.26345, 0.864981, -0.500958],  # Cerro Pachon
+    [243.14022, 0.836325, 0.546877],   # Palomar
+    [6.92124, 0.723655, 0.687873],     # Caussols
+    [149.06119, 0.855632, -0.516198],  # Siding Spring
+])
+ERAU = 6378.137 / AU_KM  # Earth radius in AU (reference constants.rs:61-67)
+
+
+def add_sites(ds, seed=DEFAULT_SEED + 7, tt_minus_ut1=69.184 - 0.02):
+    """Give every observation of `ds` an observing site and a UT1 epoch — the inputs of the device pre-pass
+    (outfit_obs_batch_t.obs_body_fixed / .mjd_ut1) instead of precomputed observer positions.
+
+    One site per trajectory; the body-fixed vector is [rho cos phi' cos lon, rho cos phi' sin lon, rho sin phi']
+    x Earth radius in AU — `Observer::earth_fixed_position` of the reference's observer dependency; its value for
+    Haleakala is pinned by src/cache/observer_centric_cache.rs:241-261 and reproduced by SITES[0] to 4 digits. UT1 = TT - const
+    (the reference goes through hifitime's UT1 provider; any epoch pair is a valid input here)."""
+    n_traj = int(ds["n_traj"])
+    rng = SplitMix64(seed)
+    site = np.minimum((rng.uniform(n_traj) * len(SITES)).astype(np.int64), len(SITES) - 1)
+    lon = np.deg2rad(SITES[site, 0])
+    bf = ERAU * np.stack([SITES[site, 1] * np.cos(lon), SITES[site, 1] * np.sin(lon), SITES[site, 2]], axis=-1)
+    counts = np.diff(ds["traj_offset"]).astype(np.int64)
+    out = dict(ds)
+    out["obs_body_fixed"] = np.ascontiguousarray(np.repeat(bf, counts, axis=0).reshape(-1))
+    out["mjd_ut1"] = ds["mjd_tt"] - tt_minus_ut1 / 86400.0
+    return out
+
+
 def dataset_sha256(ds):
     h = hashlib.sha256()
     for k in ("traj_offset", "mjd_tt", "ra", "dec", "sigma_ra", "sigma_dec", "obs_helio_equ", "obs_geo_ecl"):

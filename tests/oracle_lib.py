@@ -181,6 +181,7 @@ def lib():
         L.orc_pvobs.argtypes = [C.c_double, C.c_double, D3, D3]
         L.orc_helio_position.argtypes = [D3, D3, D3]
         L.orc_observer_prepass.argtypes = [C.POINTER(EphemC), C.c_double, C.c_double, D3, D3, D3]
+        L.orc_observer_positions.argtypes = [C.POINTER(EphemC), C.c_uint64] + [_dp] * 5
         L.orc_fit_lsq.argtypes = [C.POINTER(IODParamsC), C.POINTER(DiffCorConfigC), C.POINTER(ObsBatchC),
                                   C.POINTER(EphemC), C.POINTER(GaussResultC), C.c_int,
                                   C.POINTER(LsqResultC), C.POINTER(ObsFitC)]
@@ -237,6 +238,18 @@ def fit_full_iod(params, batch_c, ephem_c=None, n_threads=1, hoist=0):
                                 n_threads, hoist, out)
     arr = np.frombuffer(out, dtype=RESULT_DTYPE).copy()
     return rc, arr
+
+
+def observer_positions(ephem_c, mjd_tt, mjd_ut1, body_fixed):
+    """(rc, geo_ecl [n,3], helio_equ [n,3]) — the observer pre-pass of OutfitCache::build over a batch."""
+    tt = np.ascontiguousarray(mjd_tt, dtype=np.float64)
+    ut = np.ascontiguousarray(mjd_ut1, dtype=np.float64)
+    fx = np.ascontiguousarray(body_fixed, dtype=np.float64).reshape(-1)
+    n = tt.shape[0]
+    geo, hel = np.empty(3 * n), np.empty(3 * n)
+    rc = lib().orc_observer_positions(C.byref(ephem_c), n, tt.ctypes.data_as(_dp), ut.ctypes.data_as(_dp),
+                                      fx.ctypes.data_as(_dp), geo.ctypes.data_as(_dp), hel.ctypes.data_as(_dp))
+    return rc, geo.reshape(n, 3), hel.reshape(n, 3)
 
 
 def default_diffcor_config():
