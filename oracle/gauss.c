@@ -10,6 +10,8 @@
 #include <string.h>
 #include "oracle.h"
 
+uint64_t orc_dbg_aberth_sweeps[64]; /* histogram of Aberth sweeps per candidate (debug counter) */
+
 #define VLIGHT_AU (ORC_VLIGHT / ORC_AU * ORC_SECONDS_PER_DAY) /* constants.rs:79 */
 
 static inline double dot3(const double a[3], const double b[3]) {
@@ -245,7 +247,9 @@ int orc_prelim_orbit_all(const orc_gauss_obs *g, const outfit_iod_params_t *ip,
   if (orc_descartes_upper_bound(c0, c3, c6, 0.0) == 0) return OUTFIT_CAUSE_GAUSS_NO_ROOTS_FOUND;
 
   double re[8], im[8];
-  int st = orc_aberth9(poly, ip->aberth_max_iter, ip->aberth_eps, re, im, NULL);
+  uint32_t sweeps = 0;
+  int st = orc_aberth9(poly, ip->aberth_max_iter, ip->aberth_eps, re, im, &sweeps);
+  __atomic_fetch_add(&orc_dbg_aberth_sweeps[sweeps < 63 ? sweeps : 63], 1, __ATOMIC_RELAXED); /* work-distribution study */
   if (st == ORC_ABERTH_FAILED) return OUTFIT_CAUSE_POLYNOMIAL_ROOT_FINDING_FAILED;
   uint64_t max_sol = ip->max_tested_solutions;
   int n = 0;

@@ -133,11 +133,20 @@ int orc_to_equinoctial(const orc_elements *el, orc_equinoctial *eq) {
 
 /* equinoctial_element.rs:326-348 with roots 0.0.8 find_root_newton_raphson and
  * SimpleConvergency{eps: 100*EPSILON, max_iter: 25} restated. */
+uint64_t orc_dbg_kepler_evals[32]; /* histogram of f evaluations per solve (work-distribution study) */
+static int solve_kepler_equation_counted(const orc_equinoctial *eq, double lambda1, double varpi, double *F, int *evals);
 int orc_solve_kepler_equation(const orc_equinoctial *eq, double lambda1, double varpi, double *F) {
+  int evals = 0;
+  int rc = solve_kepler_equation_counted(eq, lambda1, varpi, F, &evals);
+  __atomic_fetch_add(&orc_dbg_kepler_evals[evals < 31 ? evals : 31], 1, __ATOMIC_RELAXED);
+  return rc;
+}
+static int solve_kepler_equation_counted(const orc_equinoctial *eq, double lambda1, double varpi, double *F, int *evals) {
   const double eps = ORC_EPS * 1e2;
   double x = ORC_PI + varpi;
   int iter = 0;
   for (;;) {
+    *evals += 1;
     double f = x - eq->k * sin(x) + eq->h * cos(x) - lambda1;
     double d = 1.0 - eq->k * cos(x) - eq->h * sin(x);
     if (fabs(f) < eps) { *F = x; return 0; }

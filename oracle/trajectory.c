@@ -82,6 +82,7 @@ void orc_select_rms_interval(const double *mjd, size_t n_obs, const uint32_t idx
 
 /* debug counters: residual terms evaluated with the reference's pruning vs without it */
 uint64_t orc_dbg_rms_terms = 0, orc_dbg_rms_terms_full = 0;
+const double *orc_dbg_initial_best = 0; /* pruning study: a per-trajectory starting bound */
 
 typedef struct {
   const outfit_iod_params_t *ip;
@@ -157,7 +158,7 @@ void orc_estimate_best_orbit(const outfit_iod_params_t *ip, const outfit_obs_bat
     }
   }
 
-  double best_rms = INFINITY;
+  double best_rms = orc_dbg_initial_best ? orc_dbg_initial_best[traj] : INFINITY; /* study hook, NULL in normal use */
   int have_best = 0, last_error = 0;
   orc_gauss_result best;
   uint32_t attempts = 0, best_t = 0, best_r = 0;
