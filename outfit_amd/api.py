@@ -198,6 +198,7 @@ class Ephemeris:
             e.nsub[i] = self.nsub[i]
         e.n_blocks = self.n_blocks
         e.coef = self.coef.ctypes.data_as(_dp)
+        e._owner = self  # the struct holds bare pointers: keep the arrays alive as long as it lives
         return e
 
 
@@ -266,6 +267,7 @@ class ObsBatch:
         if self.traj_key is not None:
             b.traj_key = self.traj_key.ctypes.data_as(C.POINTER(C.c_uint64))
         b.traj_key_base = self.traj_key_base
+        b._owner = self  # as above (a temporary `batch.slice(..).as_c()` must not dangle)
         return b
 
 
