@@ -384,8 +384,15 @@ int outfit_hip_selftest_aberth(uint64_t n_polys, uint64_t seed, uint64_t *counts
 /* Device self-test of the correctly-rounded sin/cos/acos (outfit_amd/csrc/device/crmath.hpp): the fast
  * path (table + rounding test) against the full double-double evaluation on n_args pseudo-random
  * arguments. counts[0] = sin/cos arguments with differing bits, counts[1] = acos arguments with differing
- * bits (both must be 0), counts[2] = sin/cos arguments that needed the full evaluation, counts[3] = 0. */
+ * bits (both must be 0), counts[2] = sin/cos arguments that needed the full evaluation, counts[3] = sinh/cosh/log
+ * (the hyperbolic cold start, prelim_hyperbolic.rs:45-141) and atan2 (orb_elem.rs:58-226) arguments with differing
+ * bits (must be 0). */
 int outfit_hip_selftest_crmath(uint64_t n_args, uint64_t seed, uint64_t *counts /* [4] */);
+/* The device's correctly-rounded functions on caller-given arguments (host arrays of n doubles), for checks
+ * against high-precision known answers: fn & 15 = 0 sin, 1 cos, 2 acos, 3 sinh, 4 cosh, 5 log (y > 1), 6 atan2
+ * (x then holds n pairs y, x);
+ * fn & 16 selects the full double-double evaluation instead of the table fast path + rounding test. */
+int outfit_hip_crmath_eval(int fn, uint64_t n, const double *x, double *out);
 const char *outfit_hip_last_error(void); /* thread-local, never NULL */
 int         outfit_hip_abi_version(void);
 int         outfit_hip_device_count(void);

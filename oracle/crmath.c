@@ -197,3 +197,18 @@ double orc_acos(double x) {
   dd y1 = dd_add_d(q, y0);
   return y1.hi;
 }
+
+/* ---- sinh / cosh / log of the hyperbolic cold start (prelim_hyperbolic.rs:45-141), correctly rounded ----
+ * Its value seeds the same chaotically sensitive correction loop as the elliptic start (measured: glibc's
+ * 1-ulp sinh/cosh against correctly-rounded ones moved a = 14 AU by 1.6e-9 on 1 object in 30 000), so it gets
+ * the same treatment as sin/cos: the correctly rounded value. Here through binary128 (libquadmath, error
+ * < 1 ulp of 113 bits, then ONE rounding to double: a wrong last bit needs the exact value within 2^-113
+ * relative of a rounding boundary) — an implementation independent of the device's double-double one
+ * (outfit_amd/csrc/device/crmath.hpp), both pinned by tests/golden/crmath_hyp_vectors.json (mpmath). */
+#include <quadmath.h>
+double orc_sinh(double x) { return orc_use_libm ? sinh(x) : (double)sinhq((__float128)x); }
+double orc_cosh(double x) { return orc_use_libm ? cosh(x) : (double)coshq((__float128)x); }
+double orc_log(double x) { return orc_use_libm ? log(x) : (double)logq((__float128)x); }
+/* atan2 of the state -> elements conversion (orb_elem.rs:58-226): a last-place difference of i or Omega is
+ * amplified ~a/r in a near-parabolic 1/a and ~1/e in omega, M of a near-circular orbit. */
+double orc_atan2(double y, double x) { return orc_use_libm ? atan2(y, x) : (double)atan2q((__float128)y, (__float128)x); }

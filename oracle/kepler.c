@@ -126,14 +126,14 @@ double orc_prelim_hyperbolic(const orc_kepler_params *p) {
   double a0 = -1.0 / p->alpha;
   double n = sqrt(p->mu) * sqrt(powi3(p->alpha));
   double c = (1.0 - p->r0 / a0) / p->e0;
-  double f0 = (c > 1.0) ? log(c + sqrt(powi2(c) - 1.0)) : 0.0;
+  double f0 = (c > 1.0) ? orc_log(c + sqrt(powi2(c) - 1.0)) : 0.0; /* log/sinh/cosh correctly rounded, crmath.c */
   if (p->sig0 < 0.0) f0 = -f0;
-  double m = (p->e0 * sinh(f0) - f0) + n * p->dt;
+  double m = (p->e0 * orc_sinh(f0) - f0) + n * p->dt;
   double f = 0.0;
   for (int i = 0; i < p->max_iter_prelim_kepuni; ++i) {
     if (fabs(f) < 15.0) {
-      double res = p->e0 * sinh(f) - f - m;
-      double der = p->e0 * cosh(f) - 1.0;
+      double res = p->e0 * orc_sinh(f) - f - m;
+      double der = p->e0 * orc_cosh(f) - 1.0;
       double step = -res / der;
       double cand = f + step;
       f = (f * cand < 0.0) ? f / 2.0 : cand;

@@ -49,6 +49,10 @@ void   orc_sincos(double x, double *s, double *c);
 double orc_sin(double x);
 double orc_cos(double x);
 double orc_acos(double x);
+double orc_sinh(double x); /* binary128 -> double: correctly rounded (hyperbolic cold start) */
+double orc_cosh(double x);
+double orc_log(double x);
+double orc_atan2(double y, double x);
 
 /* ---- kepler/ --------------------------------------------------------------- */
 typedef struct {

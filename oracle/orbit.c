@@ -20,12 +20,12 @@ void orc_ccek1(const double pos[3], const double vel[3], double epoch, orc_eleme
   double hn = sqrt(h2);
   double hu[3] = {h[0] / hn, h[1] / hn, h[2] / hn};
   double sin_i = sqrt(hu[0] * hu[0] + hu[1] * hu[1]);
-  double inc = wrap_0_2pi(atan2(sin_i, hu[2]));
+  double inc = wrap_0_2pi(orc_atan2(sin_i, hu[2]));
   double node;
   if (sin_i <= EPS_EQ) { inc = 0.0; node = 0.0; }
-  else node = wrap_0_2pi(atan2(hu[0], -hu[1]));
+  else node = wrap_0_2pi(orc_atan2(hu[0], -hu[1]));
 
-  double ci = cos(inc), si = sin(inc), cn = cos(node), sn = sin(node);
+  double ci = orc_cos(inc), si = orc_sin(inc), cn = orc_cos(node), sn = orc_sin(node); /* correctly rounded, crmath.c */
   /* M = Rx(i)^T * Rz(Om)^T ; Rx^T = [1 0 0;0 c s;0 -s c], Rz^T = [c s 0;-s c 0;0 0 1] */
   double M[3][3] = {{cn, sn, 0.0}, {ci * (-sn), ci * cn, si}, {(-si) * (-sn), (-si) * cn, ci}};
   double po[3], vo[3];
@@ -49,16 +49,16 @@ void orc_ccek1(const double pos[3], const double vel[3], double epoch, orc_eleme
     if (fabs(e - 1.0) < EPS_E) {
       parabolic = 1;
     } else {
-      double ea = atan2(esin, ecos);
-      double ma = wrap_0_2pi(ea - e * sin(ea));
-      double x1 = cos(ea) - e;
+      double ea = orc_atan2(esin, ecos);
+      double ma = wrap_0_2pi(ea - e * orc_sin(ea));
+      double x1 = orc_cos(ea) - e;
       double rd = sqrt(1.0 - e * e);
-      double x2 = rd * sin(ea);
+      double x2 = rd * orc_sin(ea);
       double nm = sqrt(x1 * x1 + x2 * x2);
       double x1n = x1 / nm, x2n = x2 / nm;
       double sp = x1n * po[1] - x2n * po[0];
       double cp = x1n * po[0] + x2n * po[1];
-      double argp = wrap_0_2pi(atan2(sp, cp));
+      double argp = wrap_0_2pi(orc_atan2(sp, cp));
       out->kind = OUTFIT_KIND_KEPLERIAN;
       out->e[0] = a; out->e[1] = e; out->e[2] = inc; out->e[3] = node; out->e[4] = argp;
       out->e[5] = ma;
@@ -70,14 +70,14 @@ void orc_ccek1(const double pos[3], const double vel[3], double epoch, orc_eleme
     double p = h2 / mu;
     double ecos = p / rad - 1.0;
     double esin = rv * p / (hn * rad);
-    double nu = atan2(esin, ecos);
+    double nu = orc_atan2(esin, ecos);
     double e = sqrt(ecos * ecos + esin * esin);
     if (fabs(e - 1.0) < EPS_E) {
       parabolic = 1;
     } else {
       out->kind = OUTFIT_KIND_COMETARY;
       out->e[0] = p / (1.0 + e); out->e[1] = e; out->e[2] = inc; out->e[3] = node;
-      out->e[4] = wrap_0_2pi(atan2(po[1], po[0]) - nu);
+      out->e[4] = wrap_0_2pi(orc_atan2(po[1], po[0]) - nu);
       out->e[5] = nu;
       return;
     }
@@ -86,10 +86,10 @@ void orc_ccek1(const double pos[3], const double vel[3], double epoch, orc_eleme
     double p = h2 / mu;
     double cnu = p / rad - 1.0;
     double snu = rv * p / (rad * hn);
-    double nu = atan2(snu, cnu);
+    double nu = orc_atan2(snu, cnu);
     out->kind = OUTFIT_KIND_COMETARY;
     out->e[0] = p / 2.0; out->e[1] = 1.0; out->e[2] = inc; out->e[3] = node;
-    out->e[4] = wrap_0_2pi(atan2(po[1], po[0]) - nu);
+    out->e[4] = wrap_0_2pi(orc_atan2(po[1], po[0]) - nu);
     out->e[5] = nu;
   }
 }

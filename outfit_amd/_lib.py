@@ -78,6 +78,7 @@ def lib():
         C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double,
         C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     L.outfit_hip_selftest_division.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.outfit_hip_crmath_eval.argtypes = [C.c_int, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.outfit_hip_selftest_crmath.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
     L.outfit_hip_selftest_aberth.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
     L.outfit_hip_observer_positions.argtypes = [C.POINTER(EphemC), C.c_uint64] + [C.POINTER(C.c_double)] * 5
@@ -106,7 +107,7 @@ EXPORTED_SYMBOLS = [
     "outfit_hip_session_device_results", "outfit_hip_session_kernel_times",
     "outfit_hip_session_set_profiling", "outfit_hip_session_destroy", "outfit_hip_propagate_universal",
     "outfit_hip_last_error", "outfit_hip_abi_version", "outfit_hip_device_count",
-    "outfit_hip_selftest_division", "outfit_hip_selftest_crmath", "outfit_hip_selftest_aberth", "outfit_hip_device_normals", "outfit_hip_observer_positions", "outfit_hip_diffcor_config_default", "outfit_hip_diffcor_config_validate",
+    "outfit_hip_selftest_division", "outfit_hip_selftest_crmath", "outfit_hip_crmath_eval", "outfit_hip_selftest_aberth", "outfit_hip_device_normals", "outfit_hip_observer_positions", "outfit_hip_diffcor_config_default", "outfit_hip_diffcor_config_validate",
     "outfit_hip_fit_lsq", "outfit_hip_session_run_lsq", "outfit_hip_session_lsq_results",
     "outfit_hip_ephem_open", "outfit_hip_ephem_header", "outfit_hip_ephem_view", "outfit_hip_ephem_close",
 ]

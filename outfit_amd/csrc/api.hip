@@ -964,6 +964,25 @@ int outfit_hip_selftest_crmath(uint64_t n_args, uint64_t seed, uint64_t* counts)
   return OUTFIT_OK;
 }
 
+int outfit_hip_crmath_eval(int fn, uint64_t n, const double* x, double* out) {
+  if ((fn & 15) > 6 || (fn & ~31)) return fail(OUTFIT_ERR_INVALID_PARAM, "fn: 0 sin, 1 cos, 2 acos, 3 sinh, 4 cosh, 5 log, 6 atan2 (+16: full evaluation)");
+  if (n && (!x || !out)) return fail(OUTFIT_ERR_INVALID_BATCH, "NULL argument");
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+    return fail(OUTFIT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+  if (n == 0) return OUTFIT_OK;
+  DevBuf<double> dx, dy;
+  TRY_RC(upload(dx, x, (size_t)n * ((fn & 15) == 6 ? 2 : 1)));
+  HIP_TRY(dy.alloc((size_t)n));
+  hipError_t e = outfit::launch_crmath_eval(fn, n, dx.p, dy.p, nullptr);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(out, dy.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+  dx.release();
+  dy.release();
+  if (e != hipSuccess) return fail(OUTFIT_ERR_HIP, hipGetErrorString(e));
+  return OUTFIT_OK;
+}
+
 int outfit_hip_selftest_division(uint64_t n_pairs, uint64_t seed, uint64_t* mismatches) {
   if (!mismatches) return fail(OUTFIT_ERR_INVALID_BATCH, "NULL argument");
   int n_dev = 0;

@@ -259,6 +259,206 @@ __device__ __forceinline__ double acos(double x) {
   return acos_slow(x);
 }
 
+// ---- exp in double-double, and from it correctly-rounded sinh / cosh / log -------------------------
+// Why: the hyperbolic cold start of the universal Kepler solve (prelim_hyperbolic.rs:45-141) evaluates
+// log, sinh and cosh, and its value enters the same chaotically sensitive correction loop as the elliptic
+// one (measured: glibc's 1-ulp sinh/cosh moved a = 14 AU by 1.6e-9 on 1 object in 30 000). Same remedy as
+// for sin/cos: the correctly rounded value, here and in the oracle (oracle/crmath.c, via binary128).
+//
+// x = k ln2 + j/128 + d, |d| <= 2^-8 (+ rounding slack): exp(x) = 2^k * T_j * exp(d), T_j a double-double table.
+struct ExpArg {
+  dd d;
+  int k, j;
+};
+__device__ __forceinline__ ExpArg exp_reduce(double x) {  // |x| < 2^10
+  const double kf = rint(x * kInvLn2);
+  dd r = {x, 0.0};
+  if (kf != 0.0) {
+    const double t = x - kf * kLn2_1;  // exact
+    const dd a = two_sum(t, -(kf * kLn2_2));
+    const dd b = two_sum(a.hi, -(kf * kLn2_3));
+    r = two_sum(b.hi, (a.lo + b.lo) - kf * kLn2_4);
+  }
+  const double jf = rint(r.hi * 128.0);
+  return {fast_two_sum(r.hi - jf * 0.0078125, r.lo), (int)kf, (int)jf};
+}
+// exp(+-(j/128 + d)) as double-double, unscaled (the caller applies 2^(+-k)); `err` = absolute error bound.
+// Fast: exp(d) = 1 + d.hi + qs, qs = d.lo (1 + d.hi) + d^2 (A(d^2) + d B(d^2)) in plain double (|qs| <= 2^-17):
+// the O(d) product with the table entry is exact (two_prod), the rest has relative size <= 2^-17, so the
+// result carries an absolute error < 2^-50 |qs| T (Horner roundings of qs, its product with T, one more
+// addition) + the table's own 2^-106 T; the Taylor remainder d^8/8! is below that for every d.
+__device__ __forceinline__ void exp_pair_fast(const ExpArg& a, dd& ep, dd& em, double& err_p, double& err_m) {
+  const double dh = a.d.hi, dl = a.d.lo, z = dh * dh;
+  const double A = 0.5 + z * (0.041666666666666664 + z * 0.001388888888888889);
+  const double B = 0.16666666666666666 + z * (0.008333333333333333 + z * 0.0001984126984126984);
+#pragma unroll
+  for (int sgn = 0; sgn < 2; ++sgn) {
+    const double h = sgn ? -dh : dh, l = sgn ? -dl : dl;
+    const double qs = (l + l * h) + z * (A + h * B);
+    const int idx = (sgn ? -a.j : a.j) + 45;
+    const double th = kExpTab[idx][0], tl = kExpTab[idx][1];
+    const dd pr = two_prod(th, h);
+    const double rest = (tl + pr.lo) + (th * qs + tl * (h + qs));
+    dd t = two_sum(th, pr.hi);
+    t.lo += rest;
+    const dd e = fast_two_sum(t.hi, t.lo);
+    const double bound = (0x1p-50 * fabs(qs) + 0x1p-103) * th;
+    if (sgn) { em = e; err_m = bound; } else { ep = e; err_p = bound; }
+  }
+}
+// Full double-double: exp(d) by Horner over 1/n!, n <= 13 (|d|^14/14! < 2^-148); relative error < 2^-100
+__device__ __forceinline__ dd exp_slow_dd(const ExpArg& a, bool negate) {
+  const dd d = negate ? neg(a.d) : a.d;
+  dd p = {kInvFact[13][0], kInvFact[13][1]};
+#pragma unroll
+  for (int n = 12; n >= 0; --n) p = add(mul(p, d), {kInvFact[n][0], kInvFact[n][1]});
+  const int idx = (negate ? -a.j : a.j) + 45;
+  return mul({kExpTab[idx][0], kExpTab[idx][1]}, p);
+}
+__device__ __forceinline__ dd scale2(dd v, int k) { return {ldexp(v.hi, k), ldexp(v.lo, k)}; }
+
+// |f| < 2^-3: sinh f = f + f z (1/6 + z (1/120 + ...)), cosh f = 1 + z (1/2 + z (1/24 + ...)), z = f^2
+__device__ __forceinline__ void sinhcosh_tiny(double f, dd& s, dd& c, double& err_s, double& err_c) {
+  const dd z = two_prod(f, f);
+  const double zh = z.hi;
+  const double rs = zh * (0.008333333333333333 + zh * (0.0001984126984126984 + zh * (2.7557319223985893e-06 + zh * (2.505210838544172e-08 + zh * (1.6059043836821613e-10 + zh * 7.647163731819816e-13)))));
+  const dd ps = fast_two_sum(kInvFact[3][0], kInvFact[3][1] + rs);
+  const dd v = mul(mul(z, ps), {f, 0.0});
+  dd t = two_sum(f, v.hi);
+  t.lo += v.lo;
+  s = fast_two_sum(t.hi, t.lo);
+  err_s = 0x1p-59 * fabs(v.hi);
+  const double rc = zh * (0.041666666666666664 + zh * (0.001388888888888889 + zh * (2.48015873015873e-05 + zh * (2.755731922398589e-07 + zh * (2.08767569878681e-09 + zh * 1.1470745597729725e-11)))));
+  const dd pc = fast_two_sum(0.5, rc);
+  const dd w = mul(z, pc);
+  t = two_sum(1.0, w.hi);
+  t.lo += w.lo;
+  c = fast_two_sum(t.hi, t.lo);
+  err_c = 0x1p-59 * fabs(w.hi);
+}
+__device__ __forceinline__ void sinhcosh_tiny_slow(double f, dd& s, dd& c) {
+  const dd z = two_prod(f, f);
+  dd ps = {kInvFact[19][0], kInvFact[19][1]}, pc = {kInvFact[20][0], kInvFact[20][1]};
+#pragma unroll
+  for (int n = 8; n >= 0; --n) ps = add(mul(ps, z), {kInvFact[2 * n + 1][0], kInvFact[2 * n + 1][1]});
+#pragma unroll
+  for (int n = 9; n >= 0; --n) pc = add(mul(pc, z), {kInvFact[2 * n][0], kInvFact[2 * n][1]});
+  s = mul(ps, {f, 0.0});
+  c = pc;
+}
+
+// correctly-rounded sinh and cosh (both at once: they share exp(+-|f|))
+__device__ __forceinline__ void sinhcosh_slow(double f, double& s, double& c) {
+  const double a = fabs(f);
+  if (!(a <= 700.0)) { s = ::sinh(f); c = ::cosh(f); return; }
+  if (f == 0.0) { s = f; c = 1.0; return; }  // keeps the sign of -0
+  dd sd, cd;
+  if (a < 0.125) {
+    sinhcosh_tiny_slow(f, sd, cd);
+    s = sd.hi; c = cd.hi;
+    return;
+  }
+  const ExpArg r = exp_reduce(a);
+  const dd ep = scale2(exp_slow_dd(r, false), r.k - 1), em = scale2(exp_slow_dd(r, true), -r.k - 1);
+  sd = add(ep, neg(em));
+  cd = add(ep, em);
+  s = copysign(sd.hi, f);
+  c = cd.hi;
+}
+__device__ __forceinline__ void sinhcosh(double f, double& s, double& c) {
+  const double a = fabs(f);
+  if (!(a <= 700.0)) { s = ::sinh(f); c = ::cosh(f); return; }
+  if (f == 0.0) { s = f; c = 1.0; return; }  // keeps the sign of -0
+  dd sd, cd;
+  double es, ec;
+  if (a < 0.125) {
+    sinhcosh_tiny(f, sd, cd, es, ec);
+    if (rounds_safely(sd, es) && rounds_safely(cd, ec)) { s = sd.hi; c = cd.hi; return; }
+    sinhcosh_slow(f, s, c);
+    return;
+  }
+  const ExpArg r = exp_reduce(a);
+  dd ep, em;
+  double bp, bm;
+  exp_pair_fast(r, ep, em, bp, bm);
+  ep = scale2(ep, r.k - 1);   // e^a / 2
+  em = scale2(em, -r.k - 1);  // e^-a / 2
+  const double e = ldexp(bp, r.k - 1) + ldexp(bm, -r.k - 1) + 0x1p-103 * ep.hi;
+  sd = add(ep, neg(em));
+  cd = add(ep, em);
+  if (rounds_safely(sd, e) && rounds_safely(cd, e)) { s = copysign(sd.hi, f); c = cd.hi; return; }
+  sinhcosh_slow(f, s, c);
+}
+
+// correctly-rounded log for finite y > 1 (the call site's domain; anything else goes to the platform log):
+// one Newton step on exp(l) = y from the platform's value l0, log y = l0 + log1p(y e^-l0 - 1)
+__device__ __forceinline__ double log_slow(double y) {
+  if (!(y > 1.0 && y < 1.0e300)) return ::log(y);
+  const double l0 = ::log(y);
+  const ExpArg r = exp_reduce(-l0);
+  const dd e = scale2(exp_slow_dd(r, false), r.k);
+  const dd t = add_d(mul(e, {y, 0.0}), -1.0);             // y e^-l0 - 1, a few ulp of 1
+  const dd corr = add(t, mul(mul(t, t), {-0.5, 0.0}));   // log1p(t) = t - t^2/2 + O(t^3), |t|^3 < 2^-150
+  return add_d(corr, l0).hi;
+}
+__device__ __forceinline__ double log(double y) {
+  if (!(y > 1.0 && y < 1.0e300)) return ::log(y);
+  const double l0 = ::log(y);
+  const ExpArg r = exp_reduce(-l0);
+  dd e, unused;
+  double be, bu;
+  exp_pair_fast(r, e, unused, be, bu);
+  e = scale2(e, r.k);
+  be = ldexp(be, r.k);
+  const dd p = two_prod(y, e.hi);
+  const double t = (p.hi - 1.0) + (p.lo + y * e.lo);  // p.hi - 1 is exact (p.hi within 2^-40 of 1)
+  const double corr = t - 0.5 * t * t;
+  const dd l = fast_two_sum(l0, corr);
+  const double err = y * be + 0x1p-51 * fabs(t) + 0x1p-105;  // + rounding of t and corr, log1p's t^3/3 (|t| < 2^-40)
+  if (fabs(t) < 0x1p-40 && rounds_safely(l, err)) return l.hi;
+  return log_slow(y);
+}
+
+// correctly-rounded atan2 for finite, non-zero y and x of ordinary magnitude (everything else — zeros,
+// infinities, NaN, |x| or |y| outside [2^-400, 2^400] — goes to the platform function, whose results there
+// are exact constants or irrelevant): one Newton step from the platform's value t0,
+//   atan2(y, x) = t0 + atan((y cos t0 - x sin t0) / (x cos t0 + y sin t0)),
+// the numerator from double-double sin/cos with exact leading products (they cancel to a few ulp).
+// Used where a last-place difference of an angle is amplified before it is returned: the rotations of the
+// state -> elements conversion (orb_elem.rs:58-226; near-parabolic a and near-circular omega, M).
+__device__ __forceinline__ bool atan2_ordinary(double y, double x) {
+  const double ay = fabs(y), ax = fabs(x);
+  return ay > 0x1p-400 && ay < 0x1p400 && ax > 0x1p-400 && ax < 0x1p400;
+}
+__device__ __forceinline__ double atan2_slow(double y, double x) {
+  if (!atan2_ordinary(y, x)) return ::atan2(y, x);
+  const double t0 = ::atan2(y, x);
+  dd s, c;
+  sincos_dd(t0, s, c);
+  const dd num = add(mul(c, {y, 0.0}), neg(mul(s, {x, 0.0})));
+  const dd den = add(mul(c, {x, 0.0}), mul(s, {y, 0.0}));
+  const dd q = div(num, den);  // tan(delta); delta - tan(delta) ~ delta^3 / 3 < 2^-150
+  return add_d(q, t0).hi;
+}
+__device__ __forceinline__ double atan2(double y, double x) {
+  if (!atan2_ordinary(y, x)) return ::atan2(y, x);
+  const double t0 = ::atan2(y, x);
+  int q;
+  const dd r = reduce_pio2(t0, q);
+  dd sr, cr, s, c;
+  sincos_fast_dd(r, sr, cr);
+  apply_quadrant(q, sr, cr, s, c);
+  const dd p1 = two_prod(y, c.hi), p2 = two_prod(x, s.hi);
+  const double num = (p1.hi - p2.hi) + ((p1.lo - p2.lo) + (y * c.lo - x * s.lo));
+  const double den = x * c.hi + y * s.hi;  // = hypot(x, y) up to rounding, > 0
+  const double delta = num / den;
+  const dd t = fast_two_sum(t0, delta);
+  // errors of sin/cos (2^-67 relative each) through the numerator, the quotient's and the sum's roundings
+  const double err = 0x1p-66 * (fabs(p1.hi) + fabs(p2.hi)) / den + 0x1p-51 * fabs(delta);
+  if (fabs(delta) < 0x1p-40 * fabs(t0) && rounds_safely(t, err)) return t.hi;
+  return atan2_slow(y, x);
+}
+
 // Aberth's initial-guess directions: theta_k = fma(2pi/8, k, (pi/2)/8), correctly rounded
 __device__ __forceinline__ void aberth_dir(int k, double& c, double& s) {
   constexpr double t[8][2] = {

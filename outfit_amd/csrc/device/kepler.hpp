@@ -160,14 +160,18 @@ __device__ __forceinline__ double prelim_hyperbolic(const KeplerProblem& p) {
   const double a0 = -1.0 / p.alpha;
   const double n = sqrt(kMu) * sqrt(p.alpha * p.alpha * p.alpha);
   const double c = (1.0 - p.r0 / a0) / p.e0;
-  double f0 = (c > 1.0) ? log(c + sqrt(c * c - 1.0)) : 0.0;
+  // log / sinh / cosh correctly rounded (crmath.hpp): this value seeds the chaotically sensitive loop
+  double f0 = (c > 1.0) ? crm::log(c + sqrt(c * c - 1.0)) : 0.0;
   if (p.sig0 < 0.0) f0 = -f0;
-  const double m = (p.e0 * sinh(f0) - f0) + n * p.dt;
+  double sh, ch;
+  crm::sinhcosh(f0, sh, ch);
+  const double m = (p.e0 * sh - f0) + n * p.dt;
   double f = 0.0;
   for (int i = 0; i < 20; ++i) {
     if (fabs(f) < 15.0) {
-      const double res = p.e0 * sinh(f) - f - m;
-      const double der = p.e0 * cosh(f) - 1.0;
+      crm::sinhcosh(f, sh, ch);
+      const double res = p.e0 * sh - f - m;
+      const double der = p.e0 * ch - 1.0;
       const double cand = f + (-res / der);
       f = (f * cand < 0.0) ? f / 2.0 : cand;
     } else {

@@ -835,7 +835,7 @@ k_selftest_aberth(unsigned long long n_per_thread, unsigned long long seed, unsi
 __global__ void __launch_bounds__(256)
 k_selftest_crmath(unsigned long long n_per_thread, unsigned long long seed, unsigned long long* out) {
   unsigned long long s = seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x + 1);
-  unsigned long long bad_sc = 0, bad_ac = 0, slow_sc = 0, slow_ac = 0;
+  unsigned long long bad_sc = 0, bad_ac = 0, slow_sc = 0, bad_hy = 0;
   for (unsigned long long it = 0; it < n_per_thread; ++it) {
     double x;
     const unsigned mode = (unsigned)(it & 7);
@@ -867,11 +867,68 @@ k_selftest_crmath(unsigned long long n_per_thread, unsigned long long seed, unsi
       const double a1 = crm::acos(y), a2 = crm::acos_slow(y);
       bad_ac += __double_as_longlong(a1) != __double_as_longlong(a2);
     }
+    // sinh / cosh / log (hyperbolic cold start): |f| < 15 as the call site guarantees, plus tiny and large arguments
+    double f;
+    if (mode < 3) f = (u - 0.5) * 30.0;
+    else if (mode == 3) f = (u - 0.5) * 0.5;                                     // around the 2^-3 switch
+    else if (mode == 4) f = random_double(s, 40) * 0x1p-20;
+    else if (mode == 5) f = (double)((long long)(u * 128.0) - 64) * 0.6931471805599453 + random_double(s, 12) * 0x1p-30;
+    else if (mode == 6) f = (double)((long long)(u * 4096.0) - 2048) * 0.0078125 + random_double(s, 12) * 0x1p-40;
+    else f = (u - 0.5) * 1400.0;
+    double h1, g1, h2, g2;
+    crm::sinhcosh(f, h1, g1);
+    crm::sinhcosh_slow(f, h2, g2);
+    bad_hy += (__double_as_longlong(h1) != __double_as_longlong(h2)) || (__double_as_longlong(g1) != __double_as_longlong(g2));
+    double yl;
+    if (mode < 3) yl = 1.0 + u * 50.0;
+    else if (mode == 3) yl = 1.0 + fabs(random_double(s, 30)) * 0x1p-10;        // just above 1 (c -> 1+)
+    else if (mode == 4) yl = exp(fabs(f));
+    else if (mode == 5) yl = 1.0 + fabs(random_double(s, 8));
+    else yl = fabs(random_double(s, 200)) + 1.0;
+    const double l1 = crm::log(yl), l2 = crm::log_slow(yl);
+    bad_hy += __double_as_longlong(l1) != __double_as_longlong(l2);
+    // atan2: all quadrants, near the axes (tiny ratios), unit-vector components
+    double ay, ax;
+    if (mode < 3) { ::sincos((u - 0.5) * 6.283185307179586, &ay, &ax); ax *= 1.0 + fabs(f); ay *= 1.0 + fabs(f); }
+    else if (mode == 3) { ay = random_double(s, 60) * 0x1p-30; ax = u - 0.5; }
+    else if (mode == 4) { ax = random_double(s, 60) * 0x1p-30; ay = u - 0.5; }
+    else { ay = random_double(s, 100); ax = random_double(s, 100); }
+    const double t1 = crm::atan2(ay, ax), t2 = crm::atan2_slow(ay, ax);
+    bad_hy += __double_as_longlong(t1) != __double_as_longlong(t2);
   }
   if (bad_sc) atomicAdd(out, bad_sc);
   if (bad_ac) atomicAdd(out + 1, bad_ac);
   if (slow_sc) atomicAdd(out + 2, slow_sc);
-  (void)slow_ac;
+  if (bad_hy) atomicAdd(out + 3, bad_hy);
+}
+
+// outfit_hip_crmath_eval: the device's correctly-rounded functions on given arguments (checked against
+// high-precision known answers by the tests). fn & 15: 0 sin, 1 cos, 2 acos, 3 sinh, 4 cosh, 5 log, 6 atan2 (x holds n pairs y, x); fn & 16: the
+// full double-double evaluation instead of Ziv's two steps.
+__global__ void __launch_bounds__(256)
+k_crmath_eval(int fn, unsigned long long n, const double* x, double* out) {
+  const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool slow = (fn & 16) != 0;
+  if ((fn & 15) == 6) {  // atan2 on pairs (y, x)
+    out[i] = slow ? crm::atan2_slow(x[2 * i], x[2 * i + 1]) : crm::atan2(x[2 * i], x[2 * i + 1]);
+    return;
+  }
+  const double v = x[i];
+  double a = 0.0, b = 0.0, r;
+  switch (fn & 15) {
+    case 0: case 1:
+      if (slow) crm::sincos_slow(v, a, b); else crm::sincos(v, a, b);
+      r = (fn & 15) == 0 ? a : b;
+      break;
+    case 2: r = slow ? crm::acos_slow(v) : crm::acos(v); break;
+    case 3: case 4:
+      if (slow) crm::sinhcosh_slow(v, a, b); else crm::sinhcosh(v, a, b);
+      r = (fn & 15) == 3 ? a : b;
+      break;
+    default: r = slow ? crm::log_slow(v) : crm::log(v); break;
+  }
+  out[i] = r;
 }
 
 // ------------------------------------------------------------------------------
@@ -901,6 +958,11 @@ hipError_t launch_selftest_crmath(unsigned long long n_threads, unsigned long lo
                                   unsigned long long seed, unsigned long long* d_out, hipStream_t s) {
   const unsigned grid = (unsigned)((n_threads + 255) / 256);
   hipLaunchKernelGGL(k_selftest_crmath, dim3(grid), dim3(256), 0, s, n_per_thread, seed, d_out);
+  return hipGetLastError();
+}
+hipError_t launch_crmath_eval(int fn, unsigned long long n, const double* x, double* out, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_crmath_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fn, n, x, out);
   return hipGetLastError();
 }
 hipError_t launch_selftest_division(unsigned long long n_threads, unsigned long long n_per_thread,

@@ -38,3 +38,83 @@ def test_glibc_is_almost_always_correctly_rounded():
     g = json.load(open(os.path.join(HERE, "golden", "crmath_vectors.json")))
     diff = sum(1 for xh, sh, _ in g["sincos"] if math.sin(float.fromhex(xh)) != float.fromhex(sh))
     assert diff <= 4
+
+
+def _hyp():
+    return json.load(open(os.path.join(HERE, "golden", "crmath_hyp_vectors.json")))
+
+
+def test_hyperbolic_functions_match_mpmath_vectors():
+    """orc_sinh / orc_cosh / orc_log (binary128 rounded once) == the correctly-rounded values, incl. the hard
+    cases within 2^-12 ulp of a rounding boundary (tools/gen_crmath_hyp_vectors.py)."""
+    import math
+    L = O.lib()
+    for f in ("orc_sinh", "orc_cosh", "orc_log"):
+        getattr(L, f).restype = C.c_double
+        getattr(L, f).argtypes = [C.c_double]
+    g = _hyp()
+    for xh, sh, ch in g["sinhcosh"] + g["sinhcosh_hard"]:
+        x = float.fromhex(xh)
+        s, c = L.orc_sinh(x), L.orc_cosh(x)
+        assert s == float.fromhex(sh) and math.copysign(1, s) == math.copysign(1, float.fromhex(sh)), x
+        assert c == float.fromhex(ch), x
+    for yh, lh in g["log"] + g["log_hard"]:
+        assert L.orc_log(float.fromhex(yh)) == float.fromhex(lh), yh
+    L.orc_atan2.restype = C.c_double
+    L.orc_atan2.argtypes = [C.c_double, C.c_double]
+    for yh, xh, ah in g["atan2"] + g["atan2_hard"]:
+        assert L.orc_atan2(float.fromhex(yh), float.fromhex(xh)) == float.fromhex(ah), (yh, xh)
+    n_a = sum(1 for yh, xh, ah in g["atan2"] if math.atan2(float.fromhex(yh), float.fromhex(xh)) != float.fromhex(ah))
+    print(f"glibc atan2 differs on {n_a} of {len(g['atan2'])}")
+    # glibc's own functions are NOT always correctly rounded here — the reason for the restatement
+    n_s = sum(1 for xh, sh, _ in g["sinhcosh"] if math.sinh(float.fromhex(xh)) != float.fromhex(sh))
+    n_c = sum(1 for xh, _, ch in g["sinhcosh"] if math.cosh(float.fromhex(xh)) != float.fromhex(ch))
+    print(f"glibc differs from the correctly rounded value on {n_s} sinh and {n_c} cosh of {len(g['sinhcosh'])} arguments")
+    assert n_s + n_c > 0
+
+
+# ---------------------------------------------------------------------------------- device twin (GPU)
+import numpy as np  # noqa: E402
+import pytest  # noqa: E402
+
+
+def _device_eval(fn, x):
+    from outfit_amd import _lib
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    dp = C.POINTER(C.c_double)
+    assert _lib.lib().outfit_hip_crmath_eval(fn, len(x), x.ctypes.data_as(dp), out.ctypes.data_as(dp)) == 0
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("slow", [0, 16])
+def test_device_crmath_matches_mpmath_vectors(slow):
+    """device/crmath.hpp on the same known answers, both the two-step (Ziv) evaluation and the full one."""
+    g = json.load(open(os.path.join(HERE, "golden", "crmath_vectors.json")))
+    x = np.array([float.fromhex(r[0]) for r in g["sincos"]])
+    assert np.array_equal(_device_eval(0 | slow, x), np.array([float.fromhex(r[1]) for r in g["sincos"]]))
+    assert np.array_equal(_device_eval(1 | slow, x), np.array([float.fromhex(r[2]) for r in g["sincos"]]))
+    y = np.array([float.fromhex(r[0]) for r in g["acos"]])
+    assert np.array_equal(_device_eval(2 | slow, y), np.array([float.fromhex(r[1]) for r in g["acos"]]))
+    h = _hyp()
+    rows = h["sinhcosh"] + h["sinhcosh_hard"]
+    f = np.array([float.fromhex(r[0]) for r in rows])
+    s, c = _device_eval(3 | slow, f), _device_eval(4 | slow, f)
+    es, ec = np.array([float.fromhex(r[1]) for r in rows]), np.array([float.fromhex(r[2]) for r in rows])
+    assert np.array_equal(s.view(np.uint64), es.view(np.uint64)), f[s.view(np.uint64) != es.view(np.uint64)][:5]
+    assert np.array_equal(c, ec), f[c != ec][:5]
+    rows = h["log"] + h["log_hard"]
+    yl = np.array([float.fromhex(r[0]) for r in rows])
+    el = np.array([float.fromhex(r[1]) for r in rows])
+    got = _device_eval(5 | slow, yl)
+    assert np.array_equal(got, el), yl[got != el][:5]
+    rows = h["atan2"] + h["atan2_hard"]
+    yx = np.array([[float.fromhex(r[0]), float.fromhex(r[1])] for r in rows])
+    ea = np.array([float.fromhex(r[2]) for r in rows])
+    out = np.empty(len(rows))
+    from outfit_amd import _lib
+    dp = C.POINTER(C.c_double)
+    flat = np.ascontiguousarray(yx.reshape(-1))
+    assert _lib.lib().outfit_hip_crmath_eval(6 | slow, len(rows), flat.ctypes.data_as(dp), out.ctypes.data_as(dp)) == 0
+    assert np.array_equal(out, ea), yx[out != ea][:5]

@@ -17,12 +17,27 @@ from outfit_amd import synth  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 20261004
+mode = sys.argv[3] if len(sys.argv) > 3 else "bench"   # bench | noise (IODParams::default(), host normals) | topo
 threads = len(os.sched_getaffinity(0))
 ed = synth.make_ephemeris()
-ds = synth.make_dataset(n, seed=seed, ephem=ed)
-batch = outfit_amd.ObsBatch.from_dict(ds)
+ds = synth.make_dataset(n, seed=seed, ephem=ed, topocentric=(mode == "topo"))
 ephem = outfit_amd.Ephemeris.from_dict(ed)
 params = synth.bench_params(outfit_amd.IODParams())
+stride = 0
+if mode == "noise":
+    params = outfit_amd.IODParams()
+    stride = params.max_triplets * params.n_noise_realizations * 6
+    ds["noise_z"] = synth.SplitMix64(seed + 1).normal(n * stride)
+batch = outfit_amd.ObsBatch.from_dict(ds)
+
+
+def sliced(i, j):
+    sub = batch.slice(i, j)
+    if stride:
+        sub.noise_z = batch.noise_z[i * stride:j * stride]
+    return sub
+
+
 cfg = outfit_amd.DifferentialCorrectionConfig()
 
 t = time.perf_counter()
@@ -36,7 +51,7 @@ ref = np.empty(n, dtype=got.dtype)
 step = 5000
 for i in range(0, n, step):  # in slices so that a progress line appears every few seconds
     j = min(n, i + step)
-    sub = batch.slice(i, j)  # keep the slice alive: as_c() holds bare pointers into its arrays
+    sub = sliced(i, j)
     rc, ref[i:j] = O.fit_full_iod(params.as_c(), sub.as_c(), ephem.as_c(), n_threads=threads, hoist=1)
     assert rc == 0
     print(f"oracle IOD {j}/{n} ({time.perf_counter() - t:.0f} s)", flush=True)
@@ -51,7 +66,7 @@ d = np.abs(got["elem"][ok] - ref["elem"][ok])
 d[:, 2:] = np.minimum(d[:, 2:], np.abs(2 * np.pi - d[:, 2:]))
 rms_rel = np.abs(got["rms"][ok] - ref["rms"][ok]) / np.maximum(1.0, ref["rms"][ok])
 out = {
-    "objects": n, "seed": seed, "oracle_threads": threads, "oracle_seconds": t_cpu, "gpu_seconds_incl_upload": t_gpu,
+    "objects": n, "seed": seed, "mode": mode, "oracle_threads": threads, "oracle_seconds": t_cpu, "gpu_seconds_incl_upload": t_gpu,
     "iod": {
         "orbits_in_oracle": int((ref["status"] == 0).sum()),
         "different_integer_outputs": int((~same).sum()),
@@ -71,7 +86,7 @@ t = time.perf_counter()
 lref = np.empty(n, dtype=lsq.dtype)
 for i in range(0, n, 4 * step):
     j = min(n, i + 4 * step)
-    sub = batch.slice(i, j)
+    sub = sliced(i, j)
     rc, lref[i:j], _ = O.fit_lsq(params.as_c(), cfg.as_c(), sub.as_c(), ephem.as_c(), got[i:j], n_threads=threads)
     assert rc == 0
     print(f"oracle LSQ {j}/{n} ({time.perf_counter() - t:.0f} s)", flush=True)
@@ -96,4 +111,4 @@ print(json.dumps(out["lsq"]), flush=True)
 bad = np.nonzero(~lsame)[0]
 np.savez_compressed(os.path.join(ROOT, "gpurun_out", "parity_at_scale_lsq.npz"), rows=bad, got=lsq[bad], ref=lref[bad])
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "parity_at_scale.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"parity_at_scale_{mode}.json"), "w"), indent=1)
