@@ -212,3 +212,16 @@ double orc_log(double x) { return orc_use_libm ? log(x) : (double)logq((__float1
 /* atan2 of the state -> elements conversion (orb_elem.rs:58-226): a last-place difference of i or Omega is
  * amplified ~a/r in a near-parabolic 1/a and ~1/e in omega, M of a near-circular orbit. */
 double orc_atan2(double y, double x) { return orc_use_libm ? atan2(y, x) : (double)atan2q((__float128)y, (__float128)x); }
+
+/* ---- scoped selection: the differential corrector evaluates ALL its elementary functions correctly rounded
+ * (its ill-conditioned normal equations amplify a last place up to 1e13 times; the device does the same and is
+ * then bit-identical), the per-observation residuals of the IOD's RMS stage keep the platform libm (2x10^6
+ * evaluations per 1000 objects; they move the RMS by <= 1e-9 relative, never the elements). orc_cr_scope is
+ * raised around the corrector (diffcor.c); orc_use_libm = 1 overrides everything to the platform libm. */
+__thread int orc_cr_scope = 0;
+static int scoped_cr(void) { return !orc_use_libm && orc_cr_scope > 0; }
+double orc_sin_s(double x) { return scoped_cr() ? orc_sin(x) : sin(x); }
+double orc_cos_s(double x) { return scoped_cr() ? orc_cos(x) : cos(x); }
+double orc_tan_s(double x) { return scoped_cr() ? (double)tanq((__float128)x) : tan(x); }
+double orc_atan2_s(double y, double x) { return scoped_cr() ? (double)atan2q((__float128)y, (__float128)x) : atan2(y, x); }
+double orc_hypot_s(double x, double y) { return scoped_cr() ? (double)hypotq((__float128)x, (__float128)y) : hypot(x, y); }

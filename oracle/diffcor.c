@@ -137,7 +137,7 @@ int orc_propagate_twobody_partials(const orc_equinoctial *eq, double t0, double 
   double lam = eq->lambda + n * (t1 - t0);
   double e2 = eq->h * eq->h + eq->k * eq->k;
   double varpi = 0.0;
-  if (e2 > ORC_EPS * 1e2) varpi = orc_principal_angle(atan2(eq->h, eq->k));
+  if (e2 > ORC_EPS * 1e2) varpi = orc_principal_angle(orc_atan2_s(eq->h, eq->k));
   lam = orc_principal_angle(lam);
   if (lam < varpi) lam += ORC_DPI;
   double F;
@@ -145,7 +145,7 @@ int orc_propagate_twobody_partials(const orc_equinoctial *eq, double t0, double 
 
   double beta = 1.0 / (1.0 + sqrt(1.0 - e2));
   double bet = beta * eq->h * eq->k;
-  double sf = sin(F), cf = cos(F);
+  double sf = orc_sin_s(F), cf = orc_cos_s(F);
   double xe = eq->a * ((1.0 - beta * (eq->h * eq->h)) * cf + bet * sf - eq->k);
   double ye = eq->a * ((1.0 - beta * (eq->k * eq->k)) * sf + bet * cf - eq->h);
   double u = 1.0 + eq->p * eq->p + eq->q * eq->q;
@@ -174,10 +174,10 @@ void orc_topocentric_radec_and_partials(const double ast_pos[3], const double as
   for (int i = 0; i < 3; ++i) cor[i] = rel[i] - lt * ast_vel[i];
   double x = cor[0], y = cor[1], z = cor[2];
   double rho = sqrt(dot3(cor, cor));
-  double rho_xy = hypot(x, y);
+  double rho_xy = orc_hypot_s(x, y);
   double rho_xy_sq = rho_xy * rho_xy;
-  *dec = atan2(z, rho_xy);
-  double a = fmod(atan2(y, x), ORC_DPI); /* rem_euclid(TAU) */
+  *dec = orc_atan2_s(z, rho_xy);
+  double a = fmod(orc_atan2_s(y, x), ORC_DPI); /* rem_euclid(TAU) */
   if (a < 0.0) a += ORC_DPI;
   *ra = a;
   double rho_sq = rho * rho;
@@ -568,7 +568,9 @@ void orc_differential_correction(const outfit_iod_params_t *ip, const outfit_dif
   el.epoch = out->iod.epoch;
   memcpy(el.e, out->iod.elem, sizeof el.e);
   orc_equinoctial eq;
+  orc_cr_scope += 1; /* from here on every elementary function is correctly rounded (crmath.c) */
   int ec = orc_to_equinoctial(&el, &eq);
+  orc_cr_scope -= 1;
   if (ec) { out->status = OUTFIT_LSQ_CONVERSION_ERROR; out->conv_error = ec; return; }
 
   orc_obs_fit *fit = (orc_obs_fit *)calloc(n ? n : 1, sizeof *fit);
@@ -587,8 +589,10 @@ void orc_differential_correction(const outfit_iod_params_t *ip, const outfit_dif
   }
   orc_diffcor_output dc;
   memset(&dc, 0, sizeof dc);
+  orc_cr_scope += 1;
   int rc = orc_run_differential_correction(&eq, b->mjd_tt + base, b->ra + base, b->dec + base, obs_pos,
                                            n, fit, cfg, &dc);
+  orc_cr_scope -= 1;
   out->total_newton_iterations = dc.total_newton_iterations;
   out->outer_passes = dc.outer_passes;
   out->epoch = eq.epoch;

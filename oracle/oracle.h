@@ -53,6 +53,12 @@ double orc_sinh(double x); /* binary128 -> double: correctly rounded (hyperbolic
 double orc_cosh(double x);
 double orc_log(double x);
 double orc_atan2(double y, double x);
+extern __thread int orc_cr_scope; /* > 0 inside the differential corrector: the *_s functions are correctly rounded */
+double orc_sin_s(double x);
+double orc_cos_s(double x);
+double orc_tan_s(double x);
+double orc_atan2_s(double y, double x);
+double orc_hypot_s(double x, double y);
 
 /* ---- kepler/ --------------------------------------------------------------- */
 typedef struct {

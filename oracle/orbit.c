@@ -98,11 +98,11 @@ void orc_ccek1(const double pos[3], const double vel[3], double epoch, orc_eleme
 static void from_kepler_internal(double epoch, double a, double e, double inc, double node,
                                  double argp, double ma, orc_equinoctial *eq) {
   double dig = node + argp;
-  eq->h = e * sin(dig);
-  eq->k = e * cos(dig);
-  double t = tan(inc / 2.0);
-  eq->p = t * sin(node);
-  eq->q = t * cos(node);
+  eq->h = e * orc_sin_s(dig);
+  eq->k = e * orc_cos_s(dig);
+  double t = orc_tan_s(inc / 2.0);
+  eq->p = t * orc_sin_s(node);
+  eq->q = t * orc_cos_s(node);
   eq->lambda = orc_principal_angle(dig + ma);
   eq->epoch = epoch;
   eq->a = a;
@@ -121,7 +121,7 @@ int orc_to_equinoctial(const orc_elements *el, orc_equinoctial *eq) {
   if (e <= 1.0) return OUTFIT_TRAJ_INVALID_ORBIT;
   const double EPSC = 1e-15;
   double s = sqrt((e - 1.0) / (e + 1.0));
-  double t = tan(0.5 * el->e[5]);
+  double t = orc_tan_s(0.5 * el->e[5]);
   double x = s * t;
   if (x < -1.0 + EPSC) x = -1.0 + EPSC;
   if (x > 1.0 - EPSC) x = 1.0 - EPSC;
@@ -147,8 +147,8 @@ static int solve_kepler_equation_counted(const orc_equinoctial *eq, double lambd
   int iter = 0;
   for (;;) {
     *evals += 1;
-    double f = x - eq->k * sin(x) + eq->h * cos(x) - lambda1;
-    double d = 1.0 - eq->k * cos(x) - eq->h * sin(x);
+    double f = x - eq->k * orc_sin_s(x) + eq->h * orc_cos_s(x) - lambda1;
+    double d = 1.0 - eq->k * orc_cos_s(x) - eq->h * orc_sin_s(x);
     if (fabs(f) < eps) { *F = x; return 0; }
     if (fabs(d) < eps) {
       if (iter == 0) { x = x + 1.0; iter = iter + 1; continue; }
@@ -170,7 +170,7 @@ int orc_propagate_twobody(const orc_equinoctial *eq, double t0, double t1, doubl
   double lam = eq->lambda + n * (t1 - t0);
   double e2 = eq->h * eq->h + eq->k * eq->k;
   double varpi = 0.0;
-  if (e2 > ORC_EPS * 1e2) varpi = orc_principal_angle(atan2(eq->h, eq->k));
+  if (e2 > ORC_EPS * 1e2) varpi = orc_principal_angle(orc_atan2_s(eq->h, eq->k));
   lam = orc_principal_angle(lam);
   if (lam < varpi) lam += ORC_DPI;
   double F;
@@ -178,7 +178,7 @@ int orc_propagate_twobody(const orc_equinoctial *eq, double t0, double t1, doubl
 
   double beta = 1.0 / (1.0 + sqrt(1.0 - e2));
   double bet = beta * eq->h * eq->k;
-  double sf = sin(F), cf = cos(F);
+  double sf = orc_sin_s(F), cf = orc_cos_s(F);
   double xe = eq->a * ((1.0 - beta * (eq->h * eq->h)) * cf + bet * sf - eq->k);
   double ye = eq->a * ((1.0 - beta * (eq->k * eq->k)) * sf + bet * cf - eq->h);
   double u = 1.0 + eq->p * eq->p + eq->q * eq->q;

@@ -459,6 +459,46 @@ __device__ __forceinline__ double atan2(double y, double x) {
   return atan2_slow(y, x);
 }
 
+// correctly-rounded tan for |x| < 2^20: double-double sin / cos and one double-double quotient
+__device__ __forceinline__ double tan_slow(double x) {
+  if (!(fabs(x) < 1048576.0)) return ::tan(x);
+  if (x == 0.0) return x;
+  dd s, c;
+  sincos_dd(x, s, c);
+  return div(s, c).hi;
+}
+__device__ __forceinline__ double tan(double x) {
+  if (!(fabs(x) < 1048576.0)) return ::tan(x);
+  if (x == 0.0) return x;
+  int q;
+  const dd r = reduce_pio2(x, q);
+  dd sr, cr;
+  sincos_fast_dd(r, sr, cr);
+  const dd num = (q & 1) ? neg(cr) : sr, den = (q & 1) ? sr : cr;  // tan(r + pi/2) = -cos r / sin r
+  const double t0 = num.hi / den.hi;
+  const dd p = two_prod(t0, den.hi);
+  const double rem = ((num.hi - p.hi) - p.lo) + (num.lo - t0 * den.lo);
+  const dd t = fast_two_sum(t0, rem / den.hi);
+  // 2^-67 relative from each of sin and cos, plus the roundings of the remainder and its quotient
+  if (rounds_safely(t, 0x1p-65 * fabs(t0))) return t.hi;
+  return tan_slow(x);
+}
+
+// correctly-rounded hypot for finite arguments of ordinary magnitude (else the platform function): x^2 + y^2
+// exactly as a double-double, its square root by one Newton correction of the IEEE sqrt of the high word.
+// (An exact tie — x^2 + y^2 the square of a 54-bit number — cannot be decided by an error bound; the nearest
+// candidate is returned.)
+__device__ __forceinline__ double hypot(double x, double y) {
+  const double ax = fabs(x), ay = fabs(y);
+  if (!(ax < 0x1p400 && ay < 0x1p400 && (ax > 0x1p-400 || ay > 0x1p-400))) return ::hypot(x, y);
+  const dd s = add(two_prod(x, x), two_prod(y, y));
+  const double r0 = sqrt(s.hi);
+  const dd p = two_prod(r0, r0);
+  const double e = ((s.hi - p.hi) - p.lo) + s.lo;
+  const dd r = fast_two_sum(r0, e / (2.0 * r0));
+  return r.hi;
+}
+
 // Aberth's initial-guess directions: theta_k = fma(2pi/8, k, (pi/2)/8), correctly rounded
 __device__ __forceinline__ void aberth_dir(int k, double& c, double& s) {
   constexpr double t[8][2] = {

@@ -143,17 +143,35 @@ struct Equinoctial {
   double epoch, a, h, k, p, q, lambda;
 };
 
+// Platform or correctly-rounded elementary functions, chosen per caller: the candidate RMS (K2c, 2x10^8
+// observation evaluations per step) keeps the platform functions — they move the RMS by <= 1e-9 relative, never the
+// returned elements; the differential corrector (ill-conditioned normal equations amplify a last place up to
+// 1e13 times) uses the correctly-rounded ones and is then bit-identical to the oracle.
+template <bool kCr> __device__ __forceinline__ void sincos_sel(double x, double& s, double& c) {
+  if constexpr (kCr) crm::sincos(x, s, c); else ::sincos(x, &s, &c);
+}
+template <bool kCr> __device__ __forceinline__ double atan2_sel(double y, double x) {
+  if constexpr (kCr) return crm::atan2(y, x); else return ::atan2(y, x);
+}
+template <bool kCr> __device__ __forceinline__ double tan_sel(double x) {
+  if constexpr (kCr) return crm::tan(x); else return ::tan(x);
+}
+template <bool kCr> __device__ __forceinline__ double hypot_sel(double x, double y) {
+  if constexpr (kCr) return crm::hypot(x, y); else return ::hypot(x, y);
+}
+
 // equinoctial_element.rs:285-313
+template <bool kCr = false>
 __device__ __forceinline__ Equinoctial from_kepler(double epoch, double a, double e, double inc, double node,
                                           double argp, double ma) {
   Equinoctial q;
   const double dig = node + argp;
   double sd, cd, sn, cn;
-  sincos(dig, &sd, &cd);
-  sincos(node, &sn, &cn);
+  sincos_sel<kCr>(dig, sd, cd);
+  sincos_sel<kCr>(node, sn, cn);
   q.h = e * sd;
   q.k = e * cd;
-  const double t = tan(inc / 2.0);
+  const double t = tan_sel<kCr>(inc / 2.0);
   q.p = t * sn;
   q.q = t * cn;
   q.lambda = principal_angle(dig + ma);
@@ -164,9 +182,10 @@ __device__ __forceinline__ Equinoctial from_kepler(double epoch, double a, doubl
 
 // orbit_type/mod.rs:399-443 ; returns 0, 3 (InvalidConversion) or 4 (InvalidOrbit) =
 // OUTFIT_TRAJ_* of include/outfit_hip.h
+template <bool kCr = false>
 __device__ __forceinline__ int to_equinoctial(const Elements& el, Equinoctial& eq) {
   if (el.kind == 0) {
-    eq = from_kepler(el.epoch, el.e[0], el.e[1], el.e[2], el.e[3], el.e[4], el.e[5]);
+    eq = from_kepler<kCr>(el.epoch, el.e[0], el.e[1], el.e[2], el.e[3], el.e[4], el.e[5]);
     return 0;
   }
   const double e = el.e[1];
@@ -177,7 +196,7 @@ __device__ __forceinline__ int to_equinoctial(const Elements& el, Equinoctial& e
   const double s = sqrt((e - 1.0) / (e + 1.0));
   const double x = clampd(s * tan(0.5 * el.e[5]), -1.0 + 1e-15, 1.0 - 1e-15);
   const double hh = 2.0 * atanh(x);
-  eq = from_kepler(el.epoch, a, e, el.e[2], el.e[3], el.e[4], e * sinh(hh) - hh);
+  eq = from_kepler<kCr>(el.epoch, a, e, el.e[2], el.e[3], el.e[4], e * sinh(hh) - hh);
   return 0;
 }
 
@@ -189,12 +208,13 @@ struct TwoBodyFrame {
   Vec3 f, g;
 };
 
+template <bool kCr = false>
 __device__ __forceinline__ TwoBodyFrame twobody_frame(const Equinoctial& q) {
   TwoBodyFrame F;
   F.n = sqrt(kMu / (q.a * q.a * q.a));
   F.e2 = q.h * q.h + q.k * q.k;
   F.varpi = 0.0;
-  if (F.e2 > kEps * 1e2) F.varpi = principal_angle(atan2(q.h, q.k));
+  if (F.e2 > kEps * 1e2) F.varpi = principal_angle(atan2_sel<kCr>(q.h, q.k));
   F.beta = 1.0 / (1.0 + sqrt(1.0 - F.e2));
   F.bet = F.beta * q.h * q.k;
   F.one_bh2 = 1.0 - F.beta * (q.h * q.h);
@@ -205,13 +225,14 @@ __device__ __forceinline__ TwoBodyFrame twobody_frame(const Equinoctial& q) {
   F.f = {(1.0 - q.p * q.p + q.q * q.q) * inv_u, cc, -2.0 * q.p * inv_u};
   F.g = {cc, (1.0 + q.p * q.p - q.q * q.q) * inv_u, 2.0 * q.q * inv_u};
   F.x0 = kPi + F.varpi;
-  sincos(F.x0, &F.sx0, &F.cx0);
+  sincos_sel<kCr>(F.x0, F.sx0, F.cx0);
   return F;
 }
 
 // equinoctial_element.rs:326-348: roots::find_root_newton_raphson on F - k sin F + h cos F = lambda1 from
 // F0 = pi + varpi, SimpleConvergency{eps: 100*EPSILON, max_iter: 25}; also returns sin F, cos F.
 // false = Err(RootFindingError)
+template <bool kCr = false>
 __device__ __forceinline__ bool solve_kepler_equation(const Equinoctial& q, const TwoBodyFrame& F, double lam,
                                                       double& x, double& sx, double& cx) {
   constexpr double eps = kEps * 1e2;
@@ -229,11 +250,11 @@ __device__ __forceinline__ bool solve_kepler_equation(const Equinoctial& q, cons
       const double x1 = x - f / d;
       const bool conv = fabs(x - x1) < eps;
       x = x1;
-      if (conv) { sincos(x, &sx, &cx); return true; }
+      if (conv) { sincos_sel<kCr>(x, sx, cx); return true; }
       iter = iter + 1;
       if (iter >= 25) return false;
     }
-    sincos(x, &sx, &cx);
+    sincos_sel<kCr>(x, sx, cx);
   }
 }
 

@@ -74,7 +74,7 @@ k_diffcor(DiffCorArgs A) {
     el.epoch = seed.epoch;
 #pragma unroll
     for (int k = 0; k < 6; ++k) el.e[k] = seed.elem[k];
-    conv_error = to_equinoctial(el, q);
+    conv_error = to_equinoctial<true>(el, q);
     if (conv_error) status = 3;  // OUTFIT_LSQ_CONVERSION_ERROR
   }
 

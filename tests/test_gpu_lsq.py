@@ -2,11 +2,10 @@
 CPU oracle (oracle/diffcor.c) — needs an MI355X. SURVEY §8f row n1: FitLSQ::fit_lsq
 (differential_orbit_correction/obs_dataset_api.rs:57-130).
 
-Integer outputs (status, dc_error, iteration / pass / measurement / rejection counts, selections) must
-match exactly. Elements: 1e-10 AU (a; h, k, p, q are dimensionless) and 1e-12 rad (lambda), widened by
-1e-7 x the element's own 1-sigma for poorly constrained short arcs (the normal equations amplify the
-last-place differences between glibc and ROCm sin/cos/atan2 by their condition number; measured: at most
-1e-8 sigma, i.e. 9e-9 AU on an arc whose sigma_a is 0.9 AU).
+The bar is BIT-EXACT records and per-observation fit data: every elementary function of the corrector is evaluated
+correctly rounded on both sides (device/crmath.hpp, oracle/crmath.c) and the linear algebra follows nalgebra's
+operation order. (Before that, the normal equations — condition numbers up to 7e12 — amplified the last-place
+differences between glibc and ROCm sin/cos/atan2 to 1e-8 sigma and flipped an iteration count on 2 objects in 10^4.)
 """
 import numpy as np
 import pytest
@@ -45,63 +44,27 @@ def oracle_lsq(params, cfg, batch, ephem, initial):
     return res, obs
 
 
-def seed_equinoctial(seeds):
-    """The corrector's starting elements (mod.rs:89-96), through the oracle's to_equinoctial."""
-    import ctypes as C
-    out = np.full((len(seeds), 6), np.nan)
-    eq = O.Equinoctial()
-    for i in np.nonzero(seeds["status"] == 0)[0]:
-        el = O.Elements(int(seeds["kind"][i]), float(seeds["epoch"][i]), (C.c_double * 6)(*seeds["elem"][i]))
-        if O.lib().orc_to_equinoctial(C.byref(el), C.byref(eq)) == 0:
-            out[i] = [eq.a, eq.h, eq.k, eq.p, eq.q, eq.lam]
-    return out
-
-
-def compare_lsq(got, got_obs, ref, ref_obs, batch, allow_flips=0, single_step_from=None, ignore=()):
+def compare_lsq(got, got_obs, ref, ref_obs, batch, ignore=()):
+    """Bit-exact: the corrector evaluates every elementary function correctly rounded on both sides and follows the
+    same operation order, so records and per-observation fit data must be the same BYTES (`ignore`: trajectories
+    left out, e.g. degenerate arcs whose records hold NaN payloads)."""
     assert got.shape == ref.shape and got_obs.shape == ref_obs.shape
-    same = np.ones(len(ref), dtype=bool)
-    for k in INT_FIELDS:
-        same &= got[k] == ref[k]
-    considered = np.ones(len(ref), dtype=bool)
-    considered[list(ignore)] = False
-    flips = int((~same & considered).sum())
-    same &= considered
-    assert flips <= allow_flips, f"{flips} trajectories took a different discrete path: {np.nonzero(~same)[0][:8]}"
-    ok = same & (ref["status"] == _abi.LSQ_DIFFCOR)
-    if ok.any():
-        g, r = got[ok], ref[ok]
-        sig = np.sqrt(np.abs(np.diagonal(r["covariance"], axis1=1, axis2=2)))
-        d = np.abs(g["elem"] - r["elem"])
-        d[:, 5] = np.minimum(d[:, 5], np.abs(2 * np.pi - d[:, 5]))
-        tol = np.array([1e-10] * 5 + [1e-12])[None, :] + 1e-7 * sig
-        # conditioning of the normal equations (covariance in correlation form)
-        cond = np.array([np.linalg.cond(c / np.outer(s_, s_)) for c, s_ in zip(r["covariance"], sig)])
-        if single_step_from is not None:
-            # a single Newton step from the seed is not a fixed point: the step itself (up to 1.5 AU on
-            # these arcs) carries the solve's relative error ~ cond x epsilon
-            step = np.abs(r["elem"] - single_step_from[ok]).max(1)
-            tol = tol + (1e-15 * cond * step)[:, None]
-        assert (d <= tol).all(), f"max element excess {np.max(d - tol)}"
-        assert np.array_equal(g["epoch"], r["epoch"])
-        # residuals are divided by sigma ~ 5e-7 rad: one ulp of a right ascension (<= 8.9e-16 rad) is 2e-9 sigma;
-        # fits that stop on stagnation far from a minimum (condition number 5e12) were measured at 1.5e-8
-        assert (np.abs(g["normalised_rms"] - r["normalised_rms"]) / np.maximum(1.0, r["normalised_rms"])).max() <= 1e-7
-        # the covariance is the inverse of a matrix whose condition number reaches 1e13 on these short
-        # arcs: last-place differences of the partials are amplified by it
-        scale = sig[:, :, None] * sig[:, None, :]
-        rel = (np.abs(g["covariance"] - r["covariance"]) / (scale + 1e-300)).reshape(len(g), -1).max(1)
-        assert (rel <= 1e-6 + 1e-15 * cond).all(), f"covariance excess {np.max(rel / (1e-6 + 1e-15 * cond))}"
-        # per-observation fit data of the converged trajectories
-        off = batch.traj_offset.astype(np.int64)
-        rows = np.concatenate([np.arange(off[t], off[t + 1]) for t in np.nonzero(ok)[0]])
-        assert np.array_equal(got_obs["selection"][rows], ref_obs["selection"][rows])
-        rtol = np.concatenate([np.full(off[t + 1] - off[t], 1e-11 + 1e-22 * c)
-                               for t, c in zip(np.nonzero(ok)[0], cond)])   # 2e-5 sigma, widened when ill-conditioned
-        assert (np.abs(got_obs["residual_ra"][rows] - ref_obs["residual_ra"][rows]) <= rtol).all()
-        assert (np.abs(got_obs["residual_dec"][rows] - ref_obs["residual_dec"][rows]) <= rtol).all()
-        smin = np.minimum(batch.sigma_ra[rows], batch.sigma_dec[rows])   # chi = |residual / sigma|
-        assert (np.abs(got_obs["chi"][rows] - ref_obs["chi"][rows]) <= 2.0 * rtol / smin + 1e-9 * ref_obs["chi"][rows]).all()
-    return flips
+    keep = np.ones(len(ref), dtype=bool)
+    keep[list(ignore)] = False
+    for k in got.dtype.names:
+        if k == "iod":
+            continue  # compared by the IOD parity tests (its rms field follows the platform functions)
+        a, b = got[k][keep], ref[k][keep]
+        same = (a == b) | ((a != a) & (b != b)) if a.dtype.kind == "f" else (a == b)
+        rows = np.nonzero(~same.reshape(len(a), -1).all(1))[0]
+        assert len(rows) == 0, f"{k}: {len(rows)} trajectories differ, first {np.nonzero(keep)[0][rows[:5]]}"
+    off = batch.traj_offset.astype(np.int64)
+    rows = np.concatenate([np.arange(off[t], off[t + 1]) for t in np.nonzero(keep)[0]] or [np.zeros(0, np.int64)])
+    for k in got_obs.dtype.names:
+        a, b = got_obs[k][rows], ref_obs[k][rows]
+        same = (a == b) | ((a != a) & (b != b)) if a.dtype.kind == "f" else (a == b)
+        assert same.all(), f"obs_fit.{k}: {int((~same).sum())} observations differ"
+    return 0
 
 
 def test_lsq_on_given_seeds_1000_objects(ephem_dict):
@@ -133,8 +96,7 @@ def test_lsq_config_variants(ephem_dict, kw):
     cfg = outfit_amd.DifferentialCorrectionConfig(**kw)
     got, got_obs = outfit_amd.fit_lsq_records(batch, ephem, params, cfg, seeds, n_devices=1)
     ref, ref_obs = oracle_lsq(params, cfg, batch, ephem, seeds)
-    compare_lsq(got, got_obs, ref, ref_obs, batch, allow_flips=1,
-                single_step_from=seed_equinoctial(seeds) if kw.get("max_newton_iterations") == 1 else None)
+    compare_lsq(got, got_obs, ref, ref_obs, batch)
     if "chi_squared_rejection_threshold" in kw:
         assert (ref["n_rejected"] > 0).sum() > 20 and (ref["outer_passes"] > 1).sum() > 20
 
@@ -150,7 +112,7 @@ def test_lsq_rejects_injected_outliers(ephem_dict):
     cfg = outfit_amd.DifferentialCorrectionConfig(rms_divergence_ratio=1e300)
     got, got_obs = outfit_amd.fit_lsq_records(batch, ephem, params, cfg, seeds, n_devices=1)
     ref, ref_obs = oracle_lsq(params, cfg, batch, ephem, seeds)
-    compare_lsq(got, got_obs, ref, ref_obs, batch, allow_flips=1)
+    compare_lsq(got, got_obs, ref, ref_obs, batch)
     ok = ref["status"] == _abi.LSQ_DIFFCOR
     assert (ref_obs["selection"][bad][ok] == _abi.OBS_REJECTED).mean() > 0.8
 
@@ -164,7 +126,7 @@ def test_lsq_end_to_end_without_seeds(ephem_dict):
     got, got_obs = outfit_amd.fit_lsq_records(batch, ephem, params, cfg, None, n_devices=1)
     ref, ref_obs = oracle_lsq(params, cfg, batch, ephem, None)
     assert np.array_equal(got["iod"]["status"], ref["iod"]["status"])
-    compare_lsq(got, got_obs, ref, ref_obs, batch, allow_flips=5)
+    compare_lsq(got, got_obs, ref, ref_obs, batch)
     res = outfit_amd.fit_lsq(batch, ephem, params, cfg)
     kinds = {type(v).__name__ for v in res.values()}
     assert "DifferentialCorrection" in kinds and "IODGauss" in kinds
@@ -193,7 +155,7 @@ def test_lsq_seed_errors_and_partial_seeds(ephem_dict):
     ref, ref_obs = oracle_lsq(params, cfg, b2, ephem, half)
     assert got["status"][5] == _abi.LSQ_IOD_ERROR and got["iod"]["status"][5] == 1
     assert got["status"][17] == _abi.LSQ_IOD_ERROR
-    compare_lsq(got, got_obs, ref, ref_obs, b2, allow_flips=2)
+    compare_lsq(got, got_obs, ref, ref_obs, b2)
     res = outfit_amd.fit_lsq(b2, ephem, params, cfg, half)
     assert isinstance(res[b2.traj_ids[5]], outfit_amd.NoFeasibleTriplets)
 
@@ -258,7 +220,7 @@ def test_lane_group_size_does_not_change_a_bit(ephem_dict, monkeypatch):
         assert rec.tobytes() == outs[0][0].tobytes() and obs.tobytes() == outs[0][1].tobytes()
     monkeypatch.delenv("OUTFIT_DIFFCOR_GROUP")
     ref, ref_obs = oracle_lsq(params, cfg, b2, ephem, seeds)
-    compare_lsq(outs[0][0], outs[0][1], ref, ref_obs, b2, allow_flips=1)
+    compare_lsq(outs[0][0], outs[0][1], ref, ref_obs, b2)
     assert (ref["n_rejected"] > 0).sum() > 10
 
 
@@ -290,7 +252,7 @@ def test_lsq_degenerate_inputs(ephem_dict):
     # nothing more can be compared
     for t in (9, 21):
         assert got["status"][t] in (_abi.LSQ_DIFFCOR, _abi.LSQ_IOD_KEPT) and ref["status"][t] in (_abi.LSQ_DIFFCOR, _abi.LSQ_IOD_KEPT)
-    compare_lsq(got, got_obs, ref, ref_obs, b2, allow_flips=1, ignore=(9, 21))
+    compare_lsq(got, got_obs, ref, ref_obs, b2, ignore=(9, 21))
     fixed = outfit_amd.DifferentialCorrectionConfig(free_elements=[0] * 6, rms_divergence_ratio=1e300)
     got, got_obs = outfit_amd.fit_lsq_records(b2, ephem, params, fixed, seeds, 1)
     ref, ref_obs = oracle_lsq(params, fixed, b2, ephem, seeds)

@@ -42,6 +42,9 @@ def compare(got, ref, allow_flips=0):
         assert np.abs(g["elem"][:, 1] - r["elem"][:, 1]).max() <= TOL_LEN
         for c in range(2, 6):
             assert ang_diff(g["elem"][:, c], r["elem"][:, c]).max() <= TOL_ANG, c
+        # stronger than the north-star tolerance above: everything that feeds the elements is either exact
+        # arithmetic in the reference's order or a correctly-rounded function on both sides
+        assert np.array_equal(g["elem"], r["elem"]), "elements are not bit-identical"
         assert np.abs(g["epoch"] - r["epoch"]).max() <= 1e-10
         assert (np.abs(g["rms"] - r["rms"]) / np.maximum(1.0, r["rms"])).max() <= 1e-9
     return flips
