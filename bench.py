@@ -50,7 +50,10 @@ def host_cores():
 def cpu_baseline(batch, ephem, params, n_obj_max, budget_s=15.0):
     """The CPU oracle (a restatement of the reference's Rayon path: one task per trajectory,
     dynamic scheduling) timed on the host cores, on a bounded prefix of the same workload."""
+    import ctypes
     import oracle_lib as O
+    # as the reference runs: the platform libm, not the oracle's correctly-rounded (binary128) functions
+    ctypes.c_int.in_dll(O.lib(), "orc_use_libm").value = 1
     cores = host_cores()
     n0 = min(n_obj_max, 64 * cores)
     sub = batch.slice(0, n0)
@@ -66,13 +69,15 @@ def cpu_baseline(batch, ephem, params, n_obj_max, budget_s=15.0):
     assert rc == 0
     return {"value": n1 / dt1, "unit": "objects/s", "cores": cores, "kind": "port",
             "sample": f"first {n1} objects of the same synthetic batch, {dt1:.1f} s, Earth re-interpolated "
-                      "per (candidate, observation) as the reference does"}
+                      "per (candidate, observation) and platform libm as the reference does"}
 
 
 def cpu_baseline_lsq(batch, ephem, params, seeds, n_obj_max, budget_s=5.0):
     """The oracle's differential correction (the reference loops over trajectories sequentially,
     obs_dataset_api.rs:76-96; threads here = the same dynamic schedule as the IOD baseline) on given seeds."""
+    import ctypes
     import oracle_lib as O
+    ctypes.c_int.in_dll(O.lib(), "orc_use_libm").value = 1  # platform libm, as the reference runs
     cores = host_cores()
     cfg = O.default_diffcor_config()
     n0 = min(n_obj_max, 2048 * cores)
