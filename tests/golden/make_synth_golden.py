@@ -24,7 +24,7 @@ params = synth.bench_params(O.default_params())
 rc, res = O.fit_full_iod(params, batch.as_c(), ephem.as_c(), n_threads=8, hoist=1)
 assert rc == 0
 out = {
-    "source": "tests/golden/make_synth_golden.py (CPU oracle, correctly-rounded sin/cos/acos)",
+    "source": "tests/golden/make_synth_golden.py (CPU oracle, correctly-rounded elementary functions, oracle/crmath.c)",
     "dataset_sha256": synth.dataset_sha256(ds),
     "n_obj": 64,
     "records": [

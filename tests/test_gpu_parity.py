@@ -265,6 +265,7 @@ def test_golden_fixture_on_gpu():
             ref = np.array([float.fromhex(x) for x in e["elem"]])
             assert np.abs(r["elem"][:2] - ref[:2]).max() <= TOL_LEN
             assert ang_diff(r["elem"][2:], ref[2:]).max() <= TOL_ANG
+            assert np.array_equal(r["elem"], ref), "elements are not bit-identical to the committed oracle output"
             assert abs(r["rms"] - float.fromhex(e["rms"])) <= 1e-9 * max(1.0, float.fromhex(e["rms"]))
 
 
