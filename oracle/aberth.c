@@ -71,7 +71,7 @@ int orc_aberth9(const double poly[9], uint32_t max_iter, double eps, double re[8
   for (int i = 0; i < N; ++i) s_of_w[i] = -fabs(monic[i]);
   s_of_w[N] = monic[N];
   double r0 = 1.0;
-  for (int guard = 0; guard < 100000; ++guard) {
+  for (int guard = 0; guard < 4096; ++guard) { /* the crate loops without a bound; 4096 (r0 up to 4097: |c6| < 1.6e7) here and on the device alike */
     cplx s = horner(s_of_w, TERMS, (cplx){r0, 0.0});
     if (s.re > 0.0) break;
     r0 += 1.0;

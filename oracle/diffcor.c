@@ -213,11 +213,14 @@ int orc_obs_and_partials_2body(const orc_equinoctial *eq, double mjd, const doub
   return 0;
 }
 
-/* least_square.rs:188-198 */
+/* least_square.rs:188-198. The reference's two `while` loops do not terminate when a - b is infinite or so large
+ * that subtracting 2 pi no longer changes it (an observed angle of 1e300): here — and identically on the device — they
+ * stop after 1024 steps (|a - b| < 6400 rad is reduced exactly as the reference does) and the result is then NaN. */
 double orc_angular_diff(double a, double b) {
   double d = a - b;
-  while (d > ORC_PI) d -= ORC_DPI;
-  while (d < -ORC_PI) d += ORC_DPI;
+  for (int i = 0; i < 1024 && d > ORC_PI; ++i) d -= ORC_DPI;
+  for (int i = 0; i < 1024 && d < -ORC_PI; ++i) d += ORC_DPI;
+  if (d > ORC_PI || d < -ORC_PI) return NAN;
   return d;
 }
 

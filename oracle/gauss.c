@@ -95,7 +95,7 @@ uint32_t orc_descartes_upper_bound(double c0, double c3, double c6, double zero_
   for (int i = 0; i < 3; ++i) {
     int s;
     if (fabs(v[i]) <= zero_eps) s = 0;
-    else s = signbit(v[i]) ? -1 : 1;
+    else s = (signbit(v[i]) || isnan(v[i])) ? -1 : 1; /* NaN: the sign bit is platform-dependent; negative by convention (device too) */
     if (s == 0) continue;
     if (last != 0 && s != last) ++count;
     last = s;

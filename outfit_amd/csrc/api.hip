@@ -116,7 +116,7 @@ struct outfit_hip_session {
   DevBuf<outfit::GaussResultRec> dc_initial;
   DevBuf<outfit::LsqResultRec> dc_out;
   DevBuf<outfit::ObsFitRec> dc_fit;
-  bool prepass_done = false, ra_bounded = true, lsq_ran = false;
+  bool prepass_done = false, lsq_ran = false;
   const outfit::GaussResultRec* iod_out = nullptr;  // where the last IOD run wrote (d_out or `results`)
   outfit::EphemTable table{};
   outfit::GaussParams gp{};
@@ -284,8 +284,6 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
   HIP_TRY(s->results.alloc((size_t)s->n_traj));
   // status -1 until an IOD run fills the records (outfit_hip_session_run_lsq reads them as "no seed")
   if (s->n_traj) HIP_TRY(hipMemset(s->results.p, 0xFF, (size_t)s->n_traj * sizeof(outfit::GaussResultRec)));
-  for (size_t i = 0; i < n; ++i)
-    if (!(std::fabs(b->ra[o0 + i]) <= 1.0e3) || !std::isfinite(b->dec[o0 + i])) { s->ra_bounded = false; break; }
   HIP_TRY(s->error_flag.alloc(1));
   HIP_TRY(hipMemset(s->error_flag.p, 0, sizeof(int)));
   if (device_geometry && n) {
@@ -546,8 +544,6 @@ int session_run_lsq(outfit_hip_session* s, const outfit_diffcor_config_t* cfg,
                     const outfit_gauss_result_t* initial, hipStream_t st) {
   HIP_TRY(hipSetDevice(s->device));
   if (const char* m = validate_diffcor(cfg)) return fail(OUTFIT_ERR_INVALID_PARAM, m);
-  if (!s->ra_bounded)
-    return fail(OUTFIT_ERR_INVALID_BATCH, "fit_lsq needs |ra| <= 1e3 rad and finite dec (angular_diff loops on the difference)");
   s->last_stream = st;
   s->lsq_ran = true;
   if (s->n_traj == 0) return OUTFIT_OK;

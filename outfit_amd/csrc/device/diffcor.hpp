@@ -141,9 +141,12 @@ __device__ __forceinline__ bool obs_and_partials(const Equinoctial& q, const Par
 
 // least_square.rs:188-198. The host bounds |ra| so the loops are short.
 __device__ __forceinline__ double angular_diff(double a, double b) {
+  // the reference's `while` loops never end for an infinite or absurdly large difference (an observed angle of
+  // 1e300): bounded here and in the oracle alike — |a - b| < 6400 rad reduces exactly as the reference, beyond: NaN
   double d = a - b;
-  while (d > kPi) d -= kTwoPi;
-  while (d < -kPi) d += kTwoPi;
+  for (int i = 0; i < 1024 && d > kPi; ++i) d -= kTwoPi;
+  for (int i = 0; i < 1024 && d < -kPi; ++i) d += kTwoPi;
+  if (d > kPi || d < -kPi) return nan("");
   return d;
 }
 

@@ -252,7 +252,9 @@ __device__ __forceinline__ unsigned descartes_upper_bound(double c0, double c3, 
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     if (fabs(v[i]) <= 0.0) continue;
-    const int s = signbit(v[i]) ? -1 : 1;
+    // a NaN coefficient: the reference reads its sign bit (is_sign_positive), which depends on where the NaN came from
+    // and on the platform (x86 generates negative, this GPU positive NaNs) — taken as negative here and in the oracle
+    const int s = (signbit(v[i]) || v[i] != v[i]) ? -1 : 1;
     if (s != last) ++count;
     last = s;
   }

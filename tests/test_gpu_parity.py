@@ -325,3 +325,55 @@ def test_cpp_host_example_config1():
     assert "K09R05F: CorrectedOrbit" in out.stdout
     assert "matches the reference's OrbFit orbit to 1e-13: yes" in out.stdout
     assert "too_short: Err(NoFeasibleTriplets" in out.stdout
+
+
+def test_corrupted_inputs_match_the_oracle(ephem_dict):
+    """NaN, infinities, absurd magnitudes, zero and negative uncertainties, repeated epochs sprinkled over the
+    observations (one kind per trajectory): the device must terminate and take the oracle's decision on every
+    trajectory — same status / cause / counters, same elements where an orbit still comes out — for the IOD and for
+    the corrector (records compared as bytes, NaN payloads included)."""
+    n = 240
+    ds = synth.make_dataset(n, seed=77, ephem=ephem_dict)
+    rng = np.random.default_rng(5)
+    m = 20  # observations per trajectory
+    bad_values = [np.nan, np.inf, -np.inf, 1e300, -1e300, 1e-300, 0.0, -1.0, 1e6, 7.0]
+    for t in range(n):
+        kind = t % 12
+        rows = t * m + rng.choice(m, size=1 + t % 3, replace=False)
+        v = bad_values[(t // 12) % len(bad_values)]
+        if kind == 0:
+            ds["ra"][rows] = v
+        elif kind == 1:
+            ds["dec"][rows] = v
+        elif kind == 2:
+            ds["sigma_ra"][rows] = v
+        elif kind == 3:
+            ds["sigma_dec"][rows] = v
+        elif kind == 4:
+            ds["obs_helio_equ"][3 * rows + 1] = v
+        elif kind == 5:
+            ds["obs_geo_ecl"][3 * rows] = v if np.isfinite(v) and abs(v) < 1e3 else 1e-5
+        elif kind == 6:
+            ds["mjd_tt"][t * m + 5: t * m + 9] = ds["mjd_tt"][t * m + 5]      # repeated epochs (still sorted)
+        elif kind == 7:
+            ds["ra"][t * m: (t + 1) * m] = ds["ra"][t * m]                     # a fixed star: no motion
+            ds["dec"][t * m: (t + 1) * m] = ds["dec"][t * m]
+        # kinds 8..11: untouched controls
+    batch = outfit_amd.ObsBatch.from_dict(ds)
+    ephem = outfit_amd.Ephemeris.from_dict(ephem_dict)
+    params = synth.bench_params(outfit_amd.IODParams())
+    got = outfit_amd.fit_full_iod_records(batch, ephem, params, 1)
+    ref = oracle(params, batch, ephem)
+    for k in ("status", "cause", "stage", "kind", "attempts", "n_triplets", "best_triplet", "best_realization"):
+        assert np.array_equal(got[k], ref[k]), (k, np.nonzero(got[k] != ref[k])[0][:8])
+    ok = ref["status"] == 0
+    assert ok.sum() > n // 3 and (~ok).sum() > 10
+    assert got["elem"][ok].tobytes() == ref["elem"][ok].tobytes()
+    cfg = outfit_amd.DifferentialCorrectionConfig(rms_divergence_ratio=10.0)
+    lsq, obs = outfit_amd.fit_lsq_records(batch, ephem, params, cfg, ref, n_devices=1)
+    rc, lref, oref = O.fit_lsq(params.as_c(), cfg.as_c(), batch.as_c(), ephem.as_c(), ref, n_threads=8)
+    assert rc == 0
+    for k in lsq.dtype.names:
+        if k != "iod":
+            assert lsq[k].tobytes() == lref[k].tobytes(), (k, np.nonzero((lsq[k] != lref[k]).reshape(n, -1).any(1))[0][:8])
+    assert obs.tobytes() == oref.tobytes()
