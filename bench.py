@@ -145,7 +145,12 @@ def main():
     gather_dev = "cuda" if args.backend == "nccl" else "cpu"
     out_all = [torch.empty((world * n_obj, BYTES_PER_RESULT), dtype=torch.uint8, device=gather_dev) for _ in range(2)] \
         if world > 1 else None
-    stream = torch.cuda.current_stream().cuda_stream
+    # An explicit torch stream: torch's default stream has handle 0, which the C ABI reads as "the session's own
+    # stream" — the collective (RCCL syncs with torch's CURRENT stream) would then not wait for the kernels.
+    tstream = torch.cuda.Stream()
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    assert stream != 0
     pending = [None, None]
     state = {"step": 0}
 

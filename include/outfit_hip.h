@@ -187,7 +187,8 @@ int outfit_hip_fit_full_iod(const outfit_iod_params_t *params,
 /* ---- resident-session API (one device) --------------------------------------
  * Same computation with inputs kept in HBM between runs; what the blocking
  * call uses internally per device and what bench.py / a long-lived host uses.
- * `stream` is a hipStream_t (NULL = the session's own stream). */
+ * `stream` is a hipStream_t; NULL = the session's own (non-blocking) stream, NOT the legacy default stream: a
+ * caller that orders other work (a collective, a copy) after a run must pass the explicit stream that work is on. */
 typedef struct outfit_hip_session outfit_hip_session_t;
 
 int outfit_hip_session_create(const outfit_iod_params_t *params,

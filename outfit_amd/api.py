@@ -385,6 +385,9 @@ class IODSession:
         self._h = h
 
     def run(self, stream=None, d_out=None):
+        """Enqueue one pass. `stream`: a HIP stream handle, e.g. `torch.cuda.Stream().cuda_stream`; None or 0 (which is
+        what torch's DEFAULT stream reports) means the session's own non-blocking stream — work queued on torch's
+        default stream is then not ordered after the run (use `results()` or a device-wide synchronize)."""
         rc = self._L.outfit_hip_session_run(self._h, C.c_void_p(stream or 0), C.c_void_p(d_out or 0))
         if rc != 0:
             _raise_rc(rc)
