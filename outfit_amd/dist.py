@@ -75,6 +75,8 @@ def fit_full_iod_distributed(batch, ephem, params, dist, device_index, compute=N
         local = torch.empty((counts[rank], RECORD_BYTES), dtype=torch.uint8, device=dev)
         if counts[rank]:
             s = IODSession(sub, ephem, params, device=device_index)
+            # torch's default stream reports handle 0 = "the session's own stream" for the C ABI: the device-wide
+            # synchronize below (not stream order) is what puts the gather after the kernels
             s.run(stream=torch.cuda.current_stream(dev).cuda_stream, d_out=local.data_ptr())
             torch.cuda.synchronize(dev)
             s.close()
