@@ -143,6 +143,9 @@ __device__ __forceinline__ double prelim_elliptic(const KeplerProblem& p) {
   const double m0 = principal_angle(u0 - p.e0 * su0);
   const double m = m0 + n * p.dt;
   double u = m;
+  // not unrolled: the body inlines the correctly-rounded functions with their second steps (~1-2 k instructions);
+  // 20 copies of it made this the largest code of the library for no measurable gain
+#pragma unroll 1
   for (int i = 0; i < 20; ++i) {
     double su, cu;
     crm::sincos(u, su, cu);
@@ -167,6 +170,9 @@ __device__ __forceinline__ double prelim_hyperbolic(const KeplerProblem& p) {
   crm::sinhcosh(f0, sh, ch);
   const double m = (p.e0 * sh - f0) + n * p.dt;
   double f = 0.0;
+  // not unrolled: the body inlines the correctly-rounded functions with their second steps (~1-2 k instructions);
+  // 20 copies of it made this the largest code of the library for no measurable gain
+#pragma unroll 1
   for (int i = 0; i < 20; ++i) {
     if (fabs(f) < 15.0) {
       crm::sinhcosh(f, sh, ch);

@@ -334,8 +334,11 @@ __device__ __forceinline__ unsigned long long wave_grab(unsigned long long* queu
 
 __global__ void __launch_bounds__(kFastBlock, kFastWavesPerSimd)
 k_gauss_correct_fast(CorrectArgs a) {
-  extern __shared__ double lds[];  // [27][blockDim.x]: S, S^-1, observer matrix
-  const unsigned tid = threadIdx.x, bs = blockDim.x;
+  extern __shared__ double lds[];  // [27][kFastBlock]: S, S^-1, observer matrix
+  // the block size is the launcher's constant: with a runtime blockDim.x every L(k) paid a scalar offset (27 of
+  // them, spilled to VGPR lanes) and a v_add_u32; as immediates they are the ds_read/ds_write offset field
+  const unsigned tid = threadIdx.x;
+  constexpr unsigned bs = kFastBlock;
   const unsigned long long n = a.I.n_cand;
   auto L = [&](unsigned k) -> double& { return lds[k * bs + tid]; };
 
@@ -421,8 +424,9 @@ k_gauss_correct_fast(CorrectArgs a) {
 // ------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kCorrectBlock, 2)
 k_gauss_correct(CorrectArgs a) {
-  extern __shared__ double lds[];  // [kCorrectLdsDoubles][blockDim.x]
-  const unsigned tid = threadIdx.x, bs = blockDim.x;
+  extern __shared__ double lds[];  // [kCorrectLdsDoubles][kCorrectBlock]
+  const unsigned tid = threadIdx.x;
+  constexpr unsigned bs = kCorrectBlock;
   const unsigned long long n = a.I.n_cand;
   const unsigned long long n_items = *a.W.slow_count;
   auto L = [&](unsigned k) -> double& { return lds[k * bs + tid]; };
