@@ -487,7 +487,7 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
       HIP_TRY(outfit::launch_gauss_correct(cg, s->n_cu, aux));
     }
     HIP_TRY(hipEventRecord(s->ev_general, aux));
-    const outfit::RmsArgs rm{ci, w, obs_pos, s->cos_dec.p, s->params.extf, s->params.dtmax};
+    const outfit::RmsArgs rm{ci, w, obs_pos, s->cos_dec.p, s->params.extf, s->params.dtmax, outfit::sincos_consts()};
     HIP_TRY(hipStreamWaitEvent(st, s->ev_prepass, 0));
     {
       Stamp stamp(s, st, K_RMS);

@@ -139,7 +139,7 @@ __device__ __forceinline__ bool obs_and_partials(const Equinoctial& q, const Par
   return true;
 }
 
-// least_square.rs:188-198. The host bounds |ra| so the loops are short.
+// least_square.rs:188-198
 __device__ __forceinline__ double angular_diff(double a, double b) {
   // the reference's `while` loops never end for an infinite or absurdly large difference (an observed angle of
   // 1e300): bounded here and in the oracle alike — |a - b| < 6400 rad reduces exactly as the reference, beyond: NaN

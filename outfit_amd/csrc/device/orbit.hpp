@@ -143,6 +143,44 @@ struct Equinoctial {
   double epoch, a, h, k, p, q, lambda;
 };
 
+// ---- sin and cos for the residual loop of K2c -------------------------------------------------------------
+// The platform sincos costs ~100 VALU instructions per call here, ~40 of them v_mov: its polynomial constants are
+// 64-bit literals, which this ISA can only feed to a VALU instruction from a register, and the compiler
+// materialises them in VGPRs inside the loop. Constants that arrive as KERNEL ARGUMENTS sit in SGPRs and are read
+// as operands directly (one scalar operand per instruction is all a Horner step needs): same ~1 ulp accuracy in ~40
+// instructions. Cody-Waite by pi/2 in three parts (k * P1 and k * P2 exact for |k| < 2^20), fdlibm's minimax
+// polynomials (k_sin.c / k_cos.c, degree 13 / 14 on [-pi/4, pi/4]). Only where a last place does not reach the
+// returned elements: the RMS of a candidate (it moves by <= 1e-9 relative against the platform functions).
+struct SinCosConsts {
+  double two_over_pi, p1, p2, p3;
+  double s1, s2, s3, s4, s5, s6;
+  double c1, c2, c3, c4, c5, c6;
+};
+inline SinCosConsts sincos_consts() {
+  return {0.6366197723675814, 1.5707963267341256, 6.077100506303966e-11, 2.0222662487959506e-21,
+          -1.66666666666666324348e-01, 8.33333333332248946124e-03, -1.98412698298579493134e-04,
+          2.75573137070700676789e-06, -2.50507602534068634195e-08, 1.58969099521155010221e-10,
+          4.16666666666666019037e-02, -1.38888888888741095749e-03, 2.48015872894767294178e-05,
+          -2.75573143513906633035e-07, 2.08757232129817482790e-09, -1.13596475577881948265e-11};
+}
+__device__ __forceinline__ void sincos_k(double x, const SinCosConsts& K, double& s, double& c) {
+  if (!(fabs(x) < 1048576.0)) { ::sincos(x, &s, &c); return; }
+  const double k = rint(x * K.two_over_pi);
+  double r = fma(-k, K.p1, x);
+  r = fma(-k, K.p2, r);
+  r = fma(-k, K.p3, r);
+  const int q = (int)k;
+  const double z = r * r;
+  const double ps = K.s2 + z * (K.s3 + z * (K.s4 + z * (K.s5 + z * K.s6)));
+  const double sr = r + (z * r) * (K.s1 + z * ps);
+  const double pc = z * (K.c1 + z * (K.c2 + z * (K.c3 + z * (K.c4 + z * (K.c5 + z * K.c6)))));
+  const double hz = 0.5 * z, w = 1.0 - hz;
+  const double cr = w + (((1.0 - w) - hz) + z * pc);
+  const double a = (q & 1) ? cr : sr, b = (q & 1) ? sr : cr;
+  s = (q & 2) ? -a : a;
+  c = ((q + 1) & 2) ? -b : b;
+}
+
 // Platform or correctly-rounded elementary functions, chosen per caller: the candidate RMS (K2c, 2x10^8
 // observation evaluations per step) keeps the platform functions — they move the RMS by <= 1e-9 relative, never the
 // returned elements; the differential corrector (ill-conditioned normal equations amplify a last place up to
@@ -234,7 +272,8 @@ __device__ __forceinline__ TwoBodyFrame twobody_frame(const Equinoctial& q) {
 // false = Err(RootFindingError)
 template <bool kCr = false>
 __device__ __forceinline__ bool solve_kepler_equation(const Equinoctial& q, const TwoBodyFrame& F, double lam,
-                                                      double& x, double& sx, double& cx) {
+                                                      double& x, double& sx, double& cx,
+                                                      const SinCosConsts* K = nullptr) {
   constexpr double eps = kEps * 1e2;
   x = F.x0; sx = F.sx0; cx = F.cx0;
   int iter = 0;
@@ -250,22 +289,22 @@ __device__ __forceinline__ bool solve_kepler_equation(const Equinoctial& q, cons
       const double x1 = x - f / d;
       const bool conv = fabs(x - x1) < eps;
       x = x1;
-      if (conv) { sincos_sel<kCr>(x, sx, cx); return true; }
+      if (conv) { if (K) sincos_k(x, *K, sx, cx); else sincos_sel<kCr>(x, sx, cx); return true; }
       iter = iter + 1;
       if (iter >= 25) return false;
     }
-    sincos_sel<kCr>(x, sx, cx);
+    if (K) sincos_k(x, *K, sx, cx); else sincos_sel<kCr>(x, sx, cx);
   }
 }
 
 // equinoctial_element.rs:809-867 with t0 = 0, t1 = dt ; false = Err(RootFindingError)
 __device__ __forceinline__ bool propagate_twobody(const Equinoctial& q, const TwoBodyFrame& F, double dt,
-                                         Vec3& pos, Vec3& vel) {
+                                         Vec3& pos, Vec3& vel, const SinCosConsts* K = nullptr) {
   double lam = principal_angle_fast(q.lambda + F.n * (dt - 0.0));
   if (lam < F.varpi) lam += kTwoPi;
   // roots::find_root_newton_raphson, SimpleConvergency{eps: 100*EPSILON, max_iter: 25}
   double x, sx, cx;
-  if (!solve_kepler_equation(q, F, lam, x, sx, cx)) return false;
+  if (!solve_kepler_equation(q, F, lam, x, sx, cx, K)) return false;
   const double xe = q.a * (F.one_bh2 * cx + F.bet * sx - q.k);
   const double ye = q.a * (F.one_bk2 * sx + F.bet * cx - q.h);
   pos = {xe * F.f.x + ye * F.g.x, xe * F.f.y + ye * F.g.y, xe * F.f.z + ye * F.g.z};
@@ -279,9 +318,9 @@ __device__ __forceinline__ bool propagate_twobody(const Equinoctial& q, const Tw
 // observation_ephemeris.rs:369-416 for one observation; false = Err(_)
 __device__ __forceinline__ bool ephemeris_error(const Equinoctial& q, const TwoBodyFrame& F, double mjd, double ra,
                                        double dec, double cos_dec, double sra, double sdec,
-                                       const Vec3& obs_pos_equ, double& term) {
+                                       const Vec3& obs_pos_equ, double& term, const SinCosConsts* K = nullptr) {
   Vec3 pe, ve;
-  if (!propagate_twobody(q, F, mjd - q.epoch, pe, ve)) return false;
+  if (!propagate_twobody(q, F, mjd - q.epoch, pe, ve, K)) return false;
   const Vec3 pq = ecl_to_equ_finite(pe), vq = ecl_to_equ_finite(ve);
   const Vec3 rel = {pq.x - obs_pos_equ.x, pq.y - obs_pos_equ.y, pq.z - obs_pos_equ.z};
   const double lt = norm(rel) / kVlightAU;

@@ -125,6 +125,7 @@ struct RmsArgs {
   const double* obs_pos;
   const double* cos_dec;
   double extf, dtmax;
+  SinCosConsts sc;  // polynomial constants as kernel arguments = scalar registers (device/orbit.hpp)
 };
 
 struct SelectArgs {

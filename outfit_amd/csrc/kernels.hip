@@ -606,7 +606,7 @@ k_orbit_rms(RmsArgs a) {
       const Vec3 op = {a.obs_pos[3 * o], a.obs_pos[3 * o + 1], a.obs_pos[3 * o + 2]};
       double term;
       if (!ephemeris_error(eq, F, a.I.mjd[o], a.I.ra[o], a.I.dec[o], a.cos_dec[o], a.I.sra[o], a.I.sdec[o], op,
-                           term)) {
+                           term, &a.sc)) {
         err = true;
         break;
       }
