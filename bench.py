@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--no-lsq", action="store_true", help="skip the differential-correction side measurement")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the real path) or gloo (rehearsal of the N>1 logic on one GPU)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal only: create the process group and run the gather path even with one rank "
+                         "(exercises the RCCL calls and their stream ordering on a one-GPU box)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal only: every rank uses GPU 0 (needs --backend gloo)")
     args = ap.parse_args()
@@ -122,8 +125,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    multi = world > 1 or args.force_dist   # the N > 1 code path (gather, barrier, max over ranks)
+    if multi:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -144,7 +152,7 @@ def main():
     out_local = [torch.empty((n_obj, BYTES_PER_RESULT), dtype=torch.uint8, device="cuda") for _ in range(2)]
     gather_dev = "cuda" if args.backend == "nccl" else "cpu"
     out_all = [torch.empty((world * n_obj, BYTES_PER_RESULT), dtype=torch.uint8, device=gather_dev) for _ in range(2)] \
-        if world > 1 else None
+        if multi else None
     # An explicit torch stream: torch's default stream has handle 0, which the C ABI reads as "the session's own
     # stream" — the collective (RCCL syncs with torch's CURRENT stream) would then not wait for the kernels.
     tstream = torch.cuda.Stream()
@@ -161,7 +169,7 @@ def main():
             pending[b].wait()
             pending[b] = None
         session.run(stream=stream, d_out=out_local[b].data_ptr())
-        if world > 1:
+        if multi:
             if args.backend == "nccl":
                 pending[b] = dist.all_gather_into_tensor(out_all[b], out_local[b], async_op=True)
             else:  # rehearsal: gloo gathers host copies
@@ -172,7 +180,7 @@ def main():
             if pending[b] is not None:
                 pending[b].wait()
                 pending[b] = None
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -208,7 +216,7 @@ def main():
                "n_diffcor": int((lrec["status"] == 0).sum()), "n_iod_kept": int((lrec["status"] == 1).sum()),
                "mean_newton_iterations": float(lrec["total_newton_iterations"].mean())}
 
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -216,7 +224,7 @@ def main():
     # sanity: the timed work produced orbits
     last = out_local[(state["step"] - 1) & 1]
     res = np.frombuffer(last.cpu().numpy().tobytes(), dtype=outfit_amd._abi.RESULT_DTYPE)
-    if world > 1:  # the gathered table holds this rank's records at its offset
+    if multi:  # the gathered table holds this rank's records at its offset
         mine = out_all[(state["step"] - 1) & 1][rank * n_obj:(rank + 1) * n_obj]
         assert bytes(mine.cpu().numpy().tobytes()) == res.tobytes(), "gathered records differ from the local ones"
     n_ok = int((res["status"] == 0).sum())
@@ -288,7 +296,7 @@ def main():
                 line["fit_lsq"]["cpu_baseline"] = cpu_baseline_lsq(batch, ephem, params, res, n_obj)
         print(json.dumps(line), flush=True)
     session.close()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
