@@ -132,10 +132,22 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend="gloo")
+        # RCCL prints a version banner on STDOUT when its communicator is created; stdout must carry the one JSON
+        # line only, so the native stdout is pointed at stderr while the group and its first collective come up
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend="gloo")
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     # ---- this rank's shard of the synthetic dataset (weak scaling: fixed objects per GPU) ----
     n_obj = args.objects
