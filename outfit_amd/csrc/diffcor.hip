@@ -43,7 +43,9 @@ __device__ __forceinline__ unsigned group_sum(unsigned v) {
 // kG lanes on identical inputs. The kernel is bound by the serial chain of its slowest trajectory
 // (iterations x observations), not by throughput: kG lanes cut that chain by almost kG.
 template <unsigned kG>
-__global__ void __launch_bounds__(64, 2)
+// one wave per SIMD: with the correctly-rounded functions inlined the kernel wants ~480 registers; at (64, 2) the
+// compiler spilled 366 VGPRs to scratch (2.35 ms per 100 k objects), with the full file the overflow lives in AGPRs (2.02 ms)
+__global__ void __launch_bounds__(64, 1)
 k_diffcor(DiffCorArgs A) {
   // normal matrix (36), right-hand side (6) and weighted square sum (1) accumulate in LDS, [entry][slot]
   constexpr unsigned kSlots = 64 / kG;
