@@ -103,7 +103,7 @@ struct outfit_hip_session {
   bool noise_device = false;
   unsigned long long noise_seed = 0, traj_key_base = 0;
   DevBuf<double> mjd, ra, dec, sra, sdec, helio, geo, obs_pos, cos_dec, unit[2], noise, coef;
-  DevBuf<double> heap_w, sum, el, dirS, roots, state, psi0;
+  DevBuf<double> heap_w, sum, dirS, roots, state, psi0;
   DevBuf<unsigned long long> heap_id, triplets[2], queue, slow_list, slow_count;
   DevBuf<unsigned> n_triplets[2], flags, n_win;
   unsigned n_cu = 256;
@@ -141,7 +141,7 @@ struct outfit_hip_session {
   void free_all() {
     traj_offset.release(); traj_key.release(); mjd.release(); ra.release(); dec.release(); sra.release(); sdec.release();
     helio.release(); geo.release(); obs_pos.release(); cos_dec.release(); unit[0].release(); unit[1].release(); noise.release(); coef.release();
-    heap_w.release(); sum.release(); el.release(); dirS.release(); roots.release(); state.release();
+    heap_w.release(); sum.release(); dirS.release(); roots.release(); state.release();
     psi0.release(); slow_list.release(); slow_count.release();
     heap_id.release(); triplets[0].release(); triplets[1].release(); queue.release();
     n_triplets[0].release(); n_triplets[1].release(); flags.release();
@@ -321,7 +321,6 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
   HIP_TRY(s->flags.alloc(n_cand));
   HIP_TRY(s->n_win.alloc(n_cand));
   HIP_TRY(s->sum.alloc(n_cand));
-  HIP_TRY(s->el.alloc(6 * n_cand));
   HIP_TRY(s->dirS.alloc(9 * n_cand));
   HIP_TRY(s->roots.alloc((size_t)outfit::kRootSlots * n_cand));
   HIP_TRY(s->state.alloc(7 * n_cand));
@@ -439,7 +438,7 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
     ci.noise_device = s->noise_device; ci.noise_seed = s->noise_seed; ci.traj_key_base = s->traj_key_base;
     ci.traj_key = s->traj_key.p;
     outfit::CandidateScratch w{};
-    w.flags = s->flags.p; w.S = s->dirS.p; w.roots = s->roots.p; w.state = s->state.p; w.el = s->el.p;
+    w.flags = s->flags.p; w.S = s->dirS.p; w.roots = s->roots.p; w.state = s->state.p;
     w.sum = s->sum.p; w.n_win = s->n_win.p; w.psi0 = s->psi0.p; w.slow_list = s->slow_list.p;
     w.slow_count = s->slow_count.p;
 

@@ -53,9 +53,29 @@ struct Elements {
   double e[6];
 };
 
+// Platform or correctly-rounded elementary functions, chosen per caller: the candidate RMS (K2c, 2x10^8
+// observation evaluations per step) keeps the platform functions — they move the RMS by <= 1e-9 relative, never the
+// returned elements; the differential corrector (ill-conditioned normal equations amplify a last place up to
+// 1e13 times) uses the correctly-rounded ones and is then bit-identical to the oracle.
+template <bool kCr> __device__ __forceinline__ void sincos_sel(double x, double& s, double& c) {
+  if constexpr (kCr) crm::sincos(x, s, c); else ::sincos(x, &s, &c);
+}
+template <bool kCr> __device__ __forceinline__ double atan2_sel(double y, double x) {
+  if constexpr (kCr) return crm::atan2(y, x); else return ::atan2(y, x);
+}
+template <bool kCr> __device__ __forceinline__ double tan_sel(double x) {
+  if constexpr (kCr) return crm::tan(x); else return ::tan(x);
+}
+template <bool kCr> __device__ __forceinline__ double hypot_sel(double x, double y) {
+  if constexpr (kCr) return crm::hypot(x, y); else return ::hypot(x, y);
+}
+
 // orb_elem.rs:58-226 (input already rotated to the ecliptic frame). The angles and the rotation's sines and
 // cosines are correctly rounded (crmath.hpp): a last-place difference of i or Omega is amplified ~a/r in the
 // near-parabolic 1/a and ~1/e in omega and M of a near-circular orbit, and these are the returned elements.
+// kCr = false (platform functions, ~900 instructions cheaper) serves the RMS evaluation of every candidate in K2c;
+// the elements that are RETURNED are recomputed with kCr = true for the selected candidate only (K3).
+template <bool kCr = true>
 __device__ __forceinline__ Elements ccek1(const Vec3& pos, const Vec3& vel, double epoch) {
   constexpr double EPS_EQ = 1e-15, EPS_PARAB = 1e-12, EPS_E = 5e-15;
   Elements out;
@@ -65,13 +85,13 @@ __device__ __forceinline__ Elements ccek1(const Vec3& pos, const Vec3& vel, doub
   const double hn = sqrt(h2);
   const Vec3 hu = {h.x / hn, h.y / hn, h.z / hn};
   const double sin_i = sqrt(hu.x * hu.x + hu.y * hu.y);
-  double inc = principal_angle(crm::atan2(sin_i, hu.z));
+  double inc = principal_angle(atan2_sel<kCr>(sin_i, hu.z));
   double node;
   if (sin_i <= EPS_EQ) { inc = 0.0; node = 0.0; }
-  else node = principal_angle(crm::atan2(hu.x, -hu.y));
+  else node = principal_angle(atan2_sel<kCr>(hu.x, -hu.y));
   double si, ci, sn, cn;
-  crm::sincos(inc, si, ci);
-  crm::sincos(node, sn, cn);
+  sincos_sel<kCr>(inc, si, ci);
+  sincos_sel<kCr>(node, sn, cn);
   // rotmt(i,0)^T * rotmt(Om,2)^T: every entry is a single product (ref_system.rs:453-462)
   const double m10 = ci * (-sn), m11 = ci * cn, m20 = (-si) * (-sn), m21 = (-si) * cn;
   const Vec3 po = {(cn * pos.x + sn * pos.y) + 0.0 * pos.z, (m10 * pos.x + m11 * pos.y) + si * pos.z,
@@ -92,9 +112,9 @@ __device__ __forceinline__ Elements ccek1(const Vec3& pos, const Vec3& vel, doub
     if (fabs(e - 1.0) < EPS_E) {
       parabolic = true;
     } else {
-      const double ea = crm::atan2(esin, ecos);
+      const double ea = atan2_sel<kCr>(esin, ecos);
       double sea, cea;
-      crm::sincos(ea, sea, cea);
+      sincos_sel<kCr>(ea, sea, cea);
       const double ma = principal_angle(ea - e * sea);
       const double x1 = cea - e;
       const double x2 = sqrt(1.0 - e * e) * sea;
@@ -104,7 +124,7 @@ __device__ __forceinline__ Elements ccek1(const Vec3& pos, const Vec3& vel, doub
       const double cp = x1n * po.x + x2n * po.y;
       out.kind = 0;
       out.e[0] = a; out.e[1] = e; out.e[2] = inc; out.e[3] = node;
-      out.e[4] = principal_angle(crm::atan2(sp, cp));
+      out.e[4] = principal_angle(atan2_sel<kCr>(sp, cp));
       out.e[5] = ma;
       return out;
     }
@@ -114,14 +134,14 @@ __device__ __forceinline__ Elements ccek1(const Vec3& pos, const Vec3& vel, doub
     const double p = h2 / kMu;
     const double ecos = p / rad - 1.0;
     const double esin = rv * p / (hn * rad);
-    const double nu = crm::atan2(esin, ecos);
+    const double nu = atan2_sel<kCr>(esin, ecos);
     const double e = sqrt(ecos * ecos + esin * esin);
     if (fabs(e - 1.0) < EPS_E) {
       parabolic = true;
     } else {
       out.kind = 1;
       out.e[0] = p / (1.0 + e); out.e[1] = e; out.e[2] = inc; out.e[3] = node;
-      out.e[4] = principal_angle(crm::atan2(po.y, po.x) - nu);
+      out.e[4] = principal_angle(atan2_sel<kCr>(po.y, po.x) - nu);
       out.e[5] = nu;
       return out;
     }
@@ -131,10 +151,10 @@ __device__ __forceinline__ Elements ccek1(const Vec3& pos, const Vec3& vel, doub
   const double p = h2 / kMu;
   const double cnu = p / rad - 1.0;
   const double snu = rv * p / (rad * hn);
-  const double nu = crm::atan2(snu, cnu);
+  const double nu = atan2_sel<kCr>(snu, cnu);
   out.kind = 1;
   out.e[0] = p / 2.0; out.e[1] = 1.0; out.e[2] = inc; out.e[3] = node;
-  out.e[4] = principal_angle(crm::atan2(po.y, po.x) - nu);
+  out.e[4] = principal_angle(atan2_sel<kCr>(po.y, po.x) - nu);
   out.e[5] = nu;
   return out;
 }
@@ -179,23 +199,6 @@ __device__ __forceinline__ void sincos_k(double x, const SinCosConsts& K, double
   const double a = (q & 1) ? cr : sr, b = (q & 1) ? sr : cr;
   s = (q & 2) ? -a : a;
   c = ((q + 1) & 2) ? -b : b;
-}
-
-// Platform or correctly-rounded elementary functions, chosen per caller: the candidate RMS (K2c, 2x10^8
-// observation evaluations per step) keeps the platform functions — they move the RMS by <= 1e-9 relative, never the
-// returned elements; the differential corrector (ill-conditioned normal equations amplify a last place up to
-// 1e13 times) uses the correctly-rounded ones and is then bit-identical to the oracle.
-template <bool kCr> __device__ __forceinline__ void sincos_sel(double x, double& s, double& c) {
-  if constexpr (kCr) crm::sincos(x, s, c); else ::sincos(x, &s, &c);
-}
-template <bool kCr> __device__ __forceinline__ double atan2_sel(double y, double x) {
-  if constexpr (kCr) return crm::atan2(y, x); else return ::atan2(y, x);
-}
-template <bool kCr> __device__ __forceinline__ double tan_sel(double x) {
-  if constexpr (kCr) return crm::tan(x); else return ::tan(x);
-}
-template <bool kCr> __device__ __forceinline__ double hypot_sel(double x, double y) {
-  if constexpr (kCr) return crm::hypot(x, y); else return ::hypot(x, y);
 }
 
 // equinoctial_element.rs:285-313

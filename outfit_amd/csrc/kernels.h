@@ -100,7 +100,6 @@ struct CandidateScratch {
   unsigned long long* slow_list;   // [n_cand] candidates for the general kernel
   unsigned long long* slow_count;  // [1]
   double* state;     // [7][n_cand]   r2[3], v2[3], epoch (equatorial J2000)
-  double* el;        // [6][n_cand]
   double* sum;       // [n_cand]
   unsigned* n_win;   // [n_cand]
 };

@@ -580,10 +580,10 @@ k_orbit_rms(RmsArgs a) {
   const double epoch = a.W.state[6 * n + cid];
 
   // build_result -> compute_orbit_from_state -> ccek1 (gauss.rs:906-923,1063-1076)
-  const Elements el = ccek1(equ_to_ecl(r2), equ_to_ecl(v2), epoch);
+  // platform functions here: these elements only feed the candidate's RMS; the selected candidate's elements are
+  // recomputed correctly rounded in K3 from the same state
+  const Elements el = ccek1<false>(equ_to_ecl(r2), equ_to_ecl(v2), epoch);
   unsigned flags = (f0 & (kFlagOk | kFlagCorrected | kFlagSlow)) | (el.kind ? kFlagCometary : 0u);
-#pragma unroll
-  for (int k = 0; k < 6; ++k) a.W.el[(unsigned long long)k * n + cid] = el.e[k];
 
   Equinoctial eq;
   const int conv = to_equinoctial(el, eq);
@@ -699,11 +699,17 @@ k_select_best(SelectArgs a) {
       const unsigned f = a.W.flags[cid];
       out.status = 0;
       out.stage = (f & kFlagCorrected) ? 1 : 0;
-      out.kind = (f & kFlagCometary) ? 1 : 0;
       out.best_triplet = (unsigned)best_c / a.n_real;
       out.best_realization = (unsigned)best_c % a.n_real;
-      out.epoch = a.W.state[6 * a.n_cand + cid];
-      for (int k = 0; k < 6; ++k) out.elem[k] = a.W.el[(unsigned long long)k * a.n_cand + cid];
+      // build_result -> compute_orbit_from_state -> ccek1 (gauss.rs:906-923,1063-1076) for the winner, with the
+      // correctly-rounded functions: these are the elements the caller gets
+      const unsigned long long nc = a.n_cand;
+      const Vec3 r2 = {a.W.state[0 * nc + cid], a.W.state[1 * nc + cid], a.W.state[2 * nc + cid]};
+      const Vec3 v2 = {a.W.state[3 * nc + cid], a.W.state[4 * nc + cid], a.W.state[5 * nc + cid]};
+      out.epoch = a.W.state[6 * nc + cid];
+      const Elements el = ccek1<true>(equ_to_ecl(r2), equ_to_ecl(v2), out.epoch);
+      out.kind = el.kind;
+      for (int k = 0; k < 6; ++k) out.elem[k] = el.e[k];
       out.rms = best;
     } else {
       out.status = 2;  // NoViableOrbit{cause, attempts}
