@@ -18,10 +18,13 @@ batch.noise_seed = 42
 s = outfit_amd.IODSession(batch, ephem, params)
 s.run()
 r = s.results()
+s.set_profiling(True)
 t = time.perf_counter()
 for _ in range(5):
     s.run()
 r = s.results()
 dt = (time.perf_counter() - t) / 5
+print({k: round(v[0] / 5, 2) for k, v in s.kernel_times().items()})
+s.set_profiling(False)
 print(f"{n} objects, default params, device noise: {1e3 * dt:.2f} ms/step = {n / dt:.3e} objects/s = "
       f"{n * 210 / dt:.3e} candidates/s; orbits {(r['status'] == 0).sum()}, noisy winner {(r['best_realization'] > 0).mean():.2f}")
