@@ -391,7 +391,8 @@ int outfit_hip_selftest_aberth(uint64_t n_polys, uint64_t seed, uint64_t *counts
 int outfit_hip_selftest_crmath(uint64_t n_args, uint64_t seed, uint64_t *counts /* [4] */);
 /* The device's correctly-rounded functions on caller-given arguments (host arrays of n doubles), for checks
  * against high-precision known answers: fn & 15 = 0 sin, 1 cos, 2 acos, 3 sinh, 4 cosh, 5 log (y > 1), 6 atan2
- * (x then holds n pairs y, x);
+ * (x then holds n pairs y, x), 7 / 8 = sin / cos as the residual loop of the RMS stage evaluates them (~1 ulp, not
+ * correctly rounded);
  * fn & 16 selects the full double-double evaluation instead of the table fast path + rounding test. */
 int outfit_hip_crmath_eval(int fn, uint64_t n, const double *x, double *out);
 const char *outfit_hip_last_error(void); /* thread-local, never NULL */

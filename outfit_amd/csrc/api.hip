@@ -960,7 +960,7 @@ int outfit_hip_selftest_crmath(uint64_t n_args, uint64_t seed, uint64_t* counts)
 }
 
 int outfit_hip_crmath_eval(int fn, uint64_t n, const double* x, double* out) {
-  if ((fn & 15) > 6 || (fn & ~31)) return fail(OUTFIT_ERR_INVALID_PARAM, "fn: 0 sin, 1 cos, 2 acos, 3 sinh, 4 cosh, 5 log, 6 atan2 (+16: full evaluation)");
+  if ((fn & 15) > 8 || (fn & ~31)) return fail(OUTFIT_ERR_INVALID_PARAM, "fn: 0 sin, 1 cos, 2 acos, 3 sinh, 4 cosh, 5 log, 6 atan2 (+16: full evaluation), 7 / 8 sin / cos of the residual loop");
   if (n && (!x || !out)) return fail(OUTFIT_ERR_INVALID_BATCH, "NULL argument");
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)

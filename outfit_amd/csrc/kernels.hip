@@ -913,10 +913,10 @@ k_selftest_crmath(unsigned long long n_per_thread, unsigned long long seed, unsi
 }
 
 // outfit_hip_crmath_eval: the device's correctly-rounded functions on given arguments (checked against
-// high-precision known answers by the tests). fn & 15: 0 sin, 1 cos, 2 acos, 3 sinh, 4 cosh, 5 log, 6 atan2 (x holds n pairs y, x); fn & 16: the
+// high-precision known answers by the tests). fn & 15: 0 sin, 1 cos, 2 acos, 3 sinh, 4 cosh, 5 log, 6 atan2 (x holds n pairs y, x), 7 / 8 sin / cos of K2c's sincos_k; fn & 16: the
 // full double-double evaluation instead of Ziv's two steps.
 __global__ void __launch_bounds__(256)
-k_crmath_eval(int fn, unsigned long long n, const double* x, double* out) {
+k_crmath_eval(int fn, unsigned long long n, const double* x, double* out, SinCosConsts sc) {
   const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const bool slow = (fn & 16) != 0;
@@ -926,6 +926,11 @@ k_crmath_eval(int fn, unsigned long long n, const double* x, double* out) {
   }
   const double v = x[i];
   double a = 0.0, b = 0.0, r;
+  if ((fn & 15) == 7 || (fn & 15) == 8) {  // K2c's kernel-argument-constant sincos (not correctly rounded: ~1 ulp)
+    sincos_k(v, sc, a, b);
+    out[i] = (fn & 15) == 7 ? a : b;
+    return;
+  }
   switch (fn & 15) {
     case 0: case 1:
       if (slow) crm::sincos_slow(v, a, b); else crm::sincos(v, a, b);
@@ -972,7 +977,7 @@ hipError_t launch_selftest_crmath(unsigned long long n_threads, unsigned long lo
 }
 hipError_t launch_crmath_eval(int fn, unsigned long long n, const double* x, double* out, hipStream_t s) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_crmath_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fn, n, x, out);
+  hipLaunchKernelGGL(k_crmath_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fn, n, x, out, sincos_consts());
   return hipGetLastError();
 }
 hipError_t launch_selftest_division(unsigned long long n_threads, unsigned long long n_per_thread,

@@ -118,3 +118,18 @@ def test_device_crmath_matches_mpmath_vectors(slow):
     flat = np.ascontiguousarray(yx.reshape(-1))
     assert _lib.lib().outfit_hip_crmath_eval(6 | slow, len(rows), flat.ctypes.data_as(dp), out.ctypes.data_as(dp)) == 0
     assert np.array_equal(out, ea), yx[out != ea][:5]
+
+
+@pytest.mark.gpu
+def test_device_residual_loop_sincos_is_accurate():
+    """K2c's own sincos (polynomial constants as kernel arguments, device/orbit.hpp) against the correctly-rounded
+    values: within 2 ulp over the angles Kepler's equation sees and far beyond (it only feeds the RMS)."""
+    g = json.load(open(os.path.join(HERE, "golden", "crmath_vectors.json")))
+    x = np.array([float.fromhex(r[0]) for r in g["sincos"]])
+    for fn, col in ((7, 1), (8, 2)):
+        want = np.array([float.fromhex(r[col]) for r in g["sincos"]])
+        got = _device_eval(fn, x)
+        ulp = np.spacing(np.abs(want))
+        big = np.abs(want) > 1e-3           # near a zero of sin/cos the 3-part reduction leaves an absolute 1e-19
+        assert (np.abs(got - want)[big] <= 2 * ulp[big]).all(), np.max(np.abs(got - want)[big] / ulp[big])
+        assert (np.abs(got - want)[~big] <= 1e-18 + 2 * ulp[~big]).all()
