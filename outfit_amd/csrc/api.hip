@@ -423,7 +423,11 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
   //     k0  :  K0(0) K0(1) K0(2) K0(3)
   //     aux :                                               general
   //     main:        K2a(0) K2a(1) K2a(2) K2a(3) prelim fast         rms(regular) rms(slow) select
-  constexpr unsigned kSub = 4;
+  unsigned kSub = 4;
+  if (const char* e = std::getenv("OUTFIT_K0_SLICES")) {  // tuning aid
+    const int v = std::atoi(e);
+    if (v == 1 || v == 2 || v == 4) kSub = (unsigned)v;
+  }
   for (uint64_t t0 = 0; t0 < s->n_traj; t0 += s->chunk) {
     const uint64_t nt = std::min<uint64_t>(s->chunk, s->n_traj - t0);
     const unsigned long long n_cand = (unsigned long long)nt * s->cand_per_traj;
