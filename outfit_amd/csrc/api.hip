@@ -130,7 +130,8 @@ struct outfit_hip_session {
   hipEvent_t ev_unit_free[2] = {nullptr, nullptr};  // last K2a reading unit buffer b has finished
   bool unit_free_recorded[2] = {false, false};
   unsigned long long chunk_seq = 0, run_seq = 0;
-  hipEvent_t ev_start = nullptr, ev_prepass = nullptr, ev_fast = nullptr, ev_general = nullptr, ev_sub[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_start = nullptr, ev_prepass = nullptr, ev_fast = nullptr, ev_general = nullptr;
+  hipEvent_t ev_sub[8] = {};
   hipStream_t last_stream = nullptr;
   bool profiling = false;
   struct Timed { int id; hipEvent_t a, b; };
@@ -160,7 +161,8 @@ struct outfit_hip_session {
         if (arr[b]) (void)hipEventDestroy(arr[b]);
         arr[b] = nullptr;
       }
-    for (hipEvent_t* e : {&ev_start, &ev_prepass, &ev_fast, &ev_general, &ev_sub[0], &ev_sub[1], &ev_sub[2], &ev_sub[3]}) {
+    for (hipEvent_t* e : {&ev_start, &ev_prepass, &ev_fast, &ev_general, &ev_sub[0], &ev_sub[1], &ev_sub[2], &ev_sub[3],
+                          &ev_sub[4], &ev_sub[5], &ev_sub[6], &ev_sub[7]}) {
       if (*e) (void)hipEventDestroy(*e);
       *e = nullptr;
     }
@@ -227,7 +229,8 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
   HIP_TRY(hipStreamCreateWithFlags(&s->k0_stream, hipStreamNonBlocking));
   for (hipEvent_t& e : s->ev_k3) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (hipEvent_t& e : s->ev_unit_free) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  for (hipEvent_t* e : {&s->ev_start, &s->ev_prepass, &s->ev_fast, &s->ev_general, &s->ev_sub[0], &s->ev_sub[1], &s->ev_sub[2], &s->ev_sub[3]})
+  for (hipEvent_t* e : {&s->ev_start, &s->ev_prepass, &s->ev_fast, &s->ev_general, &s->ev_sub[0], &s->ev_sub[1], &s->ev_sub[2], &s->ev_sub[3],
+                        &s->ev_sub[4], &s->ev_sub[5], &s->ev_sub[6], &s->ev_sub[7]})
     HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
   s->params = *params;
   s->n_traj = b->n_traj;
@@ -426,7 +429,7 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
   unsigned kSub = 4;
   if (const char* e = std::getenv("OUTFIT_K0_SLICES")) {  // tuning aid
     const int v = std::atoi(e);
-    if (v == 1 || v == 2 || v == 4) kSub = (unsigned)v;
+    if (v == 1 || v == 2 || v == 4 || v == 8) kSub = (unsigned)v;
   }
   for (uint64_t t0 = 0; t0 < s->n_traj; t0 += s->chunk) {
     const uint64_t nt = std::min<uint64_t>(s->chunk, s->n_traj - t0);
