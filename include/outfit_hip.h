@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define OUTFIT_HIP_ABI_VERSION 4
+#define OUTFIT_HIP_ABI_VERSION 5
 
 /* ---- whole-call return codes --------------------------------------------- */
 #define OUTFIT_OK                 0
@@ -172,6 +172,25 @@ typedef struct outfit_gauss_result {
 void outfit_hip_iod_params_default(outfit_iod_params_t *p);
 /* IODParamsBuilder::build validation (mod.rs:544-624); 0 or OUTFIT_ERR_INVALID_PARAM. */
 int  outfit_hip_iod_params_validate(const outfit_iod_params_t *p);
+
+/* ---- math mode ----------------------------------------------------------------
+ * Which bits the elementary functions return that feed the correction loop and the returned elements
+ * (direction cosines gauss.rs:488-502, cold starts prelim_elliptic.rs / prelim_hyperbolic.rs, the rotations of
+ * orb_elem.rs:58-226). The reference calls the platform libm there, so its own results depend on that libm; the
+ * loop amplifies a last-place difference to ~1e-10.
+ *   OUTFIT_MATH_CORRECTLY_ROUNDED (default): every such function correctly rounded — platform independent;
+ *       against a glibc run of the reference ~0.8 % of the orbits move by more than 1e-12 rad.
+ *   OUTFIT_MATH_GLIBC: sin, cos, sinh, cosh return the bits of glibc 2.35 on x86-64 (restated, device/glibcmath.hpp);
+ *       acos, log, atan2 stay correctly rounded (glibc's differ from that for 7e-4 / 2e-4 / 9e-4 of arguments).
+ *       Measured against the reference's arithmetic on glibc: integer outputs identical, no orbit beyond
+ *       1e-10 AU / 1e-12 rad (tests/test_gpu_glibc_mode.py).
+ * Process-wide; read when a session is created (sessions keep the mode they were created with) and at the start
+ * of every blocking call. The initial value comes from the environment variable OUTFIT_MATH_MODE ("glibc" / "cr").
+ * The differential corrector (fit_lsq) evaluates all its functions correctly rounded in both modes. */
+#define OUTFIT_MATH_CORRECTLY_ROUNDED 0
+#define OUTFIT_MATH_GLIBC             1
+int outfit_hip_set_math_mode(int mode); /* 0 or OUTFIT_ERR_INVALID_PARAM */
+int outfit_hip_get_math_mode(void);
 
 /* ---- blocking drop-in entry point ------------------------------------------
  * Replaces the body of fit_full_iod / fit_full_iod_parallel after prepare_iod
@@ -392,9 +411,13 @@ int outfit_hip_selftest_crmath(uint64_t n_args, uint64_t seed, uint64_t *counts 
 /* The device's correctly-rounded functions on caller-given arguments (host arrays of n doubles), for checks
  * against high-precision known answers: fn & 15 = 0 sin, 1 cos, 2 acos, 3 sinh, 4 cosh, 5 log (y > 1), 6 atan2
  * (x then holds n pairs y, x), 7 / 8 = sin / cos as the residual loop of the RMS stage evaluates them (~1 ulp, not
- * correctly rounded);
+ * correctly rounded); 9 / 10 / 11 / 12 = sin / cos / sinh / cosh of OUTFIT_MATH_GLIBC (device/glibcmath.hpp);
  * fn & 16 selects the full double-double evaluation instead of the table fast path + rounding test. */
 int outfit_hip_crmath_eval(int fn, uint64_t n, const double *x, double *out);
+/* `prelim_kepuni` (kepler/params.rs:185-191), the cold-start value of the universal Kepler solve, for n explicit
+ * problems of 6 doubles (dt, r0, sig0, alpha, e0, convergency; mu = GAUSS_GRAV^2), in the current math mode —
+ * the reference's libm-dependent KAT (kepler/params.rs:689-725) is checked through this. */
+int outfit_hip_prelim_kepuni(uint64_t n, const double *problems /* 6n */, double *out /* n */);
 const char *outfit_hip_last_error(void); /* thread-local, never NULL */
 int         outfit_hip_abi_version(void);
 int         outfit_hip_device_count(void);

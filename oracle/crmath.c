@@ -18,6 +18,13 @@
 #include "oracle.h"
 
 int orc_use_libm = 0; /* 1 = plain libm sin/cos/acos (platform-dependent), 0 = correctly rounded */
+/* study aid: per-function platform-libm selection when orc_use_libm == 0
+ * (1 sin/cos, 2 acos, 4 sinh/cosh, 8 log, 16 atan2, 32 Aberth start directions) */
+int orc_libm_mask = 0;
+#define LIBM(bit) (orc_use_libm || (orc_libm_mask & (bit)))
+/* 1 = sin, cos, sinh, cosh as glibc 2.35 evaluates them (glibcmath.c: restated, no libm call), everything else
+ * as in the default mode — what the device's OUTFIT_MATH_GLIBC mode computes. orc_use_libm = 1 overrides it. */
+int orc_math_glibc = 0;
 
 #define CRM_PIO2_P1 1.5707963267341256     /* 0x1.921fb54400000p+0  */
 #define CRM_PIO2_P2 6.077100506303966e-11  /* 0x1.0b4611a600000p-34 */
@@ -174,7 +181,8 @@ static void sincos_dd(double x, dd *s, dd *c) {
 }
 
 void orc_sincos(double x, double *s, double *c) {
-  if (orc_use_libm || !(fabs(x) < 1048576.0)) { *s = sin(x); *c = cos(x); return; }
+  if (LIBM(1) || !(fabs(x) < 1048576.0)) { *s = sin(x); *c = cos(x); return; }
+  if (orc_math_glibc) { *s = orc_glibc_sin(x); *c = orc_glibc_cos(x); return; }
   if (x == 0.0) { *s = x; *c = 1.0; return; }
   dd sd, cd;
   sincos_dd(x, &sd, &cd);
@@ -186,7 +194,7 @@ double orc_cos(double x) { double s, c; orc_sincos(x, &s, &c); return c; }
 
 /* acos by one Newton step in double-double from the libm seed: y1 = y0 + (cos y0 - x)/sin y0 */
 double orc_acos(double x) {
-  if (orc_use_libm || !(fabs(x) <= 1.0)) return acos(x);
+  if (LIBM(2) || !(fabs(x) <= 1.0)) return acos(x);
   if (x == 1.0) return 0.0;
   if (x == -1.0) return CRM_PI_HI;
   double y0 = acos(x);
@@ -206,12 +214,12 @@ double orc_acos(double x) {
  * relative of a rounding boundary) — an implementation independent of the device's double-double one
  * (outfit_amd/csrc/device/crmath.hpp), both pinned by tests/golden/crmath_hyp_vectors.json (mpmath). */
 #include <quadmath.h>
-double orc_sinh(double x) { return orc_use_libm ? sinh(x) : (double)sinhq((__float128)x); }
-double orc_cosh(double x) { return orc_use_libm ? cosh(x) : (double)coshq((__float128)x); }
-double orc_log(double x) { return orc_use_libm ? log(x) : (double)logq((__float128)x); }
+double orc_sinh(double x) { return LIBM(4) ? sinh(x) : orc_math_glibc ? orc_glibc_sinh(x) : (double)sinhq((__float128)x); }
+double orc_cosh(double x) { return LIBM(4) ? cosh(x) : orc_math_glibc ? orc_glibc_cosh(x) : (double)coshq((__float128)x); }
+double orc_log(double x) { return LIBM(8) ? log(x) : (double)logq((__float128)x); }
 /* atan2 of the state -> elements conversion (orb_elem.rs:58-226): a last-place difference of i or Omega is
  * amplified ~a/r in a near-parabolic 1/a and ~1/e in omega, M of a near-circular orbit. */
-double orc_atan2(double y, double x) { return orc_use_libm ? atan2(y, x) : (double)atan2q((__float128)y, (__float128)x); }
+double orc_atan2(double y, double x) { return LIBM(16) ? atan2(y, x) : (double)atan2q((__float128)y, (__float128)x); }
 
 /* ---- scoped selection: the differential corrector evaluates ALL its elementary functions correctly rounded
  * (its ill-conditioned normal equations amplify a last place up to 1e13 times; the device does the same and is

@@ -43,7 +43,16 @@ extern "C" {
 #define ORC_SECONDS_PER_DAY 86400.0   /* constants.rs:34 */
 
 /* ---- crmath.c: correctly-rounded sin/cos/acos (see the header of that file) ---- */
+extern int orc_libm_mask; /* per-function platform-libm selection (study aid, crmath.c) */
 extern int orc_use_libm; /* 1 = platform libm instead (results then depend on the libm) */
+extern int orc_math_glibc; /* 1 = sin/cos/sinh/cosh restated from glibc 2.35 (glibcmath.c), the rest correctly rounded */
+double orc_glibc_sin(double x);   /* glibcmath.c */
+double orc_glibc_cos(double x);
+double orc_glibc_expm1(double x);
+double orc_glibc_exp(double x);
+double orc_glibc_sinh(double x);
+double orc_glibc_cosh(double x);
+void   orc_glibc_compare_with_host(uint64_t n, uint64_t seed, uint64_t *counts /* [6] */);
 extern const double orc_aberth_cos_sin[8][2];
 void   orc_sincos(double x, double *s, double *c);
 double orc_sin(double x);

@@ -7,7 +7,7 @@ src/initial_orbit_determination/obs_dataset_api.rs:145-296).
 """
 import ctypes as C
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 OUTFIT_OK = 0
 OUTFIT_ERR_INVALID_PARAM = -1

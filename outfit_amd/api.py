@@ -333,6 +333,36 @@ def record_to_result(rec, batch=None, traj_index=None, params=None):
     return OutfitError(f"unknown status {st}")
 
 
+# ----------------------------------------------------------------------------- math mode
+MATH_CORRECTLY_ROUNDED, MATH_GLIBC = 0, 1
+
+
+def set_math_mode(mode):
+    """Process-wide OUTFIT_MATH_* (include/outfit_hip.h): which bits sin/cos/sinh/cosh return in the functions that
+    feed the correction loop. Sessions keep the mode they were created with."""
+    rc = lib().outfit_hip_set_math_mode(int(mode))
+    if rc != 0:
+        _raise_rc(rc)
+
+
+def get_math_mode():
+    return lib().outfit_hip_get_math_mode()
+
+
+class math_mode:
+    """Context manager: `with math_mode(MATH_GLIBC): ...`"""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = get_math_mode()
+        set_math_mode(self.mode)
+
+    def __exit__(self, *exc):
+        set_math_mode(self.prev)
+
+
 # ----------------------------------------------------------------------------- entry points
 def fit_full_iod_records(batch, ephem, params, n_devices=0):
     """The blocking C-ABI call; returns the raw records (numpy structured array)."""

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -23,6 +24,19 @@
 namespace {
 
 thread_local std::string g_last_error;
+
+// process-wide math mode (include/outfit_hip.h); -1 = not yet initialised from the environment
+std::atomic<int> g_math_mode{-1};
+int current_math_mode() {
+  int m = g_math_mode.load();
+  if (m < 0) {
+    const char* e = std::getenv("OUTFIT_MATH_MODE");
+    m = (e && (std::string(e) == "glibc" || std::string(e) == "1")) ? OUTFIT_MATH_GLIBC : OUTFIT_MATH_CORRECTLY_ROUNDED;
+    int expected = -1;
+    if (!g_math_mode.compare_exchange_strong(expected, m)) m = expected;
+  }
+  return m;
+}
 
 int fail(int code, const std::string& msg) {
   g_last_error = msg;
@@ -94,6 +108,7 @@ const char* const kKernelNames[K_COUNT] = {"k_triplet_select", "k_observer_prepa
 struct outfit_hip_session {
   int device = 0;
   outfit_iod_params_t params{};
+  int math_mode = 0;  // OUTFIT_MATH_* captured at creation
   uint64_t n_traj = 0, n_obs = 0;
   bool has_ephem = false, has_geo = false;
   unsigned n_real = 1, k_cap = 0, cand_per_traj = 0;
@@ -233,6 +248,7 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
                         &s->ev_sub[4], &s->ev_sub[5], &s->ev_sub[6], &s->ev_sub[7]})
     HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
   s->params = *params;
+  s->math_mode = current_math_mode();
   s->n_traj = b->n_traj;
   const uint64_t o0 = b->n_traj ? b->traj_offset[0] : 0;
   s->n_obs = b->n_traj ? b->traj_offset[b->n_traj] - o0 : 0;
@@ -349,6 +365,7 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
   s->gp.aberth_max_iter = params->aberth_max_iter;
   s->gp.max_tested_solutions = saturate_u32(params->max_tested_solutions);
   s->gp.newton_max_it = saturate_u32(params->newton_max_it);
+  s->gp.math_mode = s->math_mode;
   s->tp.dt_min = params->dt_min;
   s->tp.dt_max = params->dt_max_triplet;
   s->tp.inv_dtw = 1.0 / params->optimal_interval_time;  // f64::recip (mod.rs:347)
@@ -400,7 +417,7 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
   outfit::PrepassArgs pa{};
   pa.n_obs = s->n_obs; pa.mjd = s->mjd.p; pa.dec = s->dec.p; pa.geo_ecl = s->geo.p; pa.obs_pos = s->obs_pos.p;
   pa.cos_dec = s->cos_dec.p; pa.unit = s->unit[ub].p; pa.ra = s->ra.p; pa.has_table = on_device_earth;
-  pa.T = s->table; pa.error_flag = s->error_flag.p;
+  pa.T = s->table; pa.error_flag = s->error_flag.p; pa.math_mode = s->math_mode;
   {
     // the buffer's previous readers: the K2a launches of the run before the previous one
     if (s->unit_free_recorded[ub]) HIP_TRY(hipStreamWaitEvent(s->k0_stream, s->ev_unit_free[ub], 0));
@@ -510,6 +527,7 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
     sa.n_traj = nt; sa.traj0 = t0; sa.n_cand = n_cand; sa.cand_per_traj = s->cand_per_traj;
     sa.n_real = s->n_real; sa.n_triplets = s->n_triplets[tb].p; sa.W = w;
     sa.out = d_out ? d_out : s->results.p;
+    sa.math_mode = s->math_mode;
     {
       Stamp stamp(s, st, K_SELECT);
       HIP_TRY(outfit::launch_select_best(sa, st));
@@ -571,7 +589,7 @@ int session_run_lsq(outfit_hip_session* s, const outfit_diffcor_config_t* cfg,
     pa.n_obs = s->n_obs; pa.mjd = s->mjd.p; pa.dec = s->dec.p; pa.geo_ecl = s->geo.p; pa.obs_pos = s->obs_pos.p;
     pa.cos_dec = s->cos_dec.p; pa.unit = s->unit[0].p; pa.ra = s->ra.p; pa.has_table = on_device_earth;
     pa.parts = outfit::kPrepassObserver;  // the corrector reads obs_pos only
-    pa.T = s->table; pa.error_flag = s->error_flag.p;
+    pa.T = s->table; pa.error_flag = s->error_flag.p; pa.math_mode = s->math_mode;
     Stamp stamp(s, st, K_PREPASS);
     HIP_TRY(outfit::launch_observer_prepass(pa, st));
     s->prepass_done = true;
@@ -686,6 +704,14 @@ int outfit_hip_iod_params_validate(const outfit_iod_params_t* p) {
 }
 
 const char* outfit_hip_last_error(void) { return g_last_error.c_str(); }
+
+int outfit_hip_set_math_mode(int mode) {
+  if (mode != OUTFIT_MATH_CORRECTLY_ROUNDED && mode != OUTFIT_MATH_GLIBC)
+    return fail(OUTFIT_ERR_INVALID_PARAM, "math mode must be OUTFIT_MATH_CORRECTLY_ROUNDED or OUTFIT_MATH_GLIBC");
+  g_math_mode.store(mode);
+  return OUTFIT_OK;
+}
+int outfit_hip_get_math_mode(void) { return current_math_mode(); }
 int outfit_hip_abi_version(void) { return OUTFIT_HIP_ABI_VERSION; }
 
 int outfit_hip_device_count(void) {
@@ -969,7 +995,7 @@ int outfit_hip_selftest_crmath(uint64_t n_args, uint64_t seed, uint64_t* counts)
 }
 
 int outfit_hip_crmath_eval(int fn, uint64_t n, const double* x, double* out) {
-  if ((fn & 15) > 8 || (fn & ~31)) return fail(OUTFIT_ERR_INVALID_PARAM, "fn: 0 sin, 1 cos, 2 acos, 3 sinh, 4 cosh, 5 log, 6 atan2 (+16: full evaluation), 7 / 8 sin / cos of the residual loop");
+  if ((fn & 15) > 12 || (fn & ~31)) return fail(OUTFIT_ERR_INVALID_PARAM, "fn: 0 sin, 1 cos, 2 acos, 3 sinh, 4 cosh, 5 log, 6 atan2 (+16: full evaluation), 7 / 8 sin / cos of the residual loop, 9..12 glibc-faithful sin / cos / sinh / cosh");
   if (n && (!x || !out)) return fail(OUTFIT_ERR_INVALID_BATCH, "NULL argument");
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
@@ -979,6 +1005,24 @@ int outfit_hip_crmath_eval(int fn, uint64_t n, const double* x, double* out) {
   TRY_RC(upload(dx, x, (size_t)n * ((fn & 15) == 6 ? 2 : 1)));
   HIP_TRY(dy.alloc((size_t)n));
   hipError_t e = outfit::launch_crmath_eval(fn, n, dx.p, dy.p, nullptr);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(out, dy.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+  dx.release();
+  dy.release();
+  if (e != hipSuccess) return fail(OUTFIT_ERR_HIP, hipGetErrorString(e));
+  return OUTFIT_OK;
+}
+
+int outfit_hip_prelim_kepuni(uint64_t n, const double* problems, double* out) {
+  if (n == 0) return OUTFIT_OK;
+  if (!problems || !out) return fail(OUTFIT_ERR_INVALID_BATCH, "NULL argument");
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+    return fail(OUTFIT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+  DevBuf<double> dx, dy;
+  TRY_RC(upload(dx, problems, (size_t)n * 6));
+  HIP_TRY(dy.alloc((size_t)n));
+  hipError_t e = outfit::launch_prelim_kepuni(n, dx.p, current_math_mode(), dy.p, nullptr);
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e == hipSuccess) e = hipMemcpy(out, dy.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
   dx.release();
@@ -1025,7 +1069,7 @@ int outfit_hip_propagate_universal(uint64_t n, const double* r0v0, const double*
       rc = fail(OUTFIT_ERR_HIP, "hipMalloc failed");
       break;
     }
-    hipError_t e = outfit::launch_propagate_universal(n, d_rv.p, d_t0.p, d_t1.p, convergency, d_out.p, d_st.p,
+    hipError_t e = outfit::launch_propagate_universal(n, d_rv.p, d_t0.p, d_t1.p, convergency, current_math_mode(), d_out.p, d_st.p,
                                                       nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(out, d_out.p, (size_t)11 * n * sizeof(double), hipMemcpyDeviceToHost);

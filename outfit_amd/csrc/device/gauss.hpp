@@ -36,6 +36,7 @@ struct GaussParams {
   unsigned aberth_max_iter;
   unsigned max_tested_solutions;  // saturated to 2^32-1 on the host
   unsigned newton_max_it;         // saturated likewise
+  int math_mode;                  // kMathCr / kMathGlibc (kepler.hpp)
 };
 
 // error codes = OUTFIT_CAUSE_* of include/outfit_hip.h
@@ -215,13 +216,13 @@ __device__ __forceinline__ GaussGeometry gauss_times(const double (&t)[3]) {
 }
 
 // unit_matrix (gauss.rs:488-502) with correctly-rounded sin/cos (crmath.hpp)
-__device__ __forceinline__ Mat3 unit_matrix(const double (&ra)[3], const double (&dec)[3]) {
+__device__ __forceinline__ Mat3 unit_matrix(const double (&ra)[3], const double (&dec)[3], int math_mode) {
   Mat3 S;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     double sr, cr, sd, cd;
-    crm::sincos(ra[c], sr, cr);
-    crm::sincos(dec[c], sd, cd);
+    sincos_mode(math_mode, ra[c], sr, cr);
+    sincos_mode(math_mode, dec[c], sd, cd);
     S.m[0][c] = cr * cd;
     S.m[1][c] = sr * cd;
     S.m[2][c] = sd;
@@ -362,7 +363,7 @@ __device__ __forceinline__ CorrStep correction_iteration(const Mat3& obs, const 
   for (int side = 0; side < 2; ++side) {
     const double dt = side ? dt21 : dt01;
     const double chi = side ? st.chi21 : st.chi01;
-    const KeplerProblem p = velocity_problem(st.vc, dt, P.kepler_eps);
+    const KeplerProblem p = velocity_problem(st.vc, dt, P.kepler_eps, P.math_mode);
     const KeplerSolution sol = kFast ? run_newton(p, chi) : solve_kepuni(p, side ? st.has21 : st.has01, chi);
     const VelCorr vc = velocity_finish(sol, side ? r3 : r1, r2, st.vc.r2, dt);
     if (side) b = vc; else a = vc;

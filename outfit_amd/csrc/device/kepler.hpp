@@ -12,6 +12,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "crmath.hpp"
+#include "glibcmath.hpp"
 #include "fastdiv.hpp"
 
 namespace outfit {
@@ -121,8 +122,20 @@ __device__ __forceinline__ Stumpff s_funct(double psi, double alpha) {
   return {s0, s1, (s0 - 1.0) / alpha, (s1 - psi) / alpha};
 }
 
+// Math mode of the elementary functions that feed the correction loop and the returned elements
+// (include/outfit_hip.h OUTFIT_MATH_*): 0 = correctly rounded (crmath.hpp), 1 = sin/cos/sinh/cosh with
+// glibc 2.35's bits (glibcmath.hpp), the rest correctly rounded. Always wave-uniform (a kernel argument).
+constexpr int kMathCr = 0, kMathGlibc = 1;
+__device__ __forceinline__ void sincos_mode(int mode, double x, double& s, double& c) {
+  if (mode == kMathGlibc) glm::sincos(x, s, c); else crm::sincos(x, s, c);
+}
+__device__ __forceinline__ void sinhcosh_mode(int mode, double x, double& s, double& c) {
+  if (mode == kMathGlibc) glm::sinhcosh(x, s, c); else crm::sinhcosh(x, s, c);
+}
+
 struct KeplerProblem {
   double dt, r0, sig0, alpha, e0, convergency;
+  int math_mode;
 };
 
 // kepler/prelim_kepler/prelim_elliptic.rs:9-134
@@ -139,7 +152,7 @@ __device__ __forceinline__ double prelim_elliptic(const KeplerProblem& p) {
   if (p.sig0 < 0.0) u0 = -u0;
   u0 = principal_angle(u0);
   double su0, cu0;
-  crm::sincos(u0, su0, cu0);
+  sincos_mode(p.math_mode, u0, su0, cu0);
   const double m0 = principal_angle(u0 - p.e0 * su0);
   const double m = m0 + n * p.dt;
   double u = m;
@@ -148,7 +161,7 @@ __device__ __forceinline__ double prelim_elliptic(const KeplerProblem& p) {
 #pragma unroll 1
   for (int i = 0; i < 20; ++i) {
     double su, cu;
-    crm::sincos(u, su, cu);
+    sincos_mode(p.math_mode, u, su, cu);
     const double res = u - p.e0 * su - m;
     const double der = 1.0 - p.e0 * cu;
     const double step = -res / der;
@@ -167,7 +180,7 @@ __device__ __forceinline__ double prelim_hyperbolic(const KeplerProblem& p) {
   double f0 = (c > 1.0) ? crm::log(c + sqrt(c * c - 1.0)) : 0.0;
   if (p.sig0 < 0.0) f0 = -f0;
   double sh, ch;
-  crm::sinhcosh(f0, sh, ch);
+  sinhcosh_mode(p.math_mode, f0, sh, ch);
   const double m = (p.e0 * sh - f0) + n * p.dt;
   double f = 0.0;
   // not unrolled: the body inlines the correctly-rounded functions with their second steps (~1-2 k instructions);
@@ -175,7 +188,7 @@ __device__ __forceinline__ double prelim_hyperbolic(const KeplerProblem& p) {
 #pragma unroll 1
   for (int i = 0; i < 20; ++i) {
     if (fabs(f) < 15.0) {
-      crm::sinhcosh(f, sh, ch);
+      sinhcosh_mode(p.math_mode, f, sh, ch);
       const double res = p.e0 * sh - f - m;
       const double der = p.e0 * ch - 1.0;
       const double cand = f + (-res / der);
@@ -367,9 +380,10 @@ __device__ __forceinline__ VelCommon velocity_common_from(const EccControl& ec, 
   c.ok = isfinite(ec.h_norm) && !(ec.h_norm <= 1e6 * kEps) && ec.some;
   return c;
 }
-__device__ __forceinline__ KeplerProblem velocity_problem(const VelCommon& c, double dt, double eps) {
+__device__ __forceinline__ KeplerProblem velocity_problem(const VelCommon& c, double dt, double eps, int math_mode) {
   KeplerProblem p;
   p.dt = dt; p.r0 = c.r2; p.sig0 = c.sig0; p.alpha = c.alpha; p.e0 = c.e0; p.convergency = eps;
+  p.math_mode = math_mode;
   return p;
 }
 // Lagrange f, g and the corrected velocity from a Kepler solution (velocity.rs:144-161)
@@ -389,16 +403,16 @@ __device__ __forceinline__ VelCorr velocity_finish(const KeplerSolution& sol, co
 }
 __device__ __forceinline__ VelCorr velocity_correction(const Vec3& x1, const Vec3& x2, const Vec3& v2, double dt,
                                               double peri_max, double ecc_max, bool has_guess,
-                                              double chi_guess, double eps) {
+                                              double chi_guess, double eps, int math_mode = kMathCr) {
   const VelCommon c = velocity_common(x2, v2, peri_max, ecc_max);
   if (!c.ok) { VelCorr o; o.ok = false; return o; }
-  return velocity_finish(solve_kepuni(velocity_problem(c, dt, eps), has_guess, chi_guess), x1, x2, c.r2, dt);
+  return velocity_finish(solve_kepuni(velocity_problem(c, dt, eps, math_mode), has_guess, chi_guess), x1, x2, c.r2, dt);
 }
 
 // kepler/propagation.rs:114-207 ; out = r1[3] v1[3] f g fdot gdot psi ; returns the status code
 // documented at outfit_hip_propagate_universal (include/outfit_hip.h).
 __device__ __forceinline__ int propagate_universal(const Vec3& r, const Vec3& v, double t0, double t1,
-                                          double convergency, double* out) {
+                                          double convergency, double* out, int math_mode = kMathCr) {
   const double r0 = norm(r);
   if (r0 < kEps) return 1;
   const double v2 = dot(v, v);
@@ -409,7 +423,7 @@ __device__ __forceinline__ int propagate_universal(const Vec3& r, const Vec3& v,
   const Vec3 h = cross(r, v);
   double e = sqrt(1.0 + p.alpha * dot(h, h) / kMu);
   if (!(e >= 0.0)) e = 0.0;  // f64::max(NaN, 0.0) == 0.0
-  p.e0 = e; p.r0 = r0; p.dt = t1 - t0; p.convergency = convergency;
+  p.e0 = e; p.r0 = r0; p.dt = t1 - t0; p.convergency = convergency; p.math_mode = math_mode;
   const KeplerSolution s = solve_kepuni(p, false, 0.0);
   if (!s.ok) return 2;
   const double r1 = r0 * s.s.s0 + p.sig0 * s.s.s1 + s.s.s2;

@@ -57,8 +57,8 @@ struct Elements {
 // observation evaluations per step) keeps the platform functions — they move the RMS by <= 1e-9 relative, never the
 // returned elements; the differential corrector (ill-conditioned normal equations amplify a last place up to
 // 1e13 times) uses the correctly-rounded ones and is then bit-identical to the oracle.
-template <bool kCr> __device__ __forceinline__ void sincos_sel(double x, double& s, double& c) {
-  if constexpr (kCr) crm::sincos(x, s, c); else ::sincos(x, &s, &c);
+template <bool kCr> __device__ __forceinline__ void sincos_sel(double x, double& s, double& c, int math_mode = kMathCr) {
+  if constexpr (kCr) sincos_mode(math_mode, x, s, c); else ::sincos(x, &s, &c);
 }
 template <bool kCr> __device__ __forceinline__ double atan2_sel(double y, double x) {
   if constexpr (kCr) return crm::atan2(y, x); else return ::atan2(y, x);
@@ -76,7 +76,7 @@ template <bool kCr> __device__ __forceinline__ double hypot_sel(double x, double
 // kCr = false (platform functions, ~900 instructions cheaper) serves the RMS evaluation of every candidate in K2c;
 // the elements that are RETURNED are recomputed with kCr = true for the selected candidate only (K3).
 template <bool kCr = true>
-__device__ __forceinline__ Elements ccek1(const Vec3& pos, const Vec3& vel, double epoch) {
+__device__ __forceinline__ Elements ccek1(const Vec3& pos, const Vec3& vel, double epoch, int math_mode = kMathCr) {
   constexpr double EPS_EQ = 1e-15, EPS_PARAB = 1e-12, EPS_E = 5e-15;
   Elements out;
   out.epoch = epoch;
@@ -90,8 +90,8 @@ __device__ __forceinline__ Elements ccek1(const Vec3& pos, const Vec3& vel, doub
   if (sin_i <= EPS_EQ) { inc = 0.0; node = 0.0; }
   else node = principal_angle(atan2_sel<kCr>(hu.x, -hu.y));
   double si, ci, sn, cn;
-  sincos_sel<kCr>(inc, si, ci);
-  sincos_sel<kCr>(node, sn, cn);
+  sincos_sel<kCr>(inc, si, ci, math_mode);
+  sincos_sel<kCr>(node, sn, cn, math_mode);
   // rotmt(i,0)^T * rotmt(Om,2)^T: every entry is a single product (ref_system.rs:453-462)
   const double m10 = ci * (-sn), m11 = ci * cn, m20 = (-si) * (-sn), m21 = (-si) * cn;
   const Vec3 po = {(cn * pos.x + sn * pos.y) + 0.0 * pos.z, (m10 * pos.x + m11 * pos.y) + si * pos.z,
@@ -114,7 +114,7 @@ __device__ __forceinline__ Elements ccek1(const Vec3& pos, const Vec3& vel, doub
     } else {
       const double ea = atan2_sel<kCr>(esin, ecos);
       double sea, cea;
-      sincos_sel<kCr>(ea, sea, cea);
+      sincos_sel<kCr>(ea, sea, cea, math_mode);
       const double ma = principal_angle(ea - e * sea);
       const double x1 = cea - e;
       const double x2 = sqrt(1.0 - e * e) * sea;

@@ -62,6 +62,7 @@ struct PrepassArgs {
   double* cos_dec;
   double* unit;    // [3][n_obs] direction cosines of the (noise-free) observations
   bool has_table;  // false: only cos(dec) is produced, the residuals use obs_helio_equ
+  int math_mode;   // kMathCr / kMathGlibc for the direction cosines
   EphemTable T;
   int* error_flag;
 };
@@ -133,6 +134,7 @@ struct SelectArgs {
   const unsigned* n_triplets;
   CandidateScratch W;
   GaussResultRec* out;  // indexed by absolute trajectory
+  int math_mode;        // kMathCr / kMathGlibc for the returned elements
 };
 
 // same layouts as outfit_lsq_result_t (480 B) / outfit_obs_fit_t (32 B)
@@ -180,13 +182,14 @@ hipError_t launch_device_normals(unsigned long long seed, const unsigned long lo
                                  unsigned n_noise, double* out, hipStream_t s);
 hipError_t launch_selftest_aberth(unsigned long long n_threads, unsigned long long n_per_thread,
                                   unsigned long long seed, unsigned long long* d_out, hipStream_t s);
+hipError_t launch_prelim_kepuni(unsigned long long n, const double* prob, int math_mode, double* out, hipStream_t s);
 hipError_t launch_crmath_eval(int fn, unsigned long long n, const double* x, double* out, hipStream_t s);
 hipError_t launch_selftest_crmath(unsigned long long n_threads, unsigned long long n_per_thread,
                                   unsigned long long seed, unsigned long long* d_out, hipStream_t s);
 hipError_t launch_selftest_division(unsigned long long n_threads, unsigned long long n_per_thread,
                                     unsigned long long seed, unsigned long long* d_mismatches, hipStream_t s);
 hipError_t launch_propagate_universal(unsigned long long n, const double* rv, const double* t0,
-                                      const double* t1, double convergency, double* out, int* status,
+                                      const double* t1, double convergency, int math_mode, double* out, int* status,
                                       hipStream_t s);
 
 }  // namespace outfit

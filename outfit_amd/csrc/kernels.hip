@@ -86,8 +86,8 @@ k_observer_prepass(PrepassArgs a) {
     // functions: every noise-free candidate that uses this observation (~15 triplets each) reads the
     // three direction cosines instead of re-evaluating two double-double sincos
     double sr, cr, sd, cd;
-    crm::sincos(a.ra[o], sr, cr);
-    crm::sincos(a.dec[o], sd, cd);
+    sincos_mode(a.math_mode, a.ra[o], sr, cr);
+    sincos_mode(a.math_mode, a.dec[o], sd, cd);
     a.unit[o] = cr * cd;
     a.unit[a.n_obs + o] = sr * cd;
     a.unit[2 * a.n_obs + o] = sd;
@@ -219,7 +219,7 @@ k_gauss_roots(RootsArgs a) {
     }
   } else {
     gather_angles(a.I, c, ra, dec);
-    S = unit_matrix(ra, dec);
+    S = unit_matrix(ra, dec, a.P.math_mode);
   }
 #pragma unroll
   for (int r = 0; r < 3; ++r)
@@ -307,8 +307,8 @@ k_gauss_prelim(CorrectArgs a) {
   const double dt01 = g.t[0] - g.t[1], dt21 = g.t[2] - g.t[1];
   bool slow = !vc.ok || fabs(dt01) <= kEps || fabs(dt21) <= kEps;
   if (!slow) {
-    a.W.psi0[cid] = prelim_kepuni(velocity_problem(vc, dt01, a.P.kepler_eps));
-    a.W.psi0[n + cid] = prelim_kepuni(velocity_problem(vc, dt21, a.P.kepler_eps));
+    a.W.psi0[cid] = prelim_kepuni(velocity_problem(vc, dt01, a.P.kepler_eps, a.P.math_mode));
+    a.W.psi0[n + cid] = prelim_kepuni(velocity_problem(vc, dt21, a.P.kepler_eps, a.P.math_mode));
   }
   a.W.flags[cid] = kFlagOk | (nf << kFlagRootsShift) | (slot << kFlagFirstShift) | (slow ? kFlagSlow : 0u);
   if (slow) append_slow(a.W, cid);
@@ -707,7 +707,7 @@ k_select_best(SelectArgs a) {
       const Vec3 r2 = {a.W.state[0 * nc + cid], a.W.state[1 * nc + cid], a.W.state[2 * nc + cid]};
       const Vec3 v2 = {a.W.state[3 * nc + cid], a.W.state[4 * nc + cid], a.W.state[5 * nc + cid]};
       out.epoch = a.W.state[6 * nc + cid];
-      const Elements el = ccek1<true>(equ_to_ecl(r2), equ_to_ecl(v2), out.epoch);
+      const Elements el = ccek1<true>(equ_to_ecl(r2), equ_to_ecl(v2), out.epoch, a.math_mode);
       out.kind = el.kind;
       for (int k = 0; k < 6; ++k) out.elem[k] = el.e[k];
       out.rms = best;
@@ -724,14 +724,14 @@ k_select_best(SelectArgs a) {
 // ------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_propagate_universal(unsigned long long n, const double* rv, const double* t0, const double* t1,
-                      double convergency, double* out, int* status) {
+                      double convergency, int math_mode, double* out, int* status) {
   const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double o[11];
   for (int k = 0; k < 11; ++k) o[k] = nan("");
   const Vec3 r = {rv[6 * i], rv[6 * i + 1], rv[6 * i + 2]};
   const Vec3 v = {rv[6 * i + 3], rv[6 * i + 4], rv[6 * i + 5]};
-  status[i] = propagate_universal(r, v, t0[i], t1[i], convergency, o);
+  status[i] = propagate_universal(r, v, t0[i], t1[i], convergency, o, math_mode);
   for (int k = 0; k < 11; ++k) out[11 * i + k] = o[k];
 }
 
@@ -926,6 +926,11 @@ k_crmath_eval(int fn, unsigned long long n, const double* x, double* out, SinCos
   }
   const double v = x[i];
   double a = 0.0, b = 0.0, r;
+  if ((fn & 15) >= 9) {  // the glibc-faithful functions of OUTFIT_MATH_GLIBC (glibcmath.hpp)
+    const int g = fn & 15;
+    out[i] = g == 9 ? glm::sin(v) : g == 10 ? glm::cos(v) : g == 11 ? glm::sinh(v) : glm::cosh(v);
+    return;
+  }
   if ((fn & 15) == 7 || (fn & 15) == 8) {  // K2c's kernel-argument-constant sincos (not correctly rounded: ~1 ulp)
     sincos_k(v, sc, a, b);
     out[i] = (fn & 15) == 7 ? a : b;
@@ -944,6 +949,23 @@ k_crmath_eval(int fn, unsigned long long n, const double* x, double* out, SinCos
     default: r = slow ? crm::log_slow(v) : crm::log(v); break;
   }
   out[i] = r;
+}
+
+// outfit_hip_prelim_kepuni: the cold-start value of the universal Kepler solve (kepler/params.rs:185-191) for
+// explicit problems (dt, r0, sig0, alpha, e0, convergency), in the given math mode
+__global__ void __launch_bounds__(256)
+k_prelim_kepuni(unsigned long long n, const double* prob, int math_mode, double* out) {
+  const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  KeplerProblem p;
+  p.dt = prob[6 * i]; p.r0 = prob[6 * i + 1]; p.sig0 = prob[6 * i + 2]; p.alpha = prob[6 * i + 3];
+  p.e0 = prob[6 * i + 4]; p.convergency = prob[6 * i + 5]; p.math_mode = math_mode;
+  out[i] = prelim_kepuni(p);
+}
+hipError_t launch_prelim_kepuni(unsigned long long n, const double* prob, int math_mode, double* out, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_prelim_kepuni, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, prob, math_mode, out);
+  return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------
@@ -1062,12 +1084,12 @@ hipError_t launch_select_best(const SelectArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 hipError_t launch_propagate_universal(unsigned long long n, const double* rv, const double* t0,
-                                      const double* t1, double convergency, double* out, int* status,
+                                      const double* t1, double convergency, int math_mode, double* out, int* status,
                                       hipStream_t s) {
   if (n == 0) return hipSuccess;
   const unsigned grid = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(k_propagate_universal, dim3(grid), dim3(256), 0, s, n, rv, t0, t1, convergency, out,
-                     status);
+  hipLaunchKernelGGL(k_propagate_universal, dim3(grid), dim3(256), 0, s, n, rv, t0, t1, convergency, math_mode,
+                     out, status);
   return hipGetLastError();
 }
 
