@@ -98,8 +98,12 @@ typedef struct outfit_iod_params {
 
 /* One batch = all trajectories of a prepared dataset (what `process_traj`
  * iterates over, obs_dataset_api.rs:159-171,191-205). Observations of
- * trajectory t are rows traj_offset[t] .. traj_offset[t+1]-1 and MUST be
- * sorted by mjd_tt (fit_single_traj sorts them, obs_dataset_api.rs:222-223). */
+ * trajectory t are rows traj_offset[t] .. traj_offset[t+1]-1. The path works on each
+ * trajectory in epoch order: rows that are not already ascending in mjd_tt are put in that
+ * order inside the boundary exactly as fit_single_traj does (stable sort by f64::total_cmp,
+ * obs_dataset_api.rs:222-223) — `best_triplet` and the RMS window then refer to the sorted
+ * order, as in the reference; per-observation outputs (obs_fit) come back in the caller's
+ * row order. Already-sorted input (the usual case) costs one pass over mjd_tt. */
 typedef struct outfit_obs_batch {
   uint64_t        n_traj;
   const uint64_t *traj_offset;   /* n_traj + 1 entries                                            */
@@ -330,7 +334,8 @@ int  outfit_hip_diffcor_config_validate(const outfit_diffcor_config_t *c);
  * status OUTFIT_TRAJ_OK = use as the seed; any other status = absent/Err entry, for which the
  * reference runs the IOD (obs_dataset_api.rs:118-120, mod.rs:86). NULL = run the IOD for all.
  * `obs_fit` (nullable) receives one record per observation, indexed like the observation arrays
- * (row traj_offset[t] + i). */
+ * (row traj_offset[t] + i). (The session form rebases: its obs_fit row r is observation row traj_offset[0] + r
+ * of the batch the session was created from.) */
 int outfit_hip_fit_lsq(const outfit_iod_params_t     *iod_params,
                        const outfit_diffcor_config_t *config,
                        const outfit_obs_batch_t      *batch,

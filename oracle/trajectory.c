@@ -130,10 +130,61 @@ static double rms_orbit_error(const ctx_t *c, uint64_t base, size_t n_obs, const
   return sqrt(acc / denom);
 }
 
-/* trajectory.rs:429-545 + obs_dataset_api.rs:210-226 (observations already time-sorted) */
+/* f64::total_cmp as a signed-integer key */
+static int64_t total_order_key(double x) {
+  int64_t v;
+  memcpy(&v, &x, sizeof v);
+  return v ^ (int64_t)((uint64_t)(v >> 63) >> 1);
+}
+
+/* `obs_vec_refs.sort_by(|a, b| a.mjd_tt().total_cmp(&b.mjd_tt()))` (obs_dataset_api.rs:222-223, stable): when the
+ * rows of the trajectory are not in that order, a one-trajectory batch with the rows gathered in sorted order. */
+static double *gather_rows(const double *src, const size_t *perm, size_t n, size_t w) {
+  if (!src) return NULL;
+  double *d = (double *)malloc(sizeof(double) * n * w + 8);
+  for (size_t i = 0; i < n; ++i)
+    for (size_t k = 0; k < w; ++k) d[i * w + k] = src[perm[i] * w + k];
+  return d;
+}
+static int estimate_on_sorted_copy(const outfit_iod_params_t *ip, const outfit_obs_batch_t *b,
+                                   const outfit_ephem_t *eph, uint64_t traj, int hoist_ephem,
+                                   outfit_gauss_result_t *out) {
+  const uint64_t base = b->traj_offset[traj];
+  const size_t n = (size_t)(b->traj_offset[traj + 1] - base);
+  int sorted = 1;
+  for (size_t i = 1; i < n && sorted; ++i)
+    sorted = total_order_key(b->mjd_tt[base + i - 1]) <= total_order_key(b->mjd_tt[base + i]);
+  if (sorted) return 0;
+  size_t *perm = (size_t *)malloc(sizeof(size_t) * n);
+  for (size_t i = 0; i < n; ++i) perm[i] = (size_t)base + i;
+  for (size_t i = 1; i < n; ++i) { /* stable insertion sort */
+    size_t p = perm[i], j = i;
+    while (j > 0 && total_order_key(b->mjd_tt[perm[j - 1]]) > total_order_key(b->mjd_tt[p])) { perm[j] = perm[j - 1]; --j; }
+    perm[j] = p;
+  }
+  outfit_obs_batch_t s = *b;
+  uint64_t off[2] = {0, n};
+  s.n_traj = 1;
+  s.traj_offset = off;
+  double *col[9] = {gather_rows(b->mjd_tt, perm, n, 1), gather_rows(b->ra, perm, n, 1), gather_rows(b->dec, perm, n, 1),
+                    gather_rows(b->sigma_ra, perm, n, 1), gather_rows(b->sigma_dec, perm, n, 1),
+                    gather_rows(b->obs_helio_equ, perm, n, 3), gather_rows(b->obs_geo_ecl, perm, n, 3),
+                    gather_rows(b->obs_body_fixed, perm, n, 3), gather_rows(b->mjd_ut1, perm, n, 1)};
+  s.mjd_tt = col[0]; s.ra = col[1]; s.dec = col[2]; s.sigma_ra = col[3]; s.sigma_dec = col[4];
+  s.obs_helio_equ = col[5]; s.obs_geo_ecl = col[6]; s.obs_body_fixed = col[7]; s.mjd_ut1 = col[8];
+  if (b->noise_z) s.noise_z = b->noise_z + (size_t)traj * ip->max_triplets * (size_t)ip->n_noise_realizations * 6;
+  if (b->traj_key) s.traj_key = b->traj_key + traj; else s.traj_key_base = b->traj_key_base + traj;
+  orc_estimate_best_orbit(ip, &s, eph, 0, hoist_ephem, out);
+  for (int k = 0; k < 9; ++k) free(col[k]);
+  free(perm);
+  return 1;
+}
+
+/* trajectory.rs:429-545 + obs_dataset_api.rs:210-226 */
 void orc_estimate_best_orbit(const outfit_iod_params_t *ip, const outfit_obs_batch_t *b,
                              const outfit_ephem_t *eph, uint64_t traj, int hoist_ephem,
                              outfit_gauss_result_t *out) {
+  if (estimate_on_sorted_copy(ip, b, eph, traj, hoist_ephem, out)) return;
   ctx_t c = {ip, b, eph, hoist_ephem};
   uint64_t base = b->traj_offset[traj];
   size_t n_obs = (size_t)(b->traj_offset[traj + 1] - base);

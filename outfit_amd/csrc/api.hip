@@ -132,6 +132,9 @@ struct outfit_hip_session {
   DevBuf<outfit::LsqResultRec> dc_out;
   DevBuf<outfit::ObsFitRec> dc_fit;
   bool prepass_done = false, lsq_ran = false;
+  // fit_single_traj sorts a trajectory's observations by epoch (obs_dataset_api.rs:222-223); when the caller's rows are
+  // not already in that order, resident row i holds the caller's row perm[i] (both rebased); empty = identity
+  std::vector<uint64_t> perm;
   const outfit::GaussResultRec* iod_out = nullptr;  // where the last IOD run wrote (d_out or `results`)
   outfit::EphemTable table{};
   outfit::GaussParams gp{};
@@ -223,6 +226,44 @@ int check_batch(const outfit_iod_params_t* params, const outfit_obs_batch_t* b, 
   return OUTFIT_OK;
 }
 
+// f64::total_cmp as a signed-integer key (library/core/src/num/f64.rs)
+inline int64_t total_order_key(double x) {
+  int64_t b;
+  std::memcpy(&b, &x, sizeof b);
+  return b ^ (int64_t)((uint64_t)(b >> 63) >> 1);
+}
+
+// `obs_vec_refs.sort_by(|a, b| a.mjd_tt().total_cmp(&b.mjd_tt()))` (obs_dataset_api.rs:222-223; sort_by is stable):
+// fills perm (rebased row -> caller's rebased row) when some trajectory is not already in that order.
+void sort_permutation(const outfit_obs_batch_t* b, std::vector<uint64_t>& perm) {
+  perm.clear();
+  if (!b->n_traj || !b->mjd_tt) return;
+  const uint64_t o0 = b->traj_offset[0];
+  bool sorted = true;
+  for (uint64_t t = 0; t < b->n_traj && sorted; ++t)
+    for (uint64_t i = b->traj_offset[t] + 1; i < b->traj_offset[t + 1]; ++i)
+      if (total_order_key(b->mjd_tt[i - 1]) > total_order_key(b->mjd_tt[i])) { sorted = false; break; }
+  if (sorted) return;
+  const uint64_t n = b->traj_offset[b->n_traj] - o0;
+  perm.resize(n);
+  for (uint64_t i = 0; i < n; ++i) perm[i] = i;
+  for (uint64_t t = 0; t < b->n_traj; ++t)
+    std::stable_sort(perm.begin() + (b->traj_offset[t] - o0), perm.begin() + (b->traj_offset[t + 1] - o0),
+                     [&](uint64_t x, uint64_t y) { return total_order_key(b->mjd_tt[o0 + x]) < total_order_key(b->mjd_tt[o0 + y]); });
+}
+
+template <typename T>
+int upload(DevBuf<T>& d, const T* src, size_t n);
+
+// a per-observation column of `width` doubles per row, gathered through the sort permutation when there is one
+int upload_rows(DevBuf<double>& d, const double* src, size_t n_rows, unsigned width, const std::vector<uint64_t>& perm) {
+  if (perm.empty() || !n_rows) return upload(d, src, n_rows * width);
+  std::vector<double> tmp(n_rows * width);
+  for (size_t i = 0; i < n_rows; ++i)
+    for (unsigned k = 0; k < width; ++k) tmp[i * width + k] = src[perm[i] * width + k];
+  return upload(d, tmp.data(), tmp.size());
+}
+
 template <typename T>
 int upload(DevBuf<T>& d, const T* src, size_t n) {
   HIP_TRY(d.alloc(n));
@@ -263,19 +304,20 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
   for (uint64_t t = 0; t <= s->n_traj && s->n_traj; ++t) off[t] = b->traj_offset[t] - o0;
   TRY_RC(upload(s->traj_offset, off.data(), off.size()));
   const size_t n = (size_t)s->n_obs;
-  TRY_RC(upload(s->mjd, n ? b->mjd_tt + o0 : nullptr, n));
-  TRY_RC(upload(s->ra, n ? b->ra + o0 : nullptr, n));
-  TRY_RC(upload(s->dec, n ? b->dec + o0 : nullptr, n));
-  TRY_RC(upload(s->sra, n ? b->sigma_ra + o0 : nullptr, n));
-  TRY_RC(upload(s->sdec, n ? b->sigma_dec + o0 : nullptr, n));
+  sort_permutation(b, s->perm);
+  TRY_RC(upload_rows(s->mjd, n ? b->mjd_tt + o0 : nullptr, n, 1, s->perm));
+  TRY_RC(upload_rows(s->ra, n ? b->ra + o0 : nullptr, n, 1, s->perm));
+  TRY_RC(upload_rows(s->dec, n ? b->dec + o0 : nullptr, n, 1, s->perm));
+  TRY_RC(upload_rows(s->sra, n ? b->sigma_ra + o0 : nullptr, n, 1, s->perm));
+  TRY_RC(upload_rows(s->sdec, n ? b->sigma_dec + o0 : nullptr, n, 1, s->perm));
   const bool device_geometry = b->obs_body_fixed && b->mjd_ut1 && eph;
   if (device_geometry) HIP_TRY(s->helio.alloc(3 * n));
-  else TRY_RC(upload(s->helio, n ? b->obs_helio_equ + 3 * o0 : nullptr, 3 * n));
+  else TRY_RC(upload_rows(s->helio, n ? b->obs_helio_equ + 3 * o0 : nullptr, n, 3, s->perm));
   HIP_TRY(s->cos_dec.alloc(n));
   for (int b = 0; b < 2; ++b) HIP_TRY(s->unit[b].alloc(3 * n));  // double-buffered: written ahead on k0_stream
   if (s->has_ephem && s->has_geo) {
     if (device_geometry) HIP_TRY(s->geo.alloc(3 * n));
-    else TRY_RC(upload(s->geo, n ? b->obs_geo_ecl + 3 * o0 : nullptr, 3 * n));
+    else TRY_RC(upload_rows(s->geo, n ? b->obs_geo_ecl + 3 * o0 : nullptr, n, 3, s->perm));
     HIP_TRY(s->obs_pos.alloc(3 * n));
     unsigned per_block = 0;
     for (int k = 0; k < 3; ++k) {
@@ -308,8 +350,8 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
   if (device_geometry && n) {
     // row n2: what OutfitCache::build computes per observation, once per session (inputs are resident)
     DevBuf<double> ut1, fixed;
-    TRY_RC(upload(ut1, b->mjd_ut1 + o0, n));
-    TRY_RC(upload(fixed, b->obs_body_fixed + 3 * o0, 3 * n));
+    TRY_RC(upload_rows(ut1, b->mjd_ut1 + o0, n, 1, s->perm));
+    TRY_RC(upload_rows(fixed, b->obs_body_fixed + 3 * o0, n, 3, s->perm));
     outfit::GeometryArgs ga{};
     ga.n_obs = s->n_obs; ga.mjd_tt = s->mjd.p; ga.mjd_ut1 = ut1.p; ga.body_fixed = fixed.p; ga.T = s->table;
     ga.geo_ecl = s->geo.p; ga.helio_equ = s->helio.p; ga.error_flag = s->error_flag.p;
@@ -848,8 +890,15 @@ int outfit_hip_session_lsq_results(outfit_hip_session_t* s, outfit_lsq_result_t*
   if (flag) return fail(OUTFIT_ERR_EPHEM_RANGE, "an observation epoch lies outside the ephemeris table");
   if (s->n_traj)
     HIP_TRY(hipMemcpy(out, s->dc_out.p, (size_t)s->n_traj * sizeof(outfit_lsq_result_t), hipMemcpyDeviceToHost));
-  if (obs_fit && s->n_obs)
-    HIP_TRY(hipMemcpy(obs_fit, s->dc_fit.p, (size_t)s->n_obs * sizeof(outfit_obs_fit_t), hipMemcpyDeviceToHost));
+  if (obs_fit && s->n_obs) {
+    if (s->perm.empty()) {
+      HIP_TRY(hipMemcpy(obs_fit, s->dc_fit.p, (size_t)s->n_obs * sizeof(outfit_obs_fit_t), hipMemcpyDeviceToHost));
+    } else {  // back to the caller's row order
+      std::vector<outfit_obs_fit_t> tmp((size_t)s->n_obs);
+      HIP_TRY(hipMemcpy(tmp.data(), s->dc_fit.p, tmp.size() * sizeof(outfit_obs_fit_t), hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < tmp.size(); ++i) obs_fit[s->perm[i]] = tmp[i];
+    }
+  }
   return OUTFIT_OK;
 }
 

@@ -185,3 +185,22 @@ def test_correction_loop_is_sensitive_to_the_last_bit_of_sin_cos(ds64):
     assert d.max() < 1e-6                  # the movers stay tiny ...
     # ... but they are not guaranteed to be below the 1e-10 parity tolerance:
     print("libm vs correctly-rounded: max |d elem| =", d.max(), " objects moved:", int((d > 0).sum()))
+
+
+def test_unsorted_rows_are_sorted_like_fit_single_traj(ds64):
+    """obs_dataset_api.rs:222-223: `sort_by(total_cmp)` (stable) before estimate_best_orbit. Shuffled rows give the
+    result of the sorted trajectory; with repeated epochs the stable order of the caller's rows decides."""
+    p = synth.bench_params(O.default_params())
+    a = run(ds64, p, n=16)
+    rng = np.random.default_rng(3)
+    sh = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in ds64.items()}
+    off = ds64["traj_offset"]
+    for t in range(16):
+        lo, hi = int(off[t]), int(off[t + 1])
+        perm = lo + rng.permutation(hi - lo)
+        for k in ("mjd_tt", "ra", "dec", "sigma_ra", "sigma_dec"):
+            sh[k][lo:hi] = ds64[k][perm]
+        for k in ("obs_helio_equ", "obs_geo_ecl"):
+            sh[k].reshape(-1, 3)[lo:hi] = ds64[k].reshape(-1, 3)[perm]
+    b = run(sh, p, n=16)
+    assert a.tobytes() == b.tobytes()
