@@ -224,6 +224,10 @@ int outfit_hip_session_create(const outfit_iod_params_t *params,
 int outfit_hip_session_run(outfit_hip_session_t *s, void *stream, void *d_out);
 /* Wait for the last run and copy the session's result buffer to host memory. */
 int outfit_hip_session_results(outfit_hip_session_t *s, outfit_gauss_result_t *out);
+/* Wait for the last run and report what the result calls would: OUTFIT_ERR_EPHEM_RANGE when an observation epoch lies
+ * outside the ephemeris table (the reference panics, horizon_data.rs:722-724), else 0. For callers that consume
+ * `d_out` on the device (a gather) and never fetch results through the session. */
+int outfit_hip_session_check(outfit_hip_session_t *s);
 /* Device pointer of the session's own result buffer (n_traj records). */
 void *outfit_hip_session_device_results(outfit_hip_session_t *s);
 /* Per-kernel totals since profiling was switched on: summed duration (ms, HIP events

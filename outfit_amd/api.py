@@ -429,6 +429,12 @@ class IODSession:
             _raise_rc(rc)
         return np.frombuffer(out, dtype=RESULT_DTYPE)[:self.n_traj].copy()
 
+    def check(self):
+        """Synchronise and raise what `results()` would (EphemerisRange) without fetching anything."""
+        rc = self._L.outfit_hip_session_check(self._h)
+        if rc != 0:
+            _raise_rc(rc)
+
     def set_profiling(self, on):
         self._L.outfit_hip_session_set_profiling(self._h, 1 if on else 0)
 

@@ -803,6 +803,16 @@ int outfit_hip_session_results(outfit_hip_session_t* s, outfit_gauss_result_t* o
   return OUTFIT_OK;
 }
 
+int outfit_hip_session_check(outfit_hip_session_t* s) {
+  if (!s) return fail(OUTFIT_ERR_BAD_HANDLE, "session is NULL");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->last_stream ? s->last_stream : s->own_stream));
+  int flag = 0;
+  HIP_TRY(hipMemcpy(&flag, s->error_flag.p, sizeof(int), hipMemcpyDeviceToHost));
+  if (flag) return fail(OUTFIT_ERR_EPHEM_RANGE, "an observation epoch lies outside the ephemeris table");
+  return OUTFIT_OK;
+}
+
 void* outfit_hip_session_device_results(outfit_hip_session_t* s) { return s ? s->results.p : nullptr; }
 
 int outfit_hip_session_set_profiling(outfit_hip_session_t* s, int enabled) {

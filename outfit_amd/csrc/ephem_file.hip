@@ -69,6 +69,8 @@ int outfit_hip_ephem_open(const char* path, outfit_ephem_file_t** out) {
   for (int i = 0; i < 36; ++i) h.ipt[i / 3][i % 3] = le_u32(head + kOffIpt + 4 * i);  // parse_ipt :284-305
   h.numde = le_u32(head + kOffIpt + 144);
   for (int c = 0; c < 3; ++c) h.ipt[12][c] = le_u32(head + kOffIpt + 148 + 4 * c);    // LPT
+  // the header is untrusted input: bound everything that feeds an offset or a size before using it
+  if (h.ncon < 0 || h.ncon > 10000) return fail("implausible NCON (not a little-endian DE file?)");
   // IPT rows 13/14 follow the constant names beyond the 400th (read_ipt_13_14 :323-347). The reference keys
   // this on the DE version named by the caller (>= DE440); the file's own NUMDE is used here.
   if (h.numde >= 440 && h.ncon > 400) {
@@ -77,17 +79,19 @@ int outfit_hip_ephem_open(const char* path, outfit_ephem_file_t** out) {
     if (std::fseek(f, off, SEEK_SET) != 0 || std::fread(extra, 1, 24, f) != 24) return fail("cannot read IPT rows 13/14");
     for (int i = 0; i < 6; ++i) h.ipt[13 + i / 3][i % 3] = le_u32(extra + 4 * i);
   }
+  for (unsigned i = 0; i < 15; ++i)
+    if (h.ipt[i][1] > 32 || h.ipt[i][2] > 1024) return fail("implausible IPT row (coefficients > 32 or sub-intervals > 1024)");
   uint64_t kernel_size = 4;  // compute_recsize :239-251
   for (unsigned i = 0; i < 15; ++i) kernel_size += 2ull * h.ipt[i][1] * h.ipt[i][2] * dimension(i);
   h.recsize = kernel_size * 4;
   if (h.recsize < 16 || h.recsize > (1ull << 24)) return fail("implausible record size (not a little-endian DE file?)");
   const uint64_t ncoeff = h.recsize / 8;
-  unsigned per_block = 0;
+  uint64_t per_block = 0;  // 64-bit from values bounded above: no wrap
   for (int b = 0; b < 3; ++b) {
     const uint32_t* r = h.ipt[kBodies[b]];
-    if (r[0] < 3 || r[1] == 0 || r[2] == 0 || (uint64_t)r[0] - 1 + 3ull * r[1] * r[2] > ncoeff)
+    if (r[0] < 3 || r[1] < 2 || r[2] == 0 || (uint64_t)r[0] - 1 + 3ull * r[1] * r[2] > ncoeff)
       return fail("IPT row of EMB/Moon/Sun points outside the record");
-    per_block += 3u * r[1] * r[2];
+    per_block += 3ull * r[1] * r[2];
   }
   if (std::fseek(f, 0, SEEK_END) != 0) return fail("seek failed");
   const long size = std::ftell(f);
@@ -107,7 +111,7 @@ int outfit_hip_ephem_open(const char* path, outfit_ephem_file_t** out) {
       // block[2 + (offset - 3 + s*ncoef*3) + a*ncoef + j] = block[offset - 1 + (3 s + a) ncoef + j]:
       // the body's segment is contiguous and already in outfit_ephem_t's order.
       const uint32_t* r = h.ipt[kBodies[b]];
-      const size_t n = 3u * r[1] * r[2];
+      const size_t n = (size_t)(3ull * r[1] * r[2]);
       const unsigned char* src = rec.data() + 8 * ((size_t)r[0] - 1);
       for (size_t k = 0; k < n; ++k) dst[k] = le_f64(src + 8 * k);
       dst += n;
