@@ -45,6 +45,7 @@ extern "C" {
 /* ---- crmath.c: correctly-rounded sin/cos/acos (see the header of that file) ---- */
 extern int orc_libm_mask; /* per-function platform-libm selection (study aid, crmath.c) */
 extern int orc_use_libm; /* 1 = platform libm instead (results then depend on the libm) */
+extern int orc_tie_order;  /* triplets.c: 1 = reverse runs of equal triplet weights (test aid) */
 extern int orc_math_glibc; /* 1 = sin/cos/sinh/cosh restated from glibc 2.35 (glibcmath.c), the rest correctly rounded */
 double orc_glibc_sin(double x);   /* glibcmath.c */
 double orc_glibc_cos(double x);

@@ -96,6 +96,8 @@ static int win_empty(lastwin w, size_t anchor, size_t n) {
   return w.lo >= n || w.lo > w.hi || w.hi <= anchor + 1;
 }
 
+int orc_tie_order = 0; /* test aid, see below */
+
 /* triplet_generation/mod.rs:328-408 + index_generator.rs:133-271.
  * NOTE quirk Q1: the reduced indices are returned as-is (no keep[] remap). */
 size_t orc_generate_triplet_indices(const double *mjd, size_t n_obs, const outfit_iod_params_t *ip,
@@ -152,6 +154,16 @@ size_t orc_generate_triplet_indices(const double *mjd, size_t n_obs, const outfi
     while (j > 0 && heap[j - 1].w > x.w) { heap[j] = heap[j - 1]; --j; }
     heap[j] = x;
   }
+  /* Rust's sort_unstable_by (ipnsort for K > 20) leaves the order of EQUAL weights unspecified and is not
+   * restated; orc_tie_order = 1 reverses every run of equal weights, so that tests can show what that order does
+   * and does not decide (tests/test_oracle_pipeline.py::test_order_of_equal_weights...). */
+  if (orc_tie_order)
+    for (size_t a = 0; a < hlen;) {
+      size_t e = a + 1;
+      while (e < hlen && heap[e].w == heap[a].w) ++e;
+      for (size_t lo = a, hi = e; lo + 1 < hi; ++lo, --hi) { wtrip t = heap[lo]; heap[lo] = heap[hi - 1]; heap[hi - 1] = t; }
+      a = e;
+    }
   for (size_t i = 0; i < hlen; ++i) {
     idx[3 * i] = heap[i].i; idx[3 * i + 1] = heap[i].j; idx[3 * i + 2] = heap[i].k;
     if (wout) wout[i] = heap[i].w;

@@ -18,6 +18,7 @@ All randomness comes from one SplitMix64 stream (seed 20260101), implemented
 here in numpy so the datasets are reproducible bit for bit.
 """
 import hashlib
+import os
 
 import numpy as np
 
@@ -299,3 +300,51 @@ def bench_params(params):
     params.max_obs_for_triplets = 20
     params.n_noise_realizations = 0
     return params
+
+
+def make_dataset_blocks(n_obj, block=100000, seed=DEFAULT_SEED, ephem=None, workers=None, **kw):
+    """A large batch as the concatenation of `make_dataset(block, seed + b)` for b = 0, 1, ... — block b is
+    byte-identical to that call, so any block can be regenerated alone. Blocks are generated by child
+    interpreters (numpy only; started with subprocess, so this is safe in a process that has already
+    initialised the GPU and does not depend on what the parent's __main__ is)."""
+    import pickle
+    import subprocess
+    import sys
+    import tempfile
+    if ephem is None:
+        ephem = make_ephemeris()
+    sizes = [min(block, n_obj - b) for b in range(0, n_obj, block)]
+    if workers is None:
+        workers = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, pickle, numpy as np; sys.path.insert(0, sys.argv[1]); from outfit_amd import synth; "
+            "a = pickle.load(open(sys.argv[2], 'rb')); d = synth.make_dataset(a['n'], seed=a['seed'], ephem=a['ephem'], **a['kw']); "
+            "d.pop('ephem'); np.savez(sys.argv[3], **{k: v for k, v in d.items() if k != 'n_traj'})")
+    parts = [None] * len(sizes)
+    with tempfile.TemporaryDirectory() as tmp:
+        pending = list(enumerate(sizes))
+        running = []
+        while pending or running:
+            while pending and len(running) < workers:
+                i, n = pending.pop(0)
+                arg, out = os.path.join(tmp, f"a{i}.pkl"), os.path.join(tmp, f"b{i}.npz")
+                with open(arg, "wb") as f:
+                    pickle.dump({"n": n, "seed": seed + i, "ephem": ephem, "kw": kw}, f)
+                running.append((i, out, subprocess.Popen([sys.executable, "-c", code, root, arg, out])))
+            i, out, proc = running.pop(0)
+            if proc.wait() != 0:
+                for _, _, p in running:
+                    p.kill()
+                raise RuntimeError(f"dataset block {i} failed")
+            with np.load(out) as z:
+                parts[i] = {k: z[k] for k in z.files}
+            os.remove(out)
+    out = {"n_traj": n_obj, "ephem": ephem}
+    for k in ("mjd_tt", "ra", "dec", "sigma_ra", "sigma_dec", "obs_helio_equ", "obs_geo_ecl", "truth"):
+        out[k] = np.ascontiguousarray(np.concatenate([p[k] for p in parts], axis=0))
+    offs, base = [np.zeros(1, dtype=np.uint64)], 0
+    for p in parts:
+        offs.append(p["traj_offset"][1:] + np.uint64(base))
+        base += int(p["traj_offset"][-1])
+    out["traj_offset"] = np.concatenate(offs)
+    return out
