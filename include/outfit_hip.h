@@ -427,6 +427,10 @@ int outfit_hip_crmath_eval(int fn, uint64_t n, const double *x, double *out);
  * problems of 6 doubles (dt, r0, sig0, alpha, e0, convergency; mu = GAUSS_GRAV^2), in the current math mode —
  * the reference's libm-dependent KAT (kepler/params.rs:689-725) is checked through this. */
 int outfit_hip_prelim_kepuni(uint64_t n, const double *problems /* 6n */, double *out /* n */);
+/* Device memory freed by sessions and blocking calls is kept per device for the next call of a similar shape
+ * (hipMalloc/hipFree of the candidate scratch cost ~10 ms per 100 k-object call); this returns it to the driver.
+ * The environment variable OUTFIT_NO_CACHE=1 disables the cache. */
+int outfit_hip_trim_cache(void);
 const char *outfit_hip_last_error(void); /* thread-local, never NULL */
 int         outfit_hip_abi_version(void);
 int         outfit_hip_device_count(void);

@@ -113,7 +113,7 @@ EXPORTED_SYMBOLS = [
     "outfit_hip_last_error", "outfit_hip_abi_version", "outfit_hip_device_count",
     "outfit_hip_selftest_division", "outfit_hip_selftest_crmath", "outfit_hip_crmath_eval", "outfit_hip_selftest_aberth", "outfit_hip_device_normals", "outfit_hip_observer_positions", "outfit_hip_diffcor_config_default", "outfit_hip_diffcor_config_validate",
     "outfit_hip_fit_lsq", "outfit_hip_session_run_lsq", "outfit_hip_session_lsq_results",
-    "outfit_hip_prelim_kepuni", "outfit_hip_set_math_mode", "outfit_hip_get_math_mode",
+    "outfit_hip_trim_cache", "outfit_hip_prelim_kepuni", "outfit_hip_set_math_mode", "outfit_hip_get_math_mode",
     "outfit_hip_ephem_open", "outfit_hip_ephem_header", "outfit_hip_ephem_view", "outfit_hip_ephem_close",
 ]
 

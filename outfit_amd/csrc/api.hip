@@ -14,6 +14,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -81,19 +83,72 @@ unsigned saturate_u32(uint64_t v) {
   return v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)v;
 }
 
+// Device-memory cache. A blocking call builds and tears down a session: ~25 hipMalloc (GBs of candidate scratch) and
+// as many hipFree, each of which synchronises the device — 10+ ms per 100 k-object call. Freed blocks are kept per
+// device and handed to the next request of a similar size (never more than 2x + 1 MiB larger than asked), so a host
+// that calls repeatedly with batches of one shape allocates once. Owners synchronise their streams before
+// releasing (outfit_hip_session::free_all); contents are never assumed to be zero. outfit_hip_trim_cache() returns
+// everything to the driver; OUTFIT_NO_CACHE=1 disables the cache.
+struct DeviceCache {
+  std::mutex m;
+  std::multimap<size_t, void*> blocks[64];
+  bool disabled = std::getenv("OUTFIT_NO_CACHE") != nullptr;
+  hipError_t get(size_t bytes, void** out, size_t* cap) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!disabled && dev >= 0 && dev < 64) {
+      std::lock_guard<std::mutex> g(m);
+      auto it = blocks[dev].lower_bound(bytes);
+      if (it != blocks[dev].end() && it->first <= 2 * bytes + (1u << 20)) {
+        *out = it->second;
+        *cap = it->first;
+        blocks[dev].erase(it);
+        return hipSuccess;
+      }
+    }
+    *cap = (bytes + 255) & ~(size_t)255;
+    hipError_t e = hipMalloc(out, *cap);
+    if (e != hipSuccess && !disabled) {  // out of memory with blocks parked in the cache: give them back and retry
+      trim();
+      e = hipMalloc(out, *cap);
+    }
+    return e;
+  }
+  void put(void* p, size_t cap) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (disabled || dev < 0 || dev >= 64) { (void)hipFree(p); return; }
+    std::lock_guard<std::mutex> g(m);
+    blocks[dev].emplace(cap, p);
+  }
+  void trim() {
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    std::lock_guard<std::mutex> g(m);
+    for (int d = 0; d < 64; ++d) {
+      if (blocks[d].empty()) continue;
+      (void)hipSetDevice(d);
+      for (auto& kv : blocks[d]) (void)hipFree(kv.second);
+      blocks[d].clear();
+    }
+    (void)hipSetDevice(cur);
+  }
+};
+DeviceCache g_cache;
+
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
-  size_t n = 0;
+  size_t n = 0, cap = 0;
   hipError_t alloc(size_t count) {
     n = count;
     if (count == 0) { p = nullptr; return hipSuccess; }
-    return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    return g_cache.get(count * sizeof(T), reinterpret_cast<void**>(&p), &cap);
   }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) g_cache.put(p, cap);
     p = nullptr;
-    n = 0;
+    n = cap = 0;
   }
 };
 
@@ -151,6 +206,8 @@ struct outfit_hip_session {
   hipEvent_t ev_start = nullptr, ev_prepass = nullptr, ev_fast = nullptr, ev_general = nullptr;
   hipEvent_t ev_sub[8] = {};
   hipStream_t last_stream = nullptr;
+  hipEvent_t ev_done = nullptr;  // recorded after the last kernel of every run / run_lsq, on the stream it went to
+  bool done_recorded = false;
   bool profiling = false;
   struct Timed { int id; hipEvent_t a, b; };
   std::vector<Timed> timed;
@@ -158,6 +215,13 @@ struct outfit_hip_session {
   int kernel_launches[K_COUNT] = {};
 
   void free_all() {
+    // blocks go back to the cache, not to hipFree (which would wait for the device): nothing may still use them
+    // (the caller's stream may no longer exist: its last run is awaited through an event of ours)
+    if (ev_done && done_recorded) (void)hipEventSynchronize(ev_done);
+    for (hipStream_t st : {own_stream, aux_stream, k0_stream})
+      if (st) (void)hipStreamSynchronize(st);
+    if (ev_done) (void)hipEventDestroy(ev_done);
+    ev_done = nullptr;
     traj_offset.release(); traj_key.release(); mjd.release(); ra.release(); dec.release(); sra.release(); sdec.release();
     helio.release(); geo.release(); obs_pos.release(); cos_dec.release(); unit[0].release(); unit[1].release(); noise.release(); coef.release();
     heap_w.release(); sum.release(); dirS.release(); roots.release(); state.release();
@@ -283,6 +347,7 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
   HIP_TRY(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&s->aux_stream, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&s->k0_stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming));
   for (hipEvent_t& e : s->ev_k3) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (hipEvent_t& e : s->ev_unit_free) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (hipEvent_t* e : {&s->ev_start, &s->ev_prepass, &s->ev_fast, &s->ev_general, &s->ev_sub[0], &s->ev_sub[1], &s->ev_sub[2], &s->ev_sub[3],
@@ -577,6 +642,8 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
     HIP_TRY(hipEventRecord(s->ev_k3[tb], st));
     s->k3_recorded[tb] = true;
   }
+  HIP_TRY(hipEventRecord(s->ev_done, st));
+  s->done_recorded = true;
   return OUTFIT_OK;
 }
 
@@ -663,6 +730,8 @@ int session_run_lsq(outfit_hip_session* s, const outfit_diffcor_config_t* cfg,
     }
     HIP_TRY(outfit::launch_diffcor(a, group, st));
   }
+  HIP_TRY(hipEventRecord(s->ev_done, st));
+  s->done_recorded = true;
   return OUTFIT_OK;
 }
 
@@ -800,6 +869,11 @@ int outfit_hip_session_results(outfit_hip_session_t* s, outfit_gauss_result_t* o
   if (s->n_traj)
     HIP_TRY(hipMemcpy(out, s->results.p, (size_t)s->n_traj * sizeof(outfit_gauss_result_t),
                       hipMemcpyDeviceToHost));
+  return OUTFIT_OK;
+}
+
+int outfit_hip_trim_cache(void) {
+  g_cache.trim();
   return OUTFIT_OK;
 }
 
