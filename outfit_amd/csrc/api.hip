@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -89,9 +90,51 @@ unsigned saturate_u32(uint64_t v) {
 // that calls repeatedly with batches of one shape allocates once. Owners synchronise their streams before
 // releasing (outfit_hip_session::free_all); contents are never assumed to be zero. outfit_hip_trim_cache() returns
 // everything to the driver; OUTFIT_NO_CACHE=1 disables the cache.
+// A session's three streams and 18 events: creating them costs ~10 ms and destroying them ~9 ms (measured), so
+// they are parked per device like the memory blocks.
+struct StreamSet {
+  hipStream_t stream[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t event[18] = {};
+  bool valid = false;
+};
 struct DeviceCache {
   std::mutex m;
   std::multimap<size_t, void*> blocks[64];
+  std::vector<StreamSet> sets[64];
+  hipError_t get_streams(StreamSet* out) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!disabled && dev >= 0 && dev < 64) {
+      std::lock_guard<std::mutex> g(m);
+      if (!sets[dev].empty()) { *out = sets[dev].back(); sets[dev].pop_back(); return hipSuccess; }
+    }
+    StreamSet ss;
+    for (auto& st : ss.stream) {
+      hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+      if (e != hipSuccess) return e;
+    }
+    for (auto& ev : ss.event) {
+      hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+      if (e != hipSuccess) return e;
+    }
+    ss.valid = true;
+    *out = ss;
+    return hipSuccess;
+  }
+  static void destroy_streams(StreamSet& ss) {
+    for (auto& st : ss.stream) if (st) (void)hipStreamDestroy(st);
+    for (auto& ev : ss.event) if (ev) (void)hipEventDestroy(ev);
+    ss = StreamSet();
+  }
+  void put_streams(StreamSet& ss) {  // the owner has synchronised the streams
+    if (!ss.valid) return;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (disabled || dev < 0 || dev >= 64) { destroy_streams(ss); return; }
+    std::lock_guard<std::mutex> g(m);
+    sets[dev].push_back(ss);
+    ss = StreamSet();
+  }
   bool disabled = std::getenv("OUTFIT_NO_CACHE") != nullptr;
   hipError_t get(size_t bytes, void** out, size_t* cap) {
     int dev = 0;
@@ -126,10 +169,12 @@ struct DeviceCache {
     (void)hipGetDevice(&cur);
     std::lock_guard<std::mutex> g(m);
     for (int d = 0; d < 64; ++d) {
-      if (blocks[d].empty()) continue;
+      if (blocks[d].empty() && sets[d].empty()) continue;
       (void)hipSetDevice(d);
       for (auto& kv : blocks[d]) (void)hipFree(kv.second);
       blocks[d].clear();
+      for (auto& ss : sets[d]) destroy_streams(ss);
+      sets[d].clear();
     }
     (void)hipSetDevice(cur);
   }
@@ -158,6 +203,21 @@ const char* const kKernelNames[K_COUNT] = {"k_triplet_select", "k_observer_prepa
                                            "k_orbit_rms",      "k_orbit_rms_slow",     "k_select_best",
                                            "k_diffcor"};
 
+}  // namespace
+
+namespace {
+// OUTFIT_TRACE=1: host-side phase times of the blocking call on stderr (tuning aid)
+struct Trace {
+  bool on = std::getenv("OUTFIT_TRACE") != nullptr;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  void mark(const char* what) {
+    if (!on) return;
+    const auto t = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[outfit trace] %-28s +%.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t0).count());
+    t0 = t;
+  }
+};
+thread_local Trace g_trace;
 }  // namespace
 
 struct outfit_hip_session {
@@ -190,11 +250,19 @@ struct outfit_hip_session {
   // fit_single_traj sorts a trajectory's observations by epoch (obs_dataset_api.rs:222-223); when the caller's rows are
   // not already in that order, resident row i holds the caller's row perm[i] (both rebased); empty = identity
   std::vector<uint64_t> perm;
+  // Streamed blocking call (outfit_hip_fit_full_iod): only traj_offset and mjd are uploaded when the session is built;
+  // the other columns follow in two groups while kernels that do not need them yet are already running
+  // (group 1 = ra, dec, obs_helio_equ: before K1's direction cosines and K2a; group 2 = sigma_ra, sigma_dec,
+  // obs_geo_ecl, the Chebyshev table: before K1's observer positions and K2c). See session_run.
+  struct Deferred { DevBuf<double>* d; const double* src; size_t rows; unsigned width; int group; bool use_perm; };
+  std::vector<Deferred> deferred;
+  bool streaming = false;
   const outfit::GaussResultRec* iod_out = nullptr;  // where the last IOD run wrote (d_out or `results`)
   outfit::EphemTable table{};
   outfit::GaussParams gp{};
   outfit::TripletParams tp{};
 
+  StreamSet streams;  // owns every stream and event handle below (device cache)
   hipStream_t own_stream = nullptr;
   hipStream_t aux_stream = nullptr;  // general correction kernel, beside K2c
   hipStream_t k0_stream = nullptr;   // triplet selection, ahead of the candidate kernels (and of the previous run's tail)
@@ -203,7 +271,7 @@ struct outfit_hip_session {
   hipEvent_t ev_unit_free[2] = {nullptr, nullptr};  // last K2a reading unit buffer b has finished
   bool unit_free_recorded[2] = {false, false};
   unsigned long long chunk_seq = 0, run_seq = 0;
-  hipEvent_t ev_start = nullptr, ev_prepass = nullptr, ev_fast = nullptr, ev_general = nullptr;
+  hipEvent_t ev_start = nullptr, ev_prepass = nullptr, ev_fast = nullptr, ev_general = nullptr, ev_unit = nullptr;
   hipEvent_t ev_sub[8] = {};
   hipStream_t last_stream = nullptr;
   hipEvent_t ev_done = nullptr;  // recorded after the last kernel of every run / run_lsq, on the stream it went to
@@ -220,8 +288,7 @@ struct outfit_hip_session {
     if (ev_done && done_recorded) (void)hipEventSynchronize(ev_done);
     for (hipStream_t st : {own_stream, aux_stream, k0_stream})
       if (st) (void)hipStreamSynchronize(st);
-    if (ev_done) (void)hipEventDestroy(ev_done);
-    ev_done = nullptr;
+    g_trace.mark("  destroy: sync");
     traj_offset.release(); traj_key.release(); mjd.release(); ra.release(); dec.release(); sra.release(); sdec.release();
     helio.release(); geo.release(); obs_pos.release(); cos_dec.release(); unit[0].release(); unit[1].release(); noise.release(); coef.release();
     heap_w.release(); sum.release(); dirS.release(); roots.release(); state.release();
@@ -233,22 +300,13 @@ struct outfit_hip_session {
     dc_initial.release(); dc_out.release(); dc_fit.release();
     for (auto& t : timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     timed.clear();
-    if (own_stream) (void)hipStreamDestroy(own_stream);
-    if (aux_stream) (void)hipStreamDestroy(aux_stream);
-    aux_stream = nullptr;
-    if (k0_stream) (void)hipStreamDestroy(k0_stream);
-    k0_stream = nullptr;
-    for (hipEvent_t* arr : {ev_k3, ev_unit_free})
-      for (int b = 0; b < 2; ++b) {
-        if (arr[b]) (void)hipEventDestroy(arr[b]);
-        arr[b] = nullptr;
-      }
-    for (hipEvent_t* e : {&ev_start, &ev_prepass, &ev_fast, &ev_general, &ev_sub[0], &ev_sub[1], &ev_sub[2], &ev_sub[3],
-                          &ev_sub[4], &ev_sub[5], &ev_sub[6], &ev_sub[7]}) {
-      if (*e) (void)hipEventDestroy(*e);
-      *e = nullptr;
-    }
-    own_stream = nullptr;
+    g_trace.mark("  destroy: buffers");
+    g_cache.put_streams(streams);
+    own_stream = aux_stream = k0_stream = nullptr;
+    ev_done = ev_start = ev_prepass = ev_fast = ev_general = ev_unit = nullptr;
+    for (int b = 0; b < 2; ++b) ev_k3[b] = ev_unit_free[b] = nullptr;
+    for (auto& e : ev_sub) e = nullptr;
+    g_trace.mark("  destroy: streams+events");
   }
 };
 
@@ -290,6 +348,12 @@ int check_batch(const outfit_iod_params_t* params, const outfit_obs_batch_t* b, 
   return OUTFIT_OK;
 }
 
+#define TRY_RC(expr)              \
+  do {                            \
+    int rc__ = (expr);            \
+    if (rc__ != OUTFIT_OK) return rc__; \
+  } while (0)
+
 // f64::total_cmp as a signed-integer key (library/core/src/num/f64.rs)
 inline int64_t total_order_key(double x) {
   int64_t b;
@@ -328,6 +392,36 @@ int upload_rows(DevBuf<double>& d, const double* src, size_t n_rows, unsigned wi
   return upload(d, tmp.data(), tmp.size());
 }
 
+int copy_rows(DevBuf<double>& d, const double* src, size_t n_rows, unsigned width, const std::vector<uint64_t>* perm) {
+  if (!n_rows) return OUTFIT_OK;
+  if (!perm || perm->empty()) {
+    HIP_TRY(hipMemcpy(d.p, src, n_rows * width * sizeof(double), hipMemcpyHostToDevice));
+    return OUTFIT_OK;
+  }
+  std::vector<double> tmp(n_rows * width);
+  for (size_t i = 0; i < n_rows; ++i)
+    for (unsigned k = 0; k < width; ++k) tmp[i * width + k] = src[(*perm)[i] * width + k];
+  HIP_TRY(hipMemcpy(d.p, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+  return OUTFIT_OK;
+}
+// allocate a resident column and upload it now, or (streamed call, group > 0) when its group is flushed
+int put_rows(outfit_hip_session* s, DevBuf<double>& d, const double* src, size_t n_rows, unsigned width, int group,
+             bool use_perm = true) {
+  HIP_TRY(d.alloc(n_rows * width));
+  if (s->streaming && group > 0) {
+    s->deferred.push_back({&d, src, n_rows, width, group, use_perm});
+    return OUTFIT_OK;
+  }
+  return copy_rows(d, src, n_rows, width, use_perm ? &s->perm : nullptr);
+}
+
+int flush_group(outfit_hip_session* s, int group) {
+  for (const auto& u : s->deferred)
+    if (u.group == group) TRY_RC(copy_rows(*u.d, u.src, u.rows, u.width, u.use_perm ? &s->perm : nullptr));
+  g_trace.mark(group == 1 ? "upload group 1" : "upload group 2");
+  return OUTFIT_OK;
+}
+
 template <typename T>
 int upload(DevBuf<T>& d, const T* src, size_t n) {
   HIP_TRY(d.alloc(n));
@@ -335,24 +429,23 @@ int upload(DevBuf<T>& d, const T* src, size_t n) {
   return OUTFIT_OK;
 }
 
-#define TRY_RC(expr)              \
-  do {                            \
-    int rc__ = (expr);            \
-    if (rc__ != OUTFIT_OK) return rc__; \
-  } while (0)
 
 int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, const outfit_obs_batch_t* b,
                   const outfit_ephem_t* eph) {
   HIP_TRY(hipSetDevice(s->device));
-  HIP_TRY(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
-  HIP_TRY(hipStreamCreateWithFlags(&s->aux_stream, hipStreamNonBlocking));
-  HIP_TRY(hipStreamCreateWithFlags(&s->k0_stream, hipStreamNonBlocking));
-  HIP_TRY(hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming));
-  for (hipEvent_t& e : s->ev_k3) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  for (hipEvent_t& e : s->ev_unit_free) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  for (hipEvent_t* e : {&s->ev_start, &s->ev_prepass, &s->ev_fast, &s->ev_general, &s->ev_sub[0], &s->ev_sub[1], &s->ev_sub[2], &s->ev_sub[3],
-                        &s->ev_sub[4], &s->ev_sub[5], &s->ev_sub[6], &s->ev_sub[7]})
-    HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  HIP_TRY(g_cache.get_streams(&s->streams));
+  {
+    StreamSet& ss = s->streams;
+    s->own_stream = ss.stream[0]; s->aux_stream = ss.stream[1]; s->k0_stream = ss.stream[2];
+    int k = 0;
+    s->ev_done = ss.event[k++];
+    for (hipEvent_t& e : s->ev_k3) e = ss.event[k++];
+    for (hipEvent_t& e : s->ev_unit_free) e = ss.event[k++];
+    s->ev_start = ss.event[k++]; s->ev_prepass = ss.event[k++]; s->ev_fast = ss.event[k++];
+    s->ev_general = ss.event[k++]; s->ev_unit = ss.event[k++];
+    for (hipEvent_t& e : s->ev_sub) e = ss.event[k++];  // 1 + 2 + 2 + 5 + 8 = 18
+  }
+  g_trace.mark("  streams+events");
   s->params = *params;
   s->math_mode = current_math_mode();
   s->n_traj = b->n_traj;
@@ -369,20 +462,23 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
   for (uint64_t t = 0; t <= s->n_traj && s->n_traj; ++t) off[t] = b->traj_offset[t] - o0;
   TRY_RC(upload(s->traj_offset, off.data(), off.size()));
   const size_t n = (size_t)s->n_obs;
+  g_trace.mark("  offsets");
   sort_permutation(b, s->perm);
-  TRY_RC(upload_rows(s->mjd, n ? b->mjd_tt + o0 : nullptr, n, 1, s->perm));
-  TRY_RC(upload_rows(s->ra, n ? b->ra + o0 : nullptr, n, 1, s->perm));
-  TRY_RC(upload_rows(s->dec, n ? b->dec + o0 : nullptr, n, 1, s->perm));
-  TRY_RC(upload_rows(s->sra, n ? b->sigma_ra + o0 : nullptr, n, 1, s->perm));
-  TRY_RC(upload_rows(s->sdec, n ? b->sigma_dec + o0 : nullptr, n, 1, s->perm));
+  g_trace.mark("  sortedness");
+  if (b->obs_body_fixed && b->mjd_ut1 && eph) s->streaming = false;  // the geometry pre-pass below needs everything resident
+  TRY_RC(put_rows(s, s->mjd, n ? b->mjd_tt + o0 : nullptr, n, 1, 0));
+  TRY_RC(put_rows(s, s->ra, n ? b->ra + o0 : nullptr, n, 1, 1));
+  TRY_RC(put_rows(s, s->dec, n ? b->dec + o0 : nullptr, n, 1, 1));
+  TRY_RC(put_rows(s, s->sra, n ? b->sigma_ra + o0 : nullptr, n, 1, 2));
+  TRY_RC(put_rows(s, s->sdec, n ? b->sigma_dec + o0 : nullptr, n, 1, 2));
   const bool device_geometry = b->obs_body_fixed && b->mjd_ut1 && eph;
   if (device_geometry) HIP_TRY(s->helio.alloc(3 * n));
-  else TRY_RC(upload_rows(s->helio, n ? b->obs_helio_equ + 3 * o0 : nullptr, n, 3, s->perm));
+  else TRY_RC(put_rows(s, s->helio, n ? b->obs_helio_equ + 3 * o0 : nullptr, n, 3, 1));
   HIP_TRY(s->cos_dec.alloc(n));
   for (int b = 0; b < 2; ++b) HIP_TRY(s->unit[b].alloc(3 * n));  // double-buffered: written ahead on k0_stream
   if (s->has_ephem && s->has_geo) {
     if (device_geometry) HIP_TRY(s->geo.alloc(3 * n));
-    else TRY_RC(upload_rows(s->geo, n ? b->obs_geo_ecl + 3 * o0 : nullptr, n, 3, s->perm));
+    else TRY_RC(put_rows(s, s->geo, n ? b->obs_geo_ecl + 3 * o0 : nullptr, n, 3, 2));
     HIP_TRY(s->obs_pos.alloc(3 * n));
     unsigned per_block = 0;
     for (int k = 0; k < 3; ++k) {
@@ -395,7 +491,7 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
     s->table.jd_start = eph->jd_start; s->table.jd_end = eph->jd_end;
     s->table.block_days = eph->block_days; s->table.emrat = eph->emrat;
     s->table.n_blocks = eph->n_blocks;
-    TRY_RC(upload(s->coef, eph->coef, (size_t)eph->n_blocks * per_block));
+    TRY_RC(put_rows(s, s->coef, eph->coef, (size_t)eph->n_blocks * per_block, 1, 2, /*use_perm=*/false));
     s->table.coef = s->coef.p;
   }
   s->noise_device = params->n_noise_realizations > 0 && b->noise_source == OUTFIT_NOISE_DEVICE;
@@ -407,6 +503,7 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
     TRY_RC(upload(s->noise, b->noise_z,
                   (size_t)s->n_traj * s->k_cap * (size_t)params->n_noise_realizations * 6));
   }
+  g_trace.mark("  input columns");
   HIP_TRY(s->results.alloc((size_t)s->n_traj));
   // status -1 until an IOD run fills the records (outfit_hip_session_run_lsq reads them as "no seed")
   if (s->n_traj) HIP_TRY(hipMemset(s->results.p, 0xFF, (size_t)s->n_traj * sizeof(outfit::GaussResultRec)));
@@ -427,6 +524,7 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
     if (e != hipSuccess) return fail(OUTFIT_ERR_HIP, hipGetErrorString(e));
   }
 
+  g_trace.mark("  results+flags");
   // chunking: bound the candidate scratch (~200 B per candidate) and the heap scratch. Sized for a 288 GB device:
   // up to 64 Mi candidates (~13 GB of scratch) and 1 Mi trajectories per chunk — 10^6 objects x 100 triplets are two
   // chunks; every chunk boundary costs a fill/drain of the persistent kernels (measured at 10 chunks: +8 %).
@@ -456,6 +554,7 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
   HIP_TRY(s->psi0.alloc(2 * n_cand));
   HIP_TRY(s->slow_list.alloc(n_cand));
   HIP_TRY(s->slow_count.alloc(1));
+  g_trace.mark("  scratch alloc");
   int n_cu = 0;
   HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, s->device));
   s->n_cu = n_cu > 0 ? (unsigned)n_cu : 256u;
@@ -525,21 +624,30 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
   pa.n_obs = s->n_obs; pa.mjd = s->mjd.p; pa.dec = s->dec.p; pa.geo_ecl = s->geo.p; pa.obs_pos = s->obs_pos.p;
   pa.cos_dec = s->cos_dec.p; pa.unit = s->unit[ub].p; pa.ra = s->ra.p; pa.has_table = on_device_earth;
   pa.T = s->table; pa.error_flag = s->error_flag.p; pa.math_mode = s->math_mode;
-  {
+  // Streamed blocking call: the inputs of these two launches are still on their way; each is enqueued (first chunk)
+  // right after its upload group, while K0 / the candidate kernels already run (see `Deferred`).
+  const bool streamed = s->streaming && !s->deferred.empty();
+  auto launch_unit = [&]() -> int {
     // the buffer's previous readers: the K2a launches of the run before the previous one
     if (s->unit_free_recorded[ub]) HIP_TRY(hipStreamWaitEvent(s->k0_stream, s->ev_unit_free[ub], 0));
     pa.parts = outfit::kPrepassUnit;
     Stamp stamp(s, s->k0_stream, K_PREPASS);
     HIP_TRY(outfit::launch_observer_prepass(pa, s->k0_stream));
-  }
-  {
-    HIP_TRY(hipEventRecord(s->ev_start, st));
-    HIP_TRY(hipStreamWaitEvent(aux, s->ev_start, 0));
+    return OUTFIT_OK;
+  };
+  auto launch_observer = [&]() -> int {
     pa.parts = outfit::kPrepassObserver;
     Stamp stamp(s, aux, K_PREPASS);
     HIP_TRY(outfit::launch_observer_prepass(pa, aux));
     HIP_TRY(hipEventRecord(s->ev_prepass, aux));
     s->prepass_done = true;
+    return OUTFIT_OK;
+  };
+  HIP_TRY(hipEventRecord(s->ev_start, st));
+  HIP_TRY(hipStreamWaitEvent(aux, s->ev_start, 0));
+  if (!streamed) {
+    TRY_RC(launch_unit());
+    TRY_RC(launch_observer());
   }
   // Two latency-bound kernels run on their own streams in the shadow of VALU-bound ones:
   //   * K0 (sequential heap per lane) in kSub slices on k0_stream, each one slice ahead of the K2a slice
@@ -592,6 +700,15 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
       }
       HIP_TRY(hipEventRecord(s->ev_sub[i], k0));
     }
+    if (streamed && t0 == 0) {
+      g_trace.mark("K0 enqueued");
+      // K0 is running on mjd alone; now ra, dec and the observer vectors go up, then the direction cosines (same
+      // stream as K0, behind its slices) — the first K2a launch below waits for them through ev_unit
+      TRY_RC(flush_group(s, 1));
+      TRY_RC(launch_unit());
+      HIP_TRY(hipEventRecord(s->ev_unit, k0));
+      HIP_TRY(hipStreamWaitEvent(st, s->ev_unit, 0));
+    }
     for (unsigned i = 0; i < n_sub; ++i) {
       const uint64_t a0 = nt * i / n_sub, a1 = nt * (i + 1) / n_sub;
       HIP_TRY(hipStreamWaitEvent(st, s->ev_sub[i], 0));
@@ -611,6 +728,14 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
       HIP_TRY(outfit::launch_gauss_correct_fast(ca, s->n_cu, st));
     }
     HIP_TRY(hipEventRecord(s->ev_fast, st));
+    if (streamed && t0 == 0) {
+      g_trace.mark("roots..fast enqueued");
+      // roots / cold starts / corrections are enqueued; the uncertainties, geocentric vectors and the Chebyshev table
+      // go up under them, then the observer positions (first read by K2c)
+      TRY_RC(flush_group(s, 2));
+      TRY_RC(launch_observer());
+      s->deferred.clear();
+    }
     HIP_TRY(hipStreamWaitEvent(aux, s->ev_fast, 0));
     {
       outfit::CorrectArgs cg = ca;
@@ -831,8 +956,20 @@ int outfit_hip_device_count(void) {
   return n;
 }
 
+}  // extern "C"
+namespace {
+int session_create(const outfit_iod_params_t* params, const outfit_obs_batch_t* batch, const outfit_ephem_t* ephem,
+                   int device, bool streaming, outfit_hip_session_t** out);
+}
+extern "C" {
 int outfit_hip_session_create(const outfit_iod_params_t* params, const outfit_obs_batch_t* batch,
                               const outfit_ephem_t* ephem, int device, outfit_hip_session_t** out) {
+  return session_create(params, batch, ephem, device, /*streaming=*/false, out);
+}
+}  // extern "C"
+namespace {
+int session_create(const outfit_iod_params_t* params, const outfit_obs_batch_t* batch, const outfit_ephem_t* ephem,
+                   int device, bool streaming, outfit_hip_session_t** out) {
   if (!out) return fail(OUTFIT_ERR_BAD_HANDLE, "out_session is NULL");
   *out = nullptr;
   TRY_RC(outfit_hip_iod_params_validate(params));
@@ -843,6 +980,7 @@ int outfit_hip_session_create(const outfit_iod_params_t* params, const outfit_ob
   if (device < 0 || device >= n_dev) return fail(OUTFIT_ERR_NO_DEVICE, "device index out of range");
   auto* s = new outfit_hip_session();
   s->device = device;
+  s->streaming = streaming;
   const int rc = session_build(s, params, batch, ephem);
   if (rc != OUTFIT_OK) {
     s->free_all();
@@ -852,6 +990,8 @@ int outfit_hip_session_create(const outfit_iod_params_t* params, const outfit_ob
   *out = s;
   return OUTFIT_OK;
 }
+}  // namespace
+extern "C" {
 
 int outfit_hip_session_run(outfit_hip_session_t* s, void* stream, void* d_out) {
   if (!s) return fail(OUTFIT_ERR_BAD_HANDLE, "session is NULL");
@@ -928,11 +1068,16 @@ int outfit_hip_fit_full_iod(const outfit_iod_params_t* params, const outfit_obs_
   if (!out && batch->n_traj) return fail(OUTFIT_ERR_INVALID_BATCH, "out is NULL");
   return run_sharded(params, batch, n_devices, [&](int d, const outfit_obs_batch_t& sub, uint64_t t0) {
     outfit_hip_session_t* s = nullptr;
-    int r = outfit_hip_session_create(params, &sub, ephem, d, &s);
+    g_trace.mark("(start)");
+    int r = session_create(params, &sub, ephem, d, /*streaming=*/std::getenv("OUTFIT_NO_STREAMED_UPLOAD") == nullptr, &s);
+    g_trace.mark("session_create");
     if (r == OUTFIT_OK) r = outfit_hip_session_run(s, nullptr, nullptr);
+    g_trace.mark("session_run (enqueue)");
     if (r == OUTFIT_OK) r = outfit_hip_session_results(s, out + t0);
+    g_trace.mark("session_results");
     const std::string keep = g_last_error;
     outfit_hip_session_destroy(s);
+    g_trace.mark("session_destroy");
     g_last_error = keep;
     return r;
   });
