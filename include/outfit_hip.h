@@ -423,6 +423,10 @@ int outfit_hip_selftest_crmath(uint64_t n_args, uint64_t seed, uint64_t *counts 
  * correctly rounded); 9 / 10 / 11 / 12 = sin / cos / sinh / cosh of OUTFIT_MATH_GLIBC (device/glibcmath.hpp);
  * fn & 16 selects the full double-double evaluation instead of the table fast path + rounding test. */
 int outfit_hip_crmath_eval(int fn, uint64_t n, const double *x, double *out);
+/* Profiling aid: streams n_doubles doubles in and out (8 bytes per lane, coalesced) `repeats` times. Run under
+ * rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE it calibrates those counters for the 8-byte access width of this
+ * library's kernels (tools/profile_gpu.sh); the true traffic is n_doubles * 8 bytes each way per repeat. */
+int outfit_hip_calibration_stream(uint64_t n_doubles, int repeats);
 /* `prelim_kepuni` (kepler/params.rs:185-191), the cold-start value of the universal Kepler solve, for n explicit
  * problems of 6 doubles (dt, r0, sig0, alpha, e0, convergency; mu = GAUSS_GRAV^2), in the current math mode —
  * the reference's libm-dependent KAT (kepler/params.rs:689-725) is checked through this. */

@@ -1291,6 +1291,23 @@ int outfit_hip_crmath_eval(int fn, uint64_t n, const double* x, double* out) {
   return OUTFIT_OK;
 }
 
+int outfit_hip_calibration_stream(uint64_t n_doubles, int repeats) {
+  if (n_doubles == 0 || repeats <= 0) return OUTFIT_OK;
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+    return fail(OUTFIT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+  DevBuf<double> a, b;
+  HIP_TRY(a.alloc((size_t)n_doubles));
+  hipError_t e = b.alloc((size_t)n_doubles);
+  if (e == hipSuccess) e = hipMemset(a.p, 0, (size_t)n_doubles * sizeof(double));
+  for (int r = 0; r < repeats && e == hipSuccess; ++r) e = outfit::launch_calibration_stream(n_doubles, a.p, b.p, nullptr);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  a.release();
+  b.release();
+  if (e != hipSuccess) return fail(OUTFIT_ERR_HIP, hipGetErrorString(e));
+  return OUTFIT_OK;
+}
+
 int outfit_hip_prelim_kepuni(uint64_t n, const double* problems, double* out) {
   if (n == 0) return OUTFIT_OK;
   if (!problems || !out) return fail(OUTFIT_ERR_INVALID_BATCH, "NULL argument");

@@ -182,6 +182,7 @@ hipError_t launch_device_normals(unsigned long long seed, const unsigned long lo
                                  unsigned n_noise, double* out, hipStream_t s);
 hipError_t launch_selftest_aberth(unsigned long long n_threads, unsigned long long n_per_thread,
                                   unsigned long long seed, unsigned long long* d_out, hipStream_t s);
+hipError_t launch_calibration_stream(unsigned long long n, const double* in, double* out, hipStream_t s);
 hipError_t launch_prelim_kepuni(unsigned long long n, const double* prob, int math_mode, double* out, hipStream_t s);
 hipError_t launch_crmath_eval(int fn, unsigned long long n, const double* x, double* out, hipStream_t s);
 hipError_t launch_selftest_crmath(unsigned long long n_threads, unsigned long long n_per_thread,

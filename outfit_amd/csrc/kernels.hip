@@ -951,6 +951,21 @@ k_crmath_eval(int fn, unsigned long long n, const double* x, double* out, SinCos
   out[i] = r;
 }
 
+// Calibration of the HBM byte counters for THIS library's access width: every kernel here reads and writes 8 bytes
+// per lane (SoA doubles), a width the rocprofv3 FETCH_SIZE / WRITE_SIZE derivations are not calibrated for on gfx950
+// (MI355X_MICROARCH.md, HBM section). This kernel streams n doubles in and n doubles out, 8 B per lane, coalesced;
+// with n * 8 B far beyond the 256 MiB Infinity Cache the true traffic is n * 8 B each way.
+__global__ void __launch_bounds__(256)
+k_calibration_stream(unsigned long long n, const double* in, double* out) {
+  const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i] * 2.0;
+}
+hipError_t launch_calibration_stream(unsigned long long n, const double* in, double* out, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_calibration_stream, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, in, out);
+  return hipGetLastError();
+}
+
 // outfit_hip_prelim_kepuni: the cold-start value of the universal Kepler solve (kepler/params.rs:185-191) for
 // explicit problems (dt, r0, sig0, alpha, e0, convergency), in the given math mode
 __global__ void __launch_bounds__(256)

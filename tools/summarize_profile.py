@@ -43,6 +43,23 @@ shutil.copy(stats, os.path.join(ROOT, "profiles", f"{name}_kernel_stats.csv"))
 fetch, cf = counters("pmc_fetch")
 write, cw = counters("pmc_write")
 sq, cs = counters("pmc_sq")
+f64, c64 = counters("pmc_f64")
+# calibration of the byte counters on this library's access width (8 B per lane): tools/calib_stream.py streams
+# 2^28 doubles in and out per launch; factor = true bytes / reported bytes (reported in KiB)
+CAL_BYTES = (1 << 28) * 8.0
+cal_f, ccf = counters("calib_fetch")
+cal_w, ccw = counters("calib_write")
+k_cal = "k_calibration_stream"
+fetch_factor = write_factor = None
+if ccf.get(k_cal) and cal_f.get((k_cal, "FETCH_SIZE")):
+    fetch_factor = CAL_BYTES / (cal_f[(k_cal, "FETCH_SIZE")] * 1024 / ccf[k_cal])
+if ccw.get(k_cal) and cal_w.get((k_cal, "WRITE_SIZE")):
+    write_factor = CAL_BYTES / (cal_w[(k_cal, "WRITE_SIZE")] * 1024 / ccw[k_cal])
+source_hash = None
+try:
+    source_hash = open(os.path.join(src, "source_hash.txt")).read().strip()
+except OSError:
+    pass
 kernels = sorted({k for k, _ in sq})
 per_step = {}
 lines = []
@@ -63,7 +80,7 @@ derived = []
 total_valu = 0.0
 for k in kernels:
     r = per_step[k]
-    fb, wb = r["FETCH_SIZE"] * 1024, r["WRITE_SIZE"] * 1024
+    fb, wb = r["FETCH_SIZE"] * 1024 * (fetch_factor or 1.0), r["WRITE_SIZE"] * 1024 * (write_factor or 1.0)
     total_valu += r["SQ_INSTS_VALU"] if not k.startswith("k_diffcor") else 0.0
     derived.append("%-24s VALU wave-instr %.3e  per wave %9.0f  VALU-active/wave-cycles %.2f  fetch %8.1f MB  write %8.1f MB"
                    % (k, r["SQ_INSTS_VALU"], r["SQ_INSTS_VALU"] / max(1.0, r["SQ_WAVES"]),
@@ -78,18 +95,35 @@ with open(out, "w") as f:
     f.write(open(stats).read())
     f.write("```\n## PMC passes (separate runs: --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_*; bench.py --steps 1 --warmup 0)\n"
             "Totals per step (= per launch set over the step's objects; a kernel launched in several slices or twice in\n"
-            "the run is divided by its number of steps). FETCH_SIZE / WRITE_SIZE in KiB as reported; the guide's gfx950\n"
-            "FETCH_SIZE correction is NOT applied (8-byte-per-lane SoA gathers are an uncalibrated access width): treat the\n"
-            "read volume as a lower bound within 2x.\n```\n")
+            "the run is divided by its number of steps). FETCH_SIZE / WRITE_SIZE in KiB as reported. The guide calibrates these\n"
+            "counters for 16-byte-per-lane streams only (gfx950: FETCH_SIZE reports half the bytes) and asks for a calibration\n"
+            "in one's own access pattern otherwise: k_calibration_stream (8 B per lane, 2 GiB each way per launch, far beyond\n"
+            f"the Infinity Cache) gives true/reported = {fetch_factor} for FETCH_SIZE and {write_factor} for WRITE_SIZE;\n"
+            "the `derived` block and profiles/latest_pmc.json apply these factors.\n```\n")
     f.write("\n".join(lines) + "\n```\n## derived\n```\n" + "\n".join(derived) + "\n")
-    f.write("IOD kernels: total VALU wave-instructions per step %.3e; at 1024 SIMDs x ~2.1 GHz / 4.3 cycles per "
-            "fp64-dominated instruction = 5.0e11/s this is %.1f ms of pure issue time\n```\n" % (total_valu, total_valu / 5.0e11 * 1e3))
-pmc = {"source": f"profiles/{name}_rocprof_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+    f.write("IOD kernels: total VALU wave-instructions per step %.3e; at the fp64 issue peak of 1024 SIMDs x 2.4 GHz / 4 "
+            "cycles = 6.14e11 wave-instructions/s this is %.1f ms of pure issue time\n" % (total_valu, total_valu / 6.144e11 * 1e3))
+    if f64:
+        f.write("\nfp64 instruction mix (wave-instructions per step; SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64):\n")
+        tot = collections.Counter()
+        for k in kernels:
+            st = max(1.0, c64.get(k, 0) / LAUNCHES_PER_STEP.get(k, 1))
+            row = {c: f64.get((k, c), 0.0) / st for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")}
+            f.write("%-24s add %.3e  mul %.3e  fma %.3e  trans %.3e\n" % (k, *row.values()))
+            if not k.startswith("k_diffcor"):
+                tot.update(row)
+        fl = (tot["SQ_INSTS_VALU_ADD_F64"] + tot["SQ_INSTS_VALU_MUL_F64"] + 2 * tot["SQ_INSTS_VALU_FMA_F64"] + tot["SQ_INSTS_VALU_TRANS_F64"]) * 64
+        f.write("IOD kernels: executed fp64 lane-operations per step (add + mul + 2 fma + trans, x 64 lanes, upper bound: "
+                "inactive lanes included) %.3e = %.3e per object\n" % (fl, fl / n_obj))
+    f.write("```\n")
+pmc = {"source": f"profiles/{name}_rocprof_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_*, separate passes; "
+                 "byte counters calibrated on 8-B-per-lane streams)",
+       "source_hash": source_hash, "fetch_factor": fetch_factor, "write_factor": write_factor,
        "objects_per_step": n_obj, "kernels": {}}
 for k in kernels:
     r = per_step[k]
-    pmc["kernels"][k] = {"hbm_bytes_per_step": (r["FETCH_SIZE"] + r["WRITE_SIZE"]) * 1024,
-                         "fetch_bytes": r["FETCH_SIZE"] * 1024, "write_bytes": r["WRITE_SIZE"] * 1024,
+    fb, wb = r["FETCH_SIZE"] * 1024 * (fetch_factor or 1.0), r["WRITE_SIZE"] * 1024 * (write_factor or 1.0)
+    pmc["kernels"][k] = {"hbm_bytes_per_step": fb + wb, "fetch_bytes": fb, "write_bytes": wb,
                          "valu_wave_instr": r["SQ_INSTS_VALU"]}
 json.dump(pmc, open(os.path.join(ROOT, "profiles", "latest_pmc.json"), "w"), indent=1)
 print(open(out).read())
