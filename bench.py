@@ -330,6 +330,20 @@ def main():
                 pass
             # the counted algorithmic fp64 work (tools/count_flops.py on the 1 000-object fixture) against the fp64 peak
             fp64 = None
+            executed = None
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
+                if pmc.get("source_hash") == source_hash():
+                    ops = sum(k.get("fp64_lane_ops_upper", 0.0) for n, k in pmc["kernels"].items() if not n.startswith("k_diffcor"))
+                    if ops > 0:
+                        per_obj = ops / pmc["objects_per_step"]
+                        executed = {"fp64_lane_ops_per_object_upper": per_obj,
+                                    "achieved_tflops": value / world * per_obj / 1e12,
+                                    "frac": value / world * per_obj / 1e12 / FP64_PEAK_TFLOPS, "kind": "static_profile",
+                                    "what": "SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 lanes (FMA = 2; inactive lanes "
+                                            "included) of the committed profile of this build"}
+            except (OSError, KeyError, ValueError):
+                pass
             try:
                 fl = json.load(open(os.path.join(ROOT, "profiles", "flops_per_object.json")))
                 f_obj = fl["hoisted"]["total_fp64_ops_per_object"]
@@ -338,6 +352,7 @@ def main():
                         "reference_decomposition_ops_per_object": fl["reference"]["total_fp64_ops_per_object"],
                         "achieved_tflops": value / world * f_obj / 1e12, "peak_tflops": FP64_PEAK_TFLOPS,
                         "frac": value / world * f_obj / 1e12 / FP64_PEAK_TFLOPS,
+                        "executed": executed,
                         "note": "algorithmic = what the reference's arithmetic executes per object (counted on the CPU "
                                 "restatement, Earth hoisted); the device SKIPS part of it exactly (fixed-point exit of the "
                                 "correction loop: 55 % of its iterations), so this is work retired, not instructions "

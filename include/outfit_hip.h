@@ -250,6 +250,27 @@ int outfit_hip_propagate_universal(uint64_t n, const double *r0v0 /* 6n */,
                                    double convergency,
                                    double *out /* 11n */, int32_t *status /* n */);
 
+/* The full `SolverType { kind, params: SolverParams }` of the reference (kepler/params.rs:24-73). */
+#define OUTFIT_SOLVER_NEWTON_RAPHSON 0 /* SolverKind::NewtonRaphson (default)                                   */
+#define OUTFIT_SOLVER_BRENT_DECKER   1 /* SolverKind::BrentDecker   (kepler/brent_dekker_solver.rs)               */
+#define OUTFIT_SOLVER_AUTO           2 /* SolverKind::Auto: Newton, then Brent-Dekker on failure (params.rs:138-140) */
+#define OUTFIT_PARABOLIC_CARDANO     0 /* ParabolicPrelimMethod::Cardano (default; prelim_parabolic.rs:77-93)     */
+#define OUTFIT_PARABOLIC_NEWTON      1 /* ParabolicPrelimMethod::Newton                                           */
+typedef struct outfit_solver_type {
+  int32_t  kind;                     /* OUTFIT_SOLVER_*                                   */
+  int32_t  parabolic_solving_method; /* OUTFIT_PARABOLIC_*                                */
+  double   convergency;              /* SolverParams.convergency, default 100 eps         */
+  uint64_t max_iter_prelim_kepuni;   /* default 20                                        */
+  int32_t  has_psi_guess;            /* SolverParams.psi_guess: Option<f64>               */
+  int32_t  _pad;
+  double   psi_guess;                /* applied to every state of the batch when present  */
+} outfit_solver_type_t;
+void outfit_hip_solver_type_default(outfit_solver_type_t *s); /* SolverType::default() (params.rs:35-44,66-73) */
+/* status[i] as above, plus 4 = BrentDekkerKeplerConvergence (kinds BrentDecker and Auto, params.rs:134-141). */
+int outfit_hip_propagate_universal_ex(uint64_t n, const double *r0v0 /* 6n */, const double *t0, const double *t1,
+                                      const outfit_solver_type_t *solver,
+                                      double *out /* 11n */, int32_t *status /* n */);
+
 /* ==== next row: FitLSQ::fit_lsq — differential orbit correction =========
  * Replaces the per-trajectory loop of `FitLSQ::fit_lsq`
  * (differential_orbit_correction/obs_dataset_api.rs:57-130) after the dataset

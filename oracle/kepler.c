@@ -151,8 +151,34 @@ static void cubic_res_der(double psi, double r0, double sig0, double smdt, doubl
   *der = powi2(psi) / 2.0 + sig0 * psi + r0;
 }
 
-/* kepler/prelim_kepler/prelim_parabolic.rs:264-477 (Cardano, the default method) */
+static double prelim_parabolic_cardano(const orc_kepler_params *p);
+
+/* kepler/prelim_kepler/prelim_parabolic.rs:198-246 (ParabolicPrelimMethod::Newton): safeguarded Newton on the cubic,
+ * only when it is monotonic (:171-173), else Cardano */
+static double prelim_parabolic_newton(const orc_kepler_params *p) {
+  double smdt = sqrt(p->mu) * p->dt;
+  if (p->dt == 0.0) return 0.0;
+  if (p->sig0 * p->sig0 > 2.0 * p->r0) return prelim_parabolic_cardano(p);
+  double psi = smdt / p->r0;
+  for (int i = 0; i < p->max_iter_prelim_kepuni; ++i) {
+    double res, der;
+    cubic_res_der(psi, p->r0, p->sig0, smdt, &res, &der);
+    if (!isfinite(der) || fabs(der) < 10.0 * ORC_EPS) { psi *= 0.5; continue; }
+    double raw = -res / der, mx = 2.0 * (1.0 + fabs(psi));
+    double step = clampd(raw, -mx, mx);
+    psi += step;
+    if (fabs(step) < p->convergency) break;
+  }
+  return psi;
+}
+
+/* kepler/prelim_kepler/prelim_parabolic.rs:120-130 */
 double orc_prelim_parabolic(const orc_kepler_params *p) {
+  return p->parabolic_method == 1 ? prelim_parabolic_newton(p) : prelim_parabolic_cardano(p);
+}
+
+/* kepler/prelim_kepler/prelim_parabolic.rs:264-477 (Cardano, the default method) */
+static double prelim_parabolic_cardano(const orc_kepler_params *p) {
   double r0 = p->r0, sig0 = p->sig0, dt = p->dt;
   double smdt = sqrt(p->mu) * dt;
   if (dt == 0.0) return 0.0;
@@ -399,8 +425,37 @@ int orc_propagate_universal(const double r[3], const double v[3], double t0, dou
   memset(&p, 0, sizeof p);
   p.r0 = r0; p.sig0 = sig0; p.mu = mu; p.alpha = alpha; p.dt = t1 - t0; p.e0 = e;
   p.convergency = convergency; p.has_guess = 0; p.max_iter_prelim_kepuni = 20; p.kind = kind;
+  return orc_propagate_with_params(r, v, &p, out);
+}
+
+/* the same with the full SolverType (kepler/params.rs:24-73): kind, convergency, psi_guess, max_iter_prelim_kepuni,
+ * parabolic_solving_method are read from *st; status 2 = NewtonRaphsonKeplerConvergence, 4 =
+ * BrentDekkerKeplerConvergence (params.rs:130-142) */
+int orc_propagate_universal_ex(const double r[3], const double v[3], double t0, double t1,
+                               const outfit_solver_type_t *st, double out[11]) {
+  const double mu = ORC_GAUSS_GRAV * ORC_GAUSS_GRAV;
+  double r0 = norm3(r);
+  if (r0 < ORC_EPS) return 1;
+  double v2 = dot3(v, v);
+  double h[3];
+  cross3(r, v, h);
+  double alpha = (v2 - 2.0 * mu / r0) / mu;
+  double e = sqrt(1.0 + alpha * dot3(h, h) / mu);
+  if (!(e >= 0.0)) e = 0.0;
+  orc_kepler_params p;
+  memset(&p, 0, sizeof p);
+  p.r0 = r0; p.sig0 = dot3(r, v) / sqrt(mu); p.mu = mu; p.alpha = alpha; p.dt = t1 - t0; p.e0 = e;
+  p.convergency = st->convergency; p.has_guess = st->has_psi_guess; p.psi_guess = st->psi_guess;
+  p.max_iter_prelim_kepuni = st->max_iter_prelim_kepuni > 0x7fffffff ? 0x7fffffff : (int)st->max_iter_prelim_kepuni;
+  p.kind = st->kind; p.parabolic_method = st->parabolic_solving_method;
+  return orc_propagate_with_params(r, v, &p, out);
+}
+
+int orc_propagate_with_params(const double r[3], const double v[3], const orc_kepler_params *pp, double out[11]) {
+  const orc_kepler_params p = *pp;
+  const double mu = p.mu, r0 = p.r0, sig0 = p.sig0;
   orc_kepler_solution s;
-  if (!orc_kepler_solve(&p, &s)) return 2;
+  if (!orc_kepler_solve(&p, &s)) return p.kind == 0 ? 2 : 4;
   double sqrt_mu = sqrt(mu);
   double r1 = r0 * s.s0 + sig0 * s.s1 + s.s2;
   if (r1 < ORC_EPS) return 3;

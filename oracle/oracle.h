@@ -78,6 +78,7 @@ typedef struct {
   double psi_guess;
   int max_iter_prelim_kepuni;  /* params.rs:30, default 20                    */
   int kind;                    /* 0 NewtonRaphson, 1 BrentDecker, 2 Auto      */
+  int parabolic_method;        /* ParabolicPrelimMethod: 0 Cardano (default), 1 Newton (prelim_parabolic.rs:77-93) */
 } orc_kepler_params;
 
 typedef struct { double psi, s0, s1, s2, s3; } orc_kepler_solution;
@@ -97,6 +98,9 @@ int    orc_velocity_correction_with_guess(const double x1[3], const double x2[3]
                                           double chi_guess, double eps, double v_out[3], double *f,
                                           double *g, double *chi);
 /* out: r1[3] v1[3] f g fdot gdot psi ; returns status as outfit_hip_propagate_universal */
+int    orc_propagate_with_params(const double r[3], const double v[3], const orc_kepler_params *p, double out[11]);
+int    orc_propagate_universal_ex(const double r[3], const double v[3], double t0, double t1,
+                                  const outfit_solver_type_t *st, double out[11]);
 int    orc_propagate_universal(const double r[3], const double v[3], double t0, double t1,
                                double convergency, int kind, double out[11]);
 

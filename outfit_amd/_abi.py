@@ -146,6 +146,17 @@ NOISE_HOST = 0
 NOISE_DEVICE = 1
 
 
+class SolverTypeC(C.Structure):
+    """outfit_solver_type_t = SolverType { kind, params: SolverParams } (kepler/params.rs:24-73)"""
+    _fields_ = [("kind", C.c_int32), ("parabolic_solving_method", C.c_int32), ("convergency", C.c_double),
+                ("max_iter_prelim_kepuni", C.c_uint64), ("has_psi_guess", C.c_int32), ("_pad", C.c_int32),
+                ("psi_guess", C.c_double)]
+
+
+SOLVER_NEWTON_RAPHSON, SOLVER_BRENT_DECKER, SOLVER_AUTO = 0, 1, 2
+PARABOLIC_CARDANO, PARABOLIC_NEWTON = 0, 1
+
+
 class DiffCorConfigC(C.Structure):
     _fields_ = [
         ("max_newton_iterations", C.c_uint64),

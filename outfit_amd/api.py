@@ -621,9 +621,47 @@ def device_normals(noise_seed, n_traj, max_triplets, n_noise, traj_key=None, tra
     return out
 
 
-def propagate_universal(r, v, t0, t1, convergency=100 * 2.220446049250313e-16):
-    """Batched `kepler::propagate_universal` (kepler/propagation.rs:114-174), NewtonRaphson solver.
-    Returns (out[n,11] = r1,v1,f,g,fdot,gdot,psi ; status[n])."""
+class SolverType:
+    """`SolverType { kind, params: SolverParams }` (kepler/params.rs:24-73): kind 'NewtonRaphson' | 'BrentDecker' |
+    'Auto'; convergency; psi_guess (None = cold start); max_iter_prelim_kepuni; parabolic_solving_method 'Cardano' | 'Newton'."""
+    KINDS = {"NewtonRaphson": 0, "BrentDecker": 1, "Auto": 2}
+    PARABOLIC = {"Cardano": 0, "Newton": 1}
+
+    def __init__(self, kind="NewtonRaphson", convergency=100 * 2.220446049250313e-16, psi_guess=None,
+                 max_iter_prelim_kepuni=20, parabolic_solving_method="Cardano"):
+        self.kind, self.convergency, self.psi_guess = kind, convergency, psi_guess
+        self.max_iter_prelim_kepuni, self.parabolic_solving_method = max_iter_prelim_kepuni, parabolic_solving_method
+
+    def as_c(self):
+        c = _abi.SolverTypeC()
+        c.kind = self.KINDS[self.kind] if isinstance(self.kind, str) else int(self.kind)
+        pm = self.parabolic_solving_method
+        c.parabolic_solving_method = self.PARABOLIC[pm] if isinstance(pm, str) else int(pm)
+        c.convergency = self.convergency
+        c.max_iter_prelim_kepuni = self.max_iter_prelim_kepuni
+        c.has_psi_guess = 0 if self.psi_guess is None else 1
+        c.psi_guess = 0.0 if self.psi_guess is None else self.psi_guess
+        return c
+
+
+def propagate_universal(r, v, t0, t1, convergency=100 * 2.220446049250313e-16, solver=None):
+    """Batched `kepler::propagate_universal` (kepler/propagation.rs:114-174). `solver`: a SolverType (default:
+    NewtonRaphson with `convergency`). Returns (out[n,11] = r1,v1,f,g,fdot,gdot,psi ; status[n]); status 0 ok,
+    1 / 3 DegenerateState, 2 NewtonRaphsonKeplerConvergence, 4 BrentDekkerKeplerConvergence."""
+    if solver is not None:
+        r, v = _f64(r).reshape(-1, 3), _f64(v).reshape(-1, 3)
+        n = r.shape[0]
+        rv = np.ascontiguousarray(np.concatenate([r, v], axis=1))
+        t0a, t1a = _f64(np.broadcast_to(t0, (n,))), _f64(np.broadcast_to(t1, (n,)))
+        out = np.empty((n, 11))
+        st = np.empty(n, dtype=np.int32)
+        sc = solver.as_c()
+        rc = lib().outfit_hip_propagate_universal_ex(n, rv.ctypes.data_as(_dp), t0a.ctypes.data_as(_dp),
+                                                     t1a.ctypes.data_as(_dp), C.byref(sc), out.ctypes.data_as(_dp),
+                                                     st.ctypes.data_as(C.POINTER(C.c_int32)))
+        if rc != 0:
+            _raise_rc(rc)
+        return out, st
     r, v = _f64(r).reshape(-1, 3), _f64(v).reshape(-1, 3)
     n = r.shape[0]
     rv = np.ascontiguousarray(np.concatenate([r, v], axis=1))

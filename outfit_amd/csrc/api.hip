@@ -1345,8 +1345,36 @@ int outfit_hip_selftest_division(uint64_t n_pairs, uint64_t seed, uint64_t* mism
   return OUTFIT_OK;
 }
 
+void outfit_hip_solver_type_default(outfit_solver_type_t* s) {
+  std::memset(s, 0, sizeof *s);
+  s->kind = OUTFIT_SOLVER_NEWTON_RAPHSON;
+  s->parabolic_solving_method = OUTFIT_PARABOLIC_CARDANO;
+  s->convergency = 100.0 * std::numeric_limits<double>::epsilon();
+  s->max_iter_prelim_kepuni = 20;
+}
+
 int outfit_hip_propagate_universal(uint64_t n, const double* r0v0, const double* t0, const double* t1,
                                    double convergency, double* out, int32_t* status) {
+  outfit_solver_type_t st;
+  outfit_hip_solver_type_default(&st);
+  st.convergency = convergency;
+  return outfit_hip_propagate_universal_ex(n, r0v0, t0, t1, &st, out, status);
+}
+
+int outfit_hip_propagate_universal_ex(uint64_t n, const double* r0v0, const double* t0, const double* t1,
+                                      const outfit_solver_type_t* solver, double* out, int32_t* status) {
+  if (!solver) return fail(OUTFIT_ERR_INVALID_PARAM, "solver is NULL");
+  if (solver->kind < 0 || solver->kind > OUTFIT_SOLVER_AUTO)
+    return fail(OUTFIT_ERR_INVALID_PARAM, "solver kind must be OUTFIT_SOLVER_NEWTON_RAPHSON, _BRENT_DECKER or _AUTO");
+  if (solver->parabolic_solving_method != OUTFIT_PARABOLIC_CARDANO && solver->parabolic_solving_method != OUTFIT_PARABOLIC_NEWTON)
+    return fail(OUTFIT_ERR_INVALID_PARAM, "parabolic_solving_method must be OUTFIT_PARABOLIC_CARDANO or _NEWTON");
+  outfit::SolverSpec sv;
+  sv.kind = solver->kind;
+  sv.parabolic_newton = solver->parabolic_solving_method == OUTFIT_PARABOLIC_NEWTON;
+  sv.max_iter_prelim = solver->max_iter_prelim_kepuni > 0x7fffffffull ? 0x7fffffff : (int)solver->max_iter_prelim_kepuni;
+  sv.has_guess = solver->has_psi_guess != 0;
+  sv.guess = solver->psi_guess;
+  sv.convergency = solver->convergency;
   if (n == 0) return OUTFIT_OK;
   if (!r0v0 || !t0 || !t1 || !out || !status) return fail(OUTFIT_ERR_INVALID_BATCH, "NULL argument");
   int n_dev = 0;
@@ -1364,7 +1392,7 @@ int outfit_hip_propagate_universal(uint64_t n, const double* r0v0, const double*
       rc = fail(OUTFIT_ERR_HIP, "hipMalloc failed");
       break;
     }
-    hipError_t e = outfit::launch_propagate_universal(n, d_rv.p, d_t0.p, d_t1.p, convergency, current_math_mode(), d_out.p, d_st.p,
+    hipError_t e = outfit::launch_propagate_universal(n, d_rv.p, d_t0.p, d_t1.p, sv, current_math_mode(), d_out.p, d_st.p,
                                                       nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(out, d_out.p, (size_t)11 * n * sizeof(double), hipMemcpyDeviceToHost);

@@ -136,6 +136,9 @@ __device__ __forceinline__ void sinhcosh_mode(int mode, double x, double& s, dou
 struct KeplerProblem {
   double dt, r0, sig0, alpha, e0, convergency;
   int math_mode;
+  // SolverParams (kepler/params.rs:24-44); the IOD path always uses the defaults below (compile-time constants there)
+  int max_iter_prelim = 20;   // max_iter_prelim_kepuni
+  int parabolic_newton = 0;   // ParabolicPrelimMethod::Newton instead of Cardano
 };
 
 // kepler/prelim_kepler/prelim_elliptic.rs:9-134
@@ -159,7 +162,7 @@ __device__ __forceinline__ double prelim_elliptic(const KeplerProblem& p) {
   // not unrolled: the body inlines the correctly-rounded functions with their second steps (~1-2 k instructions);
   // 20 copies of it made this the largest code of the library for no measurable gain
 #pragma unroll 1
-  for (int i = 0; i < 20; ++i) {
+  for (int i = 0; i < p.max_iter_prelim; ++i) {
     double su, cu;
     sincos_mode(p.math_mode, u, su, cu);
     const double res = u - p.e0 * su - m;
@@ -186,7 +189,7 @@ __device__ __forceinline__ double prelim_hyperbolic(const KeplerProblem& p) {
   // not unrolled: the body inlines the correctly-rounded functions with their second steps (~1-2 k instructions);
   // 20 copies of it made this the largest code of the library for no measurable gain
 #pragma unroll 1
-  for (int i = 0; i < 20; ++i) {
+  for (int i = 0; i < p.max_iter_prelim; ++i) {
     if (fabs(f) < 15.0) {
       sinhcosh_mode(p.math_mode, f, sh, ch);
       const double res = p.e0 * sh - f - m;
@@ -208,7 +211,7 @@ __device__ __forceinline__ void cubic_res_der(double psi, double r0, double sig0
 }
 
 // kepler/prelim_kepler/prelim_parabolic.rs:264-477 (Cardano; reached only for alpha == 0)
-__device__ __forceinline__ double prelim_parabolic(const KeplerProblem& p) {
+__device__ __forceinline__ double prelim_parabolic_cardano(const KeplerProblem& p) {
   const double r0 = p.r0, sig0 = p.sig0;
   const double smdt = sqrt(kMu) * p.dt;
   if (p.dt == 0.0) return 0.0;
@@ -261,6 +264,27 @@ __device__ __forceinline__ double prelim_parabolic(const KeplerProblem& p) {
   return psi;
 }
 
+// kepler/prelim_kepler/prelim_parabolic.rs:198-246 (ParabolicPrelimMethod::Newton; Cardano when the cubic is not monotonic)
+__device__ __forceinline__ double prelim_parabolic_newton(const KeplerProblem& p) {
+  const double smdt = sqrt(kMu) * p.dt;
+  if (p.dt == 0.0) return 0.0;
+  if (p.sig0 * p.sig0 > 2.0 * p.r0) return prelim_parabolic_cardano(p);
+  double psi = smdt / p.r0;
+  for (int i = 0; i < p.max_iter_prelim; ++i) {
+    double res, der;
+    cubic_res_der(psi, p.r0, p.sig0, smdt, res, der);
+    if (!isfinite(der) || fabs(der) < 10.0 * kEps) { psi *= 0.5; continue; }
+    const double mx = 2.0 * (1.0 + fabs(psi));
+    const double step = clampd(-res / der, -mx, mx);
+    psi += step;
+    if (fabs(step) < p.convergency) break;
+  }
+  return psi;
+}
+__device__ __forceinline__ double prelim_parabolic(const KeplerProblem& p) {
+  return p.parabolic_newton ? prelim_parabolic_newton(p) : prelim_parabolic_cardano(p);
+}
+
 // kepler/params.rs:185-191
 __device__ __forceinline__ double prelim_kepuni(const KeplerProblem& p) {
   if (p.alpha < 0.0) return prelim_elliptic(p);
@@ -308,6 +332,77 @@ __device__ __forceinline__ KeplerSolution run_newton(const KeplerProblem& p, dou
 // solve_kepuni_with_guess (newton_solver.rs:151-161): psi_guess or the cold-start value
 __device__ __forceinline__ KeplerSolution solve_kepuni(const KeplerProblem& p, bool has_guess, double guess) {
   return run_newton(p, has_guess ? guess : prelim_kepuni(p));
+}
+
+// kepler/brent_dekker_solver.rs:59-62
+__device__ __forceinline__ double kepler_residual(double psi, const KeplerProblem& p) {
+  const Stumpff s = s_funct(psi, p.alpha);
+  return p.r0 * s.s1 + p.sig0 * s.s2 + s.s3 - sqrt(kMu) * p.dt;
+}
+
+// solve_kepuni_brent_dekker (kepler/brent_dekker_solver.rs:150-177,214-233,469-526): bracket around the start
+// value (guess or prelim_kepuni), golden-ratio expansion of the end with the smaller |f| (<= 60 times), then
+// Brent's iteration (inverse quadratic interpolation / secant, accepted only strictly between (3a+b)/4 and b and
+// when it at least halves the reference step; else bisection), <= 100 iterations.
+__device__ __forceinline__ KeplerSolution solve_kepuni_brent_dekker(const KeplerProblem& p, bool has_guess, double guess) {
+  constexpr double kPhi = 1.618033988749895;
+  KeplerSolution out;
+  out.ok = false; out.psi = 0.0; out.s = {1.0, 0.0, 0.0, 0.0};
+  const double psi0 = has_guess ? guess : prelim_kepuni(p);
+  const double hw = fabs(psi0) > 1.0 ? fabs(psi0) : 1.0;
+  double lo = psi0 - hw, hi = psi0 + hw;
+  double flo = kepler_residual(lo, p), fhi = kepler_residual(hi, p);
+  bool ok = false;
+#pragma unroll 1
+  for (int i = 0; i < 60; ++i) {
+    if (flo * fhi <= 0.0) { ok = true; break; }
+    const double w = hi - lo;
+    if (fabs(flo) < fabs(fhi)) { lo = lo - kPhi * w; flo = kepler_residual(lo, p); }
+    else { hi = hi + kPhi * w; fhi = kepler_residual(hi, p); }
+  }
+  if (!ok) return out;
+  double a = lo, fa = kepler_residual(lo, p), b = hi, fb = kepler_residual(hi, p);
+  if (fabs(fa) < fabs(fb)) { double t = a; a = b; b = t; t = fa; fa = fb; fb = t; }
+  double c = a, fc = fa, prev_len = fabs(hi - lo);
+  bool prev_bis = true;
+#pragma unroll 1
+  for (int it = 0; it < 100; ++it) {
+    if (fabs(fb) <= p.convergency || 0.5 * fabs(b - a) <= p.convergency) {
+      out.psi = b; out.s = s_funct(b, p.alpha); out.ok = true;
+      return out;
+    }
+    double interp;
+    if (fabs(fa - fc) > kEps && fabs(fb - fc) > kEps) {
+      const double ta = a * fb * fc / ((fa - fb) * (fa - fc));
+      const double tb = b * fa * fc / ((fb - fa) * (fb - fc));
+      const double tc = c * fa * fb / ((fc - fa) * (fc - fb));
+      interp = ta + tb + tc;
+    } else {
+      interp = b - fb * (b - a) / (fb - fa);
+    }
+    const double ref_len = prev_bis ? fabs(b - c) : prev_len;
+    const double q3 = (3.0 * a + b) / 4.0;
+    const bool inside = (q3 < b) ? (interp > q3 && interp < b) : (interp > b && interp < q3);
+    const bool progress = fabs(interp - b) < 0.5 * ref_len;
+    const bool take = inside && progress;
+    const double next = take ? interp : 0.5 * (a + b);
+    const double fnext = kepler_residual(next, p);
+    prev_len = fabs(b - c);
+    prev_bis = !take;
+    c = b; fc = fb;
+    if (fa * fnext < 0.0) { b = next; fb = fnext; }
+    else { a = next; fa = fnext; }
+    if (fabs(fa) < fabs(fb)) { double t = a; a = b; b = t; t = fa; fa = fb; fb = t; }
+  }
+  return out;
+}
+
+// UniversalKeplerParams::solve (kepler/params.rs:130-142); kind = OUTFIT_SOLVER_*
+__device__ __forceinline__ KeplerSolution solve_kepuni_kind(const KeplerProblem& p, int kind, bool has_guess, double guess) {
+  if (kind == 1) return solve_kepuni_brent_dekker(p, has_guess, guess);
+  const KeplerSolution n = solve_kepuni(p, has_guess, guess);
+  if (kind == 0 || n.ok) return n;
+  return solve_kepuni_brent_dekker(p, has_guess, guess);
 }
 
 struct EccControl {
@@ -411,8 +506,13 @@ __device__ __forceinline__ VelCorr velocity_correction(const Vec3& x1, const Vec
 
 // kepler/propagation.rs:114-207 ; out = r1[3] v1[3] f g fdot gdot psi ; returns the status code
 // documented at outfit_hip_propagate_universal (include/outfit_hip.h).
+struct SolverSpec {  // SolverType (kepler/params.rs:55-73), flattened
+  int kind = 0, parabolic_newton = 0, max_iter_prelim = 20;
+  bool has_guess = false;
+  double convergency = 100.0 * 2.220446049250313e-16, guess = 0.0;
+};
 __device__ __forceinline__ int propagate_universal(const Vec3& r, const Vec3& v, double t0, double t1,
-                                          double convergency, double* out, int math_mode = kMathCr) {
+                                          const SolverSpec& sv, double* out, int math_mode = kMathCr) {
   const double r0 = norm(r);
   if (r0 < kEps) return 1;
   const double v2 = dot(v, v);
@@ -423,9 +523,10 @@ __device__ __forceinline__ int propagate_universal(const Vec3& r, const Vec3& v,
   const Vec3 h = cross(r, v);
   double e = sqrt(1.0 + p.alpha * dot(h, h) / kMu);
   if (!(e >= 0.0)) e = 0.0;  // f64::max(NaN, 0.0) == 0.0
-  p.e0 = e; p.r0 = r0; p.dt = t1 - t0; p.convergency = convergency; p.math_mode = math_mode;
-  const KeplerSolution s = solve_kepuni(p, false, 0.0);
-  if (!s.ok) return 2;
+  p.e0 = e; p.r0 = r0; p.dt = t1 - t0; p.convergency = sv.convergency; p.math_mode = math_mode;
+  p.max_iter_prelim = sv.max_iter_prelim; p.parabolic_newton = sv.parabolic_newton;
+  const KeplerSolution s = solve_kepuni_kind(p, sv.kind, sv.has_guess, sv.guess);
+  if (!s.ok) return sv.kind == 0 ? 2 : 4;
   const double r1 = r0 * s.s.s0 + p.sig0 * s.s.s1 + s.s.s2;
   if (r1 < kEps) return 3;
   const double f = 1.0 - s.s.s2 / r0;

@@ -190,7 +190,7 @@ hipError_t launch_selftest_crmath(unsigned long long n_threads, unsigned long lo
 hipError_t launch_selftest_division(unsigned long long n_threads, unsigned long long n_per_thread,
                                     unsigned long long seed, unsigned long long* d_mismatches, hipStream_t s);
 hipError_t launch_propagate_universal(unsigned long long n, const double* rv, const double* t0,
-                                      const double* t1, double convergency, int math_mode, double* out, int* status,
+                                      const double* t1, const SolverSpec& sv, int math_mode, double* out, int* status,
                                       hipStream_t s);
 
 }  // namespace outfit

@@ -724,14 +724,14 @@ k_select_best(SelectArgs a) {
 // ------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_propagate_universal(unsigned long long n, const double* rv, const double* t0, const double* t1,
-                      double convergency, int math_mode, double* out, int* status) {
+                      SolverSpec sv, int math_mode, double* out, int* status) {
   const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double o[11];
   for (int k = 0; k < 11; ++k) o[k] = nan("");
   const Vec3 r = {rv[6 * i], rv[6 * i + 1], rv[6 * i + 2]};
   const Vec3 v = {rv[6 * i + 3], rv[6 * i + 4], rv[6 * i + 5]};
-  status[i] = propagate_universal(r, v, t0[i], t1[i], convergency, o, math_mode);
+  status[i] = propagate_universal(r, v, t0[i], t1[i], sv, o, math_mode);
   for (int k = 0; k < 11; ++k) out[11 * i + k] = o[k];
 }
 
@@ -1099,11 +1099,11 @@ hipError_t launch_select_best(const SelectArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 hipError_t launch_propagate_universal(unsigned long long n, const double* rv, const double* t0,
-                                      const double* t1, double convergency, int math_mode, double* out, int* status,
+                                      const double* t1, const SolverSpec& sv, int math_mode, double* out, int* status,
                                       hipStream_t s) {
   if (n == 0) return hipSuccess;
   const unsigned grid = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(k_propagate_universal, dim3(grid), dim3(256), 0, s, n, rv, t0, t1, convergency, math_mode,
+  hipLaunchKernelGGL(k_propagate_universal, dim3(grid), dim3(256), 0, s, n, rv, t0, t1, sv, math_mode,
                      out, status);
   return hipGetLastError();
 }

@@ -30,7 +30,7 @@ class KeplerParams(C.Structure):
         ("dt", C.c_double), ("r0", C.c_double), ("sig0", C.c_double), ("mu", C.c_double),
         ("alpha", C.c_double), ("e0", C.c_double), ("convergency", C.c_double),
         ("has_guess", C.c_int), ("psi_guess", C.c_double),
-        ("max_iter_prelim_kepuni", C.c_int), ("kind", C.c_int),
+        ("max_iter_prelim_kepuni", C.c_int), ("kind", C.c_int), ("parabolic_method", C.c_int),
     ]
 
 
@@ -115,6 +115,8 @@ def lib():
             D3, D3, D3, C.c_double, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double,
             D3, _dp, _dp, _dp]
         L.orc_propagate_universal.argtypes = [D3, D3, C.c_double, C.c_double, C.c_double, C.c_int, D11]
+        from outfit_amd._abi import SolverTypeC
+        L.orc_propagate_universal_ex.argtypes = [D3, D3, C.c_double, C.c_double, C.POINTER(SolverTypeC), D11]
         L.orc_eccentricity_control.argtypes = [D3, D3, C.c_double, C.c_double,
                                                C.POINTER(C.c_int), _dp, _dp, _dp]
         L.orc_ccek1.argtypes = [D3, D3, C.c_double, C.POINTER(Elements)]

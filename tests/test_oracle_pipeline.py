@@ -236,3 +236,31 @@ def test_order_of_equal_weights_decides_nothing_the_reference_returns(ds64):
             continue
         assert a[f].tobytes() == b[f].tobytes(), f
     assert (a["best_triplet"] != b["best_triplet"]).any()   # the index does move
+
+
+def test_select_rms_interval_on_the_reference_data_file():
+    """src/trajectory.rs:566-625 (`test_select_rms_interval`): on the 37 observations of tests/data/2015AB.obs the best
+    triplet (generator + weights + bounded heap, max_triplets = 10: the exactly restated insertion-sort regime)
+    and `select_rms_interval` give the windows (0,36), (14,36), (17,33) for three (extf, dtmax) settings."""
+    import json
+    import os
+    k = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_2015AB.json")))
+    mjd = np.ascontiguousarray([o["mjd_tt"] for o in k["observations"]])
+    assert len(mjd) == 37 and (np.diff(mjd) > 0).all()
+    L = O.lib()
+    L.orc_generate_triplet_indices.restype = C.c_size_t
+    L.orc_generate_triplet_indices.argtypes = [C.POINTER(C.c_double), C.c_size_t, C.c_void_p, C.POINTER(C.c_uint32),
+                                               C.POINTER(C.c_double)]
+    L.orc_select_rms_interval.argtypes = [C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_uint32), C.c_void_p,
+                                          C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    p = O.default_params()
+    for f, v in k["select_rms_interval"]["params"].items():
+        setattr(p, f, v)
+    idx, w = (C.c_uint32 * 30)(), (C.c_double * 10)()
+    n = L.orc_generate_triplet_indices(mjd.ctypes.data_as(C.POINTER(C.c_double)), 37, C.byref(p), idx, w)
+    assert n == 10 and list(w) == sorted(w)
+    for case in k["select_rms_interval"]["cases"]:
+        p.extf, p.dtmax = case["extf"], case["dtmax"]
+        s, e = C.c_size_t(), C.c_size_t()
+        L.orc_select_rms_interval(mjd.ctypes.data_as(C.POINTER(C.c_double)), 37, idx, C.byref(p), C.byref(s), C.byref(e))
+        assert [s.value, e.value] == case["window"], (case, list(idx[:3]))

@@ -123,7 +123,11 @@ pmc = {"source": f"profiles/{name}_rocprof_summary.md (rocprofv3 --pmc FETCH_SIZ
 for k in kernels:
     r = per_step[k]
     fb, wb = r["FETCH_SIZE"] * 1024 * (fetch_factor or 1.0), r["WRITE_SIZE"] * 1024 * (write_factor or 1.0)
+    st64 = max(1.0, c64.get(k, 0) / LAUNCHES_PER_STEP.get(k, 1))
+    g = lambda c: f64.get((k, c), 0.0) / st64  # noqa: E731
     pmc["kernels"][k] = {"hbm_bytes_per_step": fb + wb, "fetch_bytes": fb, "write_bytes": wb,
+                         "fp64_lane_ops_upper": 64.0 * (g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64")
+                                                        + 2.0 * g("SQ_INSTS_VALU_FMA_F64") + g("SQ_INSTS_VALU_TRANS_F64")),
                          "valu_wave_instr": r["SQ_INSTS_VALU"]}
 json.dump(pmc, open(os.path.join(ROOT, "profiles", "latest_pmc.json"), "w"), indent=1)
 print(open(out).read())
