@@ -867,7 +867,20 @@ int run_sharded(const outfit_iod_params_t* params, const outfit_obs_batch_t* bat
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
     return fail(OUTFIT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
-  if (n_devices <= 0 || n_devices > n_dev) n_devices = n_dev;
+  // Testing aid: OUTFIT_SHARD_DEVICES="0,0" runs that many shards, shard k on the listed device — the per-device
+  // host-thread path (one thread, one session, one slice of `out` per shard) on a single-GPU box.
+  std::vector<int> dev_map;
+  if (const char* e = std::getenv("OUTFIT_SHARD_DEVICES")) {
+    for (const char* p = e; *p;) {
+      char* end = nullptr;
+      const long v = std::strtol(p, &end, 10);
+      if (end == p) break;
+      if (v >= 0 && v < n_dev) dev_map.push_back((int)v);
+      p = (*end == ',') ? end + 1 : end;
+    }
+  }
+  if (!dev_map.empty()) n_devices = (int)dev_map.size();
+  else if (n_devices <= 0 || n_devices > n_dev) n_devices = n_dev;
   if (batch->n_traj == 0) return OUTFIT_OK;
   n_devices = (int)std::min<uint64_t>((uint64_t)n_devices, batch->n_traj);
   const uint64_t o0 = batch->traj_offset[0], total = batch->traj_offset[batch->n_traj] - o0;
@@ -890,7 +903,7 @@ int run_sharded(const outfit_iod_params_t* params, const outfit_obs_batch_t* bat
       sub.noise_z = batch->noise_z + (size_t)t0 * params->max_triplets * (size_t)params->n_noise_realizations * 6;
     if (batch->traj_key) sub.traj_key = batch->traj_key + t0;
     else sub.traj_key_base = batch->traj_key_base + t0;
-    rc[d] = work(d, sub, t0);
+    rc[d] = work(dev_map.empty() ? d : dev_map[d], sub, t0);
     if (rc[d] != OUTFIT_OK) msg[d] = g_last_error;  // thread-local: keep the shard's message
   };
   if (n_devices == 1) {

@@ -54,13 +54,72 @@ def records_from_tensor(t):
     return np.frombuffer(t.cpu().numpy().tobytes(), dtype=RESULT_DTYPE)
 
 
-def fit_full_iod_distributed(batch, ephem, params, dist, device_index, compute=None):
+class ShardedIOD:
+    """This rank's shard of a batch, RESIDENT on its GPU, plus the gather of everybody's records.
+
+    Build once, `run()` as often as needed (each call = the rank's kernels + one all_gather of the 96-byte records):
+    the session, its result buffer and the gather buffers live as long as the object. Ordering is by stream, not by a
+    device-wide synchronize: the kernels go to an explicit torch stream, the collective is issued under that stream
+    (RCCL orders a collective after torch's CURRENT stream), the host waits once for the gathered table.
+    With a gloo group (rehearsal on one GPU / CPU tensors) the records are copied to the host on that stream first."""
+
+    def __init__(self, batch, ephem, params, dist, device_index):
+        import torch
+        from .api import IODSession
+        self.dist, self.torch = dist, torch
+        rank, world = dist.get_rank(), dist.get_world_size()
+        cuts = partition_by_observations(batch.traj_offset, world)
+        self.counts = [cuts[r + 1] - cuts[r] for r in range(world)]
+        self.rank, self.t0, self.t1 = rank, cuts[rank], cuts[rank + 1]
+        sub = batch.slice(self.t0, self.t1)
+        if batch.noise_z is not None:
+            stride = params.max_triplets * params.n_noise_realizations * 6
+            sub.noise_z = batch.noise_z[self.t0 * stride: self.t1 * stride]
+        self.dev = torch.device("cuda", device_index)
+        torch.cuda.current_stream(self.dev)                      # torch's HIP runtime first (see _lib.lib)
+        self.stream = torch.cuda.Stream(self.dev)                # explicit: handle 0 would mean "the session's own"
+        self.local = torch.empty((self.counts[rank], RECORD_BYTES), dtype=torch.uint8, device=self.dev)
+        self.session = IODSession(sub, ephem, params, device=device_index) if self.counts[rank] else None
+        self.nccl = dist.get_backend() == "nccl"
+
+    def run(self):
+        """-> structured records of ALL trajectories, in trajectory order."""
+        torch = self.torch
+        with torch.cuda.stream(self.stream):
+            if self.session is not None:
+                self.session.run(stream=self.stream.cuda_stream, d_out=self.local.data_ptr())
+            if self.nccl:
+                out = all_gather_records(self.local, self.counts, self.dist)
+            else:
+                host = self.local.to("cpu", non_blocking=False)  # waits for the kernels on this stream
+                out = all_gather_records(host, self.counts, self.dist)
+        if self.session is not None:
+            self.session.check()   # an epoch outside the ephemeris table raises here, as on one GPU
+        self.stream.synchronize()
+        return records_from_tensor(out)
+
+    def close(self):
+        if self.session is not None:
+            self.session.close()
+            self.session = None
+
+
+def fit_full_iod_distributed(batch, ephem, params, dist, device_index, compute=None, sharded=None):
     """Strong-scaling entry: every rank passes the SAME batch, computes its own range on its GPU
-    and returns the records of ALL trajectories (gathered).
+    and returns the records of ALL trajectories (gathered). Pass `sharded` (a ShardedIOD built from the same
+    arguments) to reuse the resident shard across calls; otherwise one is built and closed here.
 
     `compute(sub_batch) -> structured records` may be injected (the CPU tests pass the oracle
     there to exercise the sharding and the gather under gloo); by default it is the HIP session."""
     import torch
+    if compute is None:
+        own = sharded is None
+        sh = sharded or ShardedIOD(batch, ephem, params, dist, device_index)
+        try:
+            return sh.run()
+        finally:
+            if own:
+                sh.close()
     rank, world = dist.get_rank(), dist.get_world_size()
     cuts = partition_by_observations(batch.traj_offset, world)
     counts = [cuts[r + 1] - cuts[r] for r in range(world)]
@@ -69,20 +128,8 @@ def fit_full_iod_distributed(batch, ephem, params, dist, device_index, compute=N
     if batch.noise_z is not None:
         stride = params.max_triplets * params.n_noise_realizations * 6
         sub.noise_z = batch.noise_z[t0 * stride: t1 * stride]
-    if compute is None:
-        from .api import IODSession
-        dev = torch.device("cuda", device_index)
-        local = torch.empty((counts[rank], RECORD_BYTES), dtype=torch.uint8, device=dev)
-        if counts[rank]:
-            s = IODSession(sub, ephem, params, device=device_index)
-            # torch's default stream reports handle 0 = "the session's own stream" for the C ABI: the device-wide
-            # synchronize below (not stream order) is what puts the gather after the kernels
-            s.run(stream=torch.cuda.current_stream(dev).cuda_stream, d_out=local.data_ptr())
-            torch.cuda.synchronize(dev)
-            s.close()
-    else:
-        recs = compute(sub) if counts[rank] else np.zeros(0, dtype=RESULT_DTYPE)
-        local = torch.from_numpy(np.frombuffer(recs.tobytes(), dtype=np.uint8).reshape(-1, RECORD_BYTES).copy())
+    recs = compute(sub) if counts[rank] else np.zeros(0, dtype=RESULT_DTYPE)
+    local = torch.from_numpy(np.frombuffer(recs.tobytes(), dtype=np.uint8).reshape(-1, RECORD_BYTES).copy())
     return records_from_tensor(all_gather_records(local, counts, dist))
 
 
@@ -119,7 +166,7 @@ def fit_lsq_distributed(batch, ephem, iod_params, diff_cor_config, dist, device_
     else:
         recs = compute(sub, sub_init)
     local = torch.from_numpy(np.frombuffer(recs.tobytes(), dtype=np.uint8).reshape(-1, LSQ_RECORD_BYTES).copy())
-    if compute is None:
+    if compute is None and dist.get_backend() == "nccl":
         local = local.to(torch.device("cuda", device_index))
     out = all_gather_records(local, counts, dist)
     return np.frombuffer(out.cpu().numpy().tobytes(), dtype=LSQ_DTYPE)
