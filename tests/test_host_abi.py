@@ -161,3 +161,24 @@ def test_record_to_result_mirrors_reference_variants():
     assert isinstance(outfit_amd.api.record_to_result(rec), outfit_amd.NoFeasibleTriplets)
     rec["status"] = 3
     assert isinstance(outfit_amd.api.record_to_result(rec), outfit_amd.InvalidConversion)
+
+
+def test_no_kernel_needs_a_dynamically_sized_stack():
+    """The private segment of every kernel must be sized at compile time: hipcc's resource report (kept by the
+    Makefile next to the objects) has to say `Dynamic Stack: False` for each of them. A kernel that calls through a
+    function pointer or recurses gets `Dynamic Stack: True`, and the HIP runtime then sizes its scratch from
+    hipLimitStackSize (1 KiB per lane by default) whatever the callee needs — an overrun is a
+    HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION ("scratch")."""
+    import glob
+    import re
+    build = os.path.join(ROOT, "outfit_amd", "csrc", "_build")
+    reports = glob.glob(os.path.join(build, "*.resource.txt"))
+    if not reports:
+        pytest.skip("library not built by the Makefile of this tree")
+    text = "".join(open(r).read() for r in reports)
+    names = re.findall(r"Function Name: (\S+)", text)
+    dyn = re.findall(r"Dynamic Stack: (\w+)", text)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", text)]
+    assert len(names) >= 20 and len(names) == len(dyn) == len(scratch)
+    assert all(d == "False" for d in dyn), [n for n, d in zip(names, dyn) if d != "False"]
+    assert max(scratch) <= 1024, dict(zip(names, scratch))   # today: 448 B (k_gauss_correct), spills only
