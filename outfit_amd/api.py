@@ -503,6 +503,19 @@ class EquinoctialElements:
         """EquinoctialUncertainty::from_covariance (orbit_type/uncertainty.rs:261-271)."""
         return tuple(float(np.sqrt(self.covariance[i, i])) for i in range(6))
 
+    def to_keplerian(self):
+        """`KeplerianElements::from(EquinoctialElements)` (orbit_type/keplerian_element.rs:185-233; known answer
+        equinoctial_element.rs:1240-1264): (a, e, i, Omega, omega, M), angles by `principal_angle`."""
+        import math
+        a, h, k, p, q, lam = (float(x) for x in self.elements)
+        two_pi = 6.283185307179586
+        pa = lambda x: (lambda r: r + two_pi if r < 0.0 else r)(math.fmod(x, two_pi))  # noqa: E731  f64::rem_euclid
+        ecc = math.sqrt(h * h + k * k)
+        dig = 0.0 if ecc < 1.0e-12 else math.atan2(h, k)
+        tgi2 = math.sqrt(p * p + q * q)
+        node = 0.0 if tgi2 < 1.0e-12 else math.atan2(p, q)
+        return (a, ecc, 2.0 * math.atan(tgi2), node, pa(dig - node), pa(lam - dig))
+
 
 @dataclass
 class DifferentialCorrection:

@@ -182,3 +182,18 @@ def test_no_kernel_needs_a_dynamically_sized_stack():
     assert len(names) >= 20 and len(names) == len(dyn) == len(scratch)
     assert all(d == "False" for d in dyn), [n for n, d in zip(names, dyn) if d != "False"]
     assert max(scratch) <= 1024, dict(zip(names, scratch))   # today: 448 B (k_gauss_correct), spills only
+
+
+def test_equinoctial_to_keplerian_known_answer():
+    """orbit_type/equinoctial_element.rs:1240-1264 (`test_equinoctial_conversion`, assert_eq!): the host-side conversion
+    of a `fit_lsq` result to Keplerian elements reproduces the reference's values bit for bit (on a glibc host; the
+    functions involved — sqrt, atan2, atan — are evaluated by the platform libm on both sides)."""
+    import numpy as np
+    equ = outfit_amd.EquinoctialElements(0.0, (1.8017360713, 0.2693736809404963, 0.08856415260522467,
+                                               0.0008089970142830734, 0.10168201110394352, 1.693697008), np.eye(6))
+    want = (1.8017360713, 0.2835591457, 0.20267383289999996, 0.007955979, 1.2451951388, 0.4405458902000001)
+    got = equ.to_keplerian()
+    assert all(abs(g - w) <= 1e-15 * max(1.0, abs(w)) for g, w in zip(got, want)), got
+    import platform
+    if platform.libc_ver()[0] == "glibc":
+        assert got == want

@@ -264,3 +264,55 @@ def test_select_rms_interval_on_the_reference_data_file():
         s, e = C.c_size_t(), C.c_size_t()
         L.orc_select_rms_interval(mjd.ctypes.data_as(C.POINTER(C.c_double)), 37, idx, C.byref(p), C.byref(s), C.byref(e))
         assert [s.value, e.value] == case["window"], (case, list(idx[:3]))
+
+
+def test_reference_index_generator_cases_and_properties():
+    """index_generator.rs:333-656: the down-sampling known answers (:333-405) and the property tests — generator ==
+    brute force (with the reference's own 1e-12 slack, :313-327), no duplicates, i < j < k, spans inside [dt_min, dt_max]
+    (:553-607), down-sampling keeps both ends, respects the cap and is strictly increasing (:628-655) — on the
+    reference's input distributions, 400 random cases each."""
+    L = O.lib()
+    L.orc_downsample_uniform_with_edges.restype = C.c_size_t
+    L.orc_downsample_uniform_with_edges.argtypes = [C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t)]
+
+    def down(n, max_keep):
+        buf = (C.c_size_t * (max(n, max_keep) + 3))()
+        k = L.orc_downsample_uniform_with_edges(n, max_keep, buf)
+        return list(buf[:k])
+    assert down(0, 10) == [] and down(5, 10) == [0, 1, 2, 3, 4] and down(5, 5) == [0, 1, 2, 3, 4]
+    assert down(9, 3) == [0, 4, 8]
+    r = down(3, 2)
+    assert r[0] == 0 and r[-1] == 2
+    for n in range(4, 31):
+        for mk in range(3, n + 1):
+            r = down(n, mk)
+            assert r[0] == 0 and r[-1] == n - 1 and len(r) <= mk and all(a < b for a, b in zip(r, r[1:])), (n, mk, r)
+    for n in range(1, 51):
+        for mk in range(3, 51):
+            r = down(n, mk)
+            assert len(r) <= max(min(mk, n), 3) and r[0] == 0 and r[-1] == n - 1
+    r = down(100, 10)
+    assert all(a < b for a, b in zip(r, r[1:]))
+
+    L.orc_generate_triplet_indices.restype = C.c_size_t
+    L.orc_generate_triplet_indices.argtypes = [C.POINTER(C.c_double), C.c_size_t, C.c_void_p, C.POINTER(C.c_uint32),
+                                               C.POINTER(C.c_double)]
+    rng = np.random.default_rng(20260102)
+    ip = O.default_params()
+    ip.max_triplets, ip.max_obs_for_triplets = 1000, 1000
+    idx = (C.c_uint32 * 3000)()
+    for _ in range(400):
+        n = int(rng.integers(3, 13))
+        t = np.concatenate([[0.0], np.cumsum(rng.uniform(0.1, 5.0, n - 1))])
+        ip.dt_min = float(rng.uniform(0.0, 10.0))
+        ip.dt_max_triplet = ip.dt_min + float(rng.uniform(0.0, 20.0))
+        k = L.orc_generate_triplet_indices(t.ctypes.data_as(C.POINTER(C.c_double)), n, C.byref(ip), idx, None)
+        got = [(idx[3 * s], idx[3 * s + 1], idx[3 * s + 2]) for s in range(k)]
+        assert len(set(got)) == len(got)                                       # prop_no_duplicates
+        for i, j, m in got:                                                    # prop_all_invariants_hold
+            assert i < j < m and ip.dt_min <= t[m] - t[i] <= ip.dt_max_triplet
+        lo = {(i, j, m) for i, j, m in itertools.combinations(range(n), 3)
+              if ip.dt_min + 1e-12 <= t[m] - t[i] <= ip.dt_max_triplet - 1e-12}
+        hi = {(i, j, m) for i, j, m in itertools.combinations(range(n), 3)
+              if ip.dt_min - 1e-12 <= t[m] - t[i] <= ip.dt_max_triplet + 1e-12}
+        assert lo <= set(got) <= hi                                            # prop_matches_brute_force
