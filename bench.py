@@ -291,7 +291,7 @@ def main():
         # dominant kernel and its roofline (algorithmic bytes, SURVEY §8d / DESIGN.md)
         # ... among the kernels of the critical path: K0, K1 and the general correction kernel run on side
         # streams in the shadow of these and their event times include waiting for a free CU
-        main_stream = [k for k in ktimes if k in ("k_gauss_roots", "k_gauss_prelim", "k_gauss_correct_fast",
+        main_stream = [k for k in ktimes if k in ("k_gauss_roots", "k_gauss_correct_fast",
                                                     "k_orbit_rms", "k_orbit_rms_slow", "k_select_best")]
         dom = max(main_stream, key=lambda k: ktimes[k][0]) if main_stream else None
         bytes_per_obj = (n_obs / n_obj) * (BYTES_PER_OBS_IN + BYTES_PER_OBS_GEO) + BYTES_PER_RESULT

@@ -197,9 +197,9 @@ struct DevBuf {
   }
 };
 
-enum KernelId { K_TRIPLETS = 0, K_PREPASS, K_ROOTS, K_PRELIM, K_CORRECT_FAST, K_CORRECT, K_RMS, K_RMS_SLOW, K_SELECT, K_DIFFCOR, K_COUNT };
+enum KernelId { K_TRIPLETS = 0, K_PREPASS, K_ROOTS, K_CORRECT_FAST, K_CORRECT, K_RMS, K_RMS_SLOW, K_SELECT, K_DIFFCOR, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"k_triplet_select", "k_observer_prepass",   "k_gauss_roots",
-                                           "k_gauss_prelim",   "k_gauss_correct_fast", "k_gauss_correct",
+                                           "k_gauss_correct_fast", "k_gauss_correct",
                                            "k_orbit_rms",      "k_orbit_rms_slow",     "k_select_best",
                                            "k_diffcor"};
 
@@ -709,6 +709,7 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
       HIP_TRY(hipEventRecord(s->ev_unit, k0));
       HIP_TRY(hipStreamWaitEvent(st, s->ev_unit, 0));
     }
+    HIP_TRY(outfit::reset_slow_list(w, st));
     for (unsigned i = 0; i < n_sub; ++i) {
       const uint64_t a0 = nt * i / n_sub, a1 = nt * (i + 1) / n_sub;
       HIP_TRY(hipStreamWaitEvent(st, s->ev_sub[i], 0));
@@ -719,10 +720,6 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
     HIP_TRY(hipEventRecord(s->ev_unit_free[ub], st));  // last K2a of this run so far: unit[ub] may be rewritten after it
     s->unit_free_recorded[ub] = true;
     const outfit::CorrectArgs ca{ci, w, s->gp, s->queue.p};
-    {
-      Stamp stamp(s, st, K_PRELIM);
-      HIP_TRY(outfit::launch_gauss_prelim(ca, st));
-    }
     {
       Stamp stamp(s, st, K_CORRECT_FAST);
       HIP_TRY(outfit::launch_gauss_correct_fast(ca, s->n_cu, st));

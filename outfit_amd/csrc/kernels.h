@@ -169,7 +169,7 @@ struct DiffCorArgs {
 hipError_t launch_triplet_select(const TripletArgs& a, bool lds_heap, hipStream_t s);
 hipError_t launch_observer_prepass(const PrepassArgs& a, hipStream_t s);
 hipError_t launch_gauss_roots(const RootsArgs& a, hipStream_t s);
-hipError_t launch_gauss_prelim(const CorrectArgs& a, hipStream_t s);
+hipError_t reset_slow_list(const CandidateScratch& w, hipStream_t s);
 hipError_t launch_gauss_correct_fast(const CorrectArgs& a, unsigned n_cu, hipStream_t s);
 hipError_t launch_gauss_correct(const CorrectArgs& a, unsigned n_cu, hipStream_t s);
 hipError_t launch_orbit_rms(const RmsArgs& a, bool slow_list, hipStream_t s);

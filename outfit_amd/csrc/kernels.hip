@@ -22,6 +22,7 @@
 //
 // Compiled with -ffp-contract=off: the reference (Rust) never fuses a*b+c.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "kernels.h"
 #include "device/ephem.hpp"
 #include "device/earthrot.hpp"
@@ -195,9 +196,54 @@ __device__ __forceinline__ void gather_times_observer(const CandidateIndex& I, c
 }
 
 // ------------------------------------------------------------------------------
+// K2a': first accepted root and the cold-start values of its two universal-Kepler
+// solves, one lane per candidate (dense: every lane runs the expensive correctly-rounded
+// cold start at the same time instead of inside the persistent kernel's divergent trips).
+// The first iteration of pos_and_vel_correction calls solve_kepuni_with_guess with
+// psi_guess = None, i.e. run_newton(prelim_kepuni(params)) (newton_solver.rs:151-161);
+// the value prelim_kepuni(params) is what is stored here.
+// ------------------------------------------------------------------------------
+__device__ __forceinline__ void append_slow(const CandidateScratch& W, unsigned long long cid) {
+  const unsigned long long at = atomicAdd(W.slow_count, 1ull);
+  W.slow_list[at] = cid;
+}
+
+struct CandidateGeometry {
+  Mat3 S, Sinv, obs;
+  double t[3];
+  GaussGeometry q;
+};
+__device__ __forceinline__ CandidateGeometry load_geometry(const CandidateIndex& I, const CandidateScratch& W,
+                                                           unsigned long long cid) {
+  CandidateGeometry g;
+  const CandidateRef c = decode_candidate(I, cid);
+  gather_times_observer(I, c, g.t, g.obs);
+  if (c.r == 0) {
+    // noise-free realisation: the direction matrix is three columns of K1's per-observation table (48 MB for 2x10^6
+    // observations: served by L2 / Infinity Cache) — it is not stored per candidate (72 B x 10^7 per step)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const unsigned long long o = c.base + c.idx[k];
+      g.S.m[0][k] = I.unit[o];
+      g.S.m[1][k] = I.unit[I.n_obs_total + o];
+      g.S.m[2][k] = I.unit[2 * I.n_obs_total + o];
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) g.S.m[r][k] = W.S[(unsigned long long)(3 * r + k) * I.n_cand + cid];
+  }
+  (void)try_inverse(g.S, g.Sinv);  // non-singular: K2a checked it
+  g.q = gauss_times(g.t);
+  return g;
+}
+
+// ------------------------------------------------------------------------------
 // K2a: direction matrix, 8th-degree polynomial, Aberth roots, root filter
 // ------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+template <unsigned kOcc>
+__global__ void __launch_bounds__(256, kOcc)
 k_gauss_roots(RootsArgs a) {
   const unsigned long long lid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (lid >= a.cand_count) return;
@@ -221,10 +267,12 @@ k_gauss_roots(RootsArgs a) {
     gather_angles(a.I, c, ra, dec);
     S = unit_matrix(ra, dec, a.P.math_mode);
   }
+  if (c.r != 0) {  // noisy realisation: its direction matrix costs six correctly-rounded sincos — kept for K2b
 #pragma unroll
-  for (int r = 0; r < 3; ++r)
+    for (int r = 0; r < 3; ++r)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) a.W.S[(unsigned long long)(3 * r + k) * n + cid] = S.m[r][k];
+      for (int k = 0; k < 3; ++k) a.W.S[(unsigned long long)(3 * r + k) * n + cid] = S.m[r][k];
+  }
   if (!try_inverse(S, Sinv)) { a.W.flags[cid] = (unsigned)kCauseSingular; return; }
   gather_times_observer(a.I, c, t, obs);
   const GaussGeometry q = gauss_times(t);
@@ -249,63 +297,26 @@ k_gauss_roots(RootsArgs a) {
       ++nf;
     }
   }
-  a.W.flags[cid] = nf ? (kFlagOk | (nf << kFlagRootsShift)) : (unsigned)kCauseNoRoots;
-}
-
-// ------------------------------------------------------------------------------
-// K2a': first accepted root and the cold-start values of its two universal-Kepler
-// solves, one lane per candidate (dense: every lane runs the expensive correctly-rounded
-// cold start at the same time instead of inside the persistent kernel's divergent trips).
-// The first iteration of pos_and_vel_correction calls solve_kepuni_with_guess with
-// psi_guess = None, i.e. run_newton(prelim_kepuni(params)) (newton_solver.rs:151-161);
-// the value prelim_kepuni(params) is what is stored here.
-// ------------------------------------------------------------------------------
-__device__ __forceinline__ void append_slow(const CandidateScratch& W, unsigned long long cid) {
-  const unsigned long long at = atomicAdd(W.slow_count, 1ull);
-  W.slow_list[at] = cid;
-}
-
-struct CandidateGeometry {
-  Mat3 S, Sinv, obs;
-  double t[3];
-  GaussGeometry q;
-};
-__device__ __forceinline__ CandidateGeometry load_geometry(const CandidateIndex& I, const CandidateScratch& W,
-                                                           unsigned long long cid) {
-  CandidateGeometry g;
-  const CandidateRef c = decode_candidate(I, cid);
-  gather_times_observer(I, c, g.t, g.obs);
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int k = 0; k < 3; ++k) g.S.m[r][k] = W.S[(unsigned long long)(3 * r + k) * I.n_cand + cid];
-  (void)try_inverse(g.S, g.Sinv);  // non-singular: K2a checked it
-  g.q = gauss_times(g.t);
-  return g;
-}
-
-__global__ void __launch_bounds__(256)
-k_gauss_prelim(CorrectArgs a) {
-  const unsigned long long cid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const unsigned long long n = a.I.n_cand;
-  if (cid >= n) return;
-  const unsigned f = a.W.flags[cid];
-  if ((f & kFlagEmpty) || !(f & kFlagOk)) return;
-  const unsigned nf = (f >> kFlagRootsShift) & 0xFu;
-  const CandidateGeometry g = load_geometry(a.I, a.W, cid);
+  if (nf == 0) { a.W.flags[cid] = (unsigned)kCauseNoRoots; return; }
+  // ---- K2a' fused: first accepted root and the cold-start values of its two universal-Kepler solves. The first
+  // iteration of pos_and_vel_correction calls solve_kepuni_with_guess with psi_guess = None, i.e.
+  // run_newton(prelim_kepuni(params)) (newton_solver.rs:151-161); prelim_kepuni(params) is what is stored.
+  // Everything it needs (S, S^-1, observer matrix, times) is still in registers; the filtered roots are read back
+  // from this lane's own stores (dynamic indexing of the iterates would push them to scratch).
   Mat3 pos;
   Vec3 vel;
   double e_pre;
   VelCommon vc;
   unsigned slot = 0;
   bool accepted = false;
+#pragma unroll 1
   for (; slot < nf; ++slot) {
     const double r2 = a.W.roots[(unsigned long long)slot * n + cid];
-    if (accept_root(g.obs, g.S, g.Sinv, g.t[1], g.q, a.P, r2, pos, vel, e_pre, vc)) { accepted = true; break; }
+    if (accept_root(obs, S, Sinv, t[1], q, a.P, r2, pos, vel, e_pre, vc)) { accepted = true; break; }
   }
   if (!accepted) { a.W.flags[cid] = (unsigned)kCauseNoRoots; return; }  // no solution at all
-  const double dt01 = g.t[0] - g.t[1], dt21 = g.t[2] - g.t[1];
-  bool slow = !vc.ok || fabs(dt01) <= kEps || fabs(dt21) <= kEps;
+  const double dt01 = t[0] - t[1], dt21 = t[2] - t[1];
+  const bool slow = !vc.ok || fabs(dt01) <= kEps || fabs(dt21) <= kEps;
   if (!slow) {
     a.W.psi0[cid] = prelim_kepuni(velocity_problem(vc, dt01, a.P.kepler_eps, a.P.math_mode));
     a.W.psi0[n + cid] = prelim_kepuni(velocity_problem(vc, dt21, a.P.kepler_eps, a.P.math_mode));
@@ -1043,16 +1054,15 @@ hipError_t launch_observer_prepass(const PrepassArgs& a, hipStream_t s) {
 hipError_t launch_gauss_roots(const RootsArgs& a, hipStream_t s) {
   if (a.cand_count == 0) return hipSuccess;
   const unsigned grid = (unsigned)((a.cand_count + 255) / 256);
-  hipLaunchKernelGGL(k_gauss_roots, dim3(grid), dim3(256), 0, s, a);
+  static const int occ = [] { const char* e = std::getenv("OUTFIT_ROOTS_OCC"); return e ? std::atoi(e) : 4; }();  // tuning aid
+  if (occ == 2) hipLaunchKernelGGL(k_gauss_roots<2>, dim3(grid), dim3(256), 0, s, a);
+  else if (occ == 3) hipLaunchKernelGGL(k_gauss_roots<3>, dim3(grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(k_gauss_roots<4>, dim3(grid), dim3(256), 0, s, a);
   return hipGetLastError();
 }
-hipError_t launch_gauss_prelim(const CorrectArgs& a, hipStream_t s) {
-  if (a.I.n_cand == 0) return hipSuccess;
-  hipError_t e = hipMemsetAsync(a.W.slow_count, 0, sizeof(unsigned long long), s);
-  if (e != hipSuccess) return e;
-  const unsigned grid = (unsigned)((a.I.n_cand + 255) / 256);
-  hipLaunchKernelGGL(k_gauss_prelim, dim3(grid), dim3(256), 0, s, a);
-  return hipGetLastError();
+// the slow list is filled by K2a (fused cold start): reset it before the first K2a slice of a chunk
+hipError_t reset_slow_list(const CandidateScratch& w, hipStream_t s) {
+  return hipMemsetAsync(w.slow_count, 0, sizeof(unsigned long long), s);
 }
 hipError_t launch_gauss_correct_fast(const CorrectArgs& a, unsigned n_cu, hipStream_t s) {
   if (a.I.n_cand == 0) return hipSuccess;
