@@ -48,6 +48,14 @@ struct HeapView {
     w[dst * stride] = w[src * stride];
     id[dst * stride] = id[src * stride];
   }
+  // the stored form of an id, for slot-to-slot copies that do not need to decode it
+  typedef unsigned long long Raw;
+  __device__ __forceinline__ Raw raw(unsigned s) const { return id[s * stride]; }
+  __device__ __forceinline__ Raw encode(unsigned long long ii) const { return ii; }
+  __device__ __forceinline__ void set_raw(unsigned s, double ww, Raw r) const {
+    w[s * stride] = ww;
+    id[s * stride] = r;
+  }
 };
 struct LdsHeapView {
   double* w;
@@ -68,6 +76,17 @@ struct LdsHeapView {
     w[dst * stride] = w[src * stride];
     id[dst * stride] = id[src * stride];
   }
+  typedef unsigned Raw;
+  __device__ __forceinline__ Raw raw(unsigned s) const { return id[s * stride]; }
+  __device__ __forceinline__ Raw encode(unsigned long long ii) const {
+    unsigned i, j, k;
+    unpack_triplet(ii, i, j, k);
+    return (i << 20) | (j << 10) | k;
+  }
+  __device__ __forceinline__ void set_raw(unsigned s, double ww, Raw r) const {
+    w[s * stride] = ww;
+    id[s * stride] = r;
+  }
 };
 
 // WeightedTriplet::cmp (mod.rs:135-146): weight first; indices only when a weight is NaN.
@@ -75,36 +94,47 @@ struct LdsHeapView {
 __device__ __forceinline__ bool wt_le(double wa, double wb) { return wa <= wb; }
 
 // std::collections::BinaryHeap::sift_up(start, pos) with the element held out of the array
+// Every level reads the weight AND the stored id of the slots it may copy in one batch of independent LDS loads (one
+// round trip of latency per level instead of two or three): K0 is a chain of dependent LDS accesses per lane.
+template <class View>
+__device__ __forceinline__ unsigned heap_sift_up_raw(const View& h, unsigned start, unsigned pos, double ew,
+                                                     typename View::Raw er) {
+  while (pos > start) {
+    const unsigned parent = (pos - 1) / 2;
+    const double wp = h.W(parent);
+    const typename View::Raw rp = h.raw(parent);
+    if (wt_le(ew, wp)) break;
+    h.set_raw(pos, wp, rp);
+    pos = parent;
+  }
+  h.set_raw(pos, ew, er);
+  return pos;
+}
 template <class View>
 __device__ __forceinline__ unsigned heap_sift_up(const View& h, unsigned start, unsigned pos, double ew,
                                         unsigned long long ei) {
-  while (pos > start) {
-    const unsigned parent = (pos - 1) / 2;
-    if (wt_le(ew, h.W(parent))) break;
-    h.move(pos, parent);
-    pos = parent;
-  }
-  h.set(pos, ew, ei);
-  return pos;
+  return heap_sift_up_raw(h, start, pos, ew, h.encode(ei));
 }
 
 // BinaryHeap::pop(): swap the last element into the root, sift_down_to_bottom(0), sift_up
 template <class View>
 __device__ __forceinline__ void heap_pop(const View& h, unsigned& len) {
   const double lw = h.W(len - 1);
-  const unsigned long long li = h.I(len - 1);
+  const typename View::Raw lr = h.raw(len - 1);
   --len;
   if (len == 0) return;
   const unsigned end = len;
   unsigned pos = 0, child = 1;
   while (end >= 2 && child <= end - 2) {
-    if (wt_le(h.W(child), h.W(child + 1))) child += 1;
-    h.move(pos, child);
-    pos = child;
+    const double wl = h.W(child), wr = h.W(child + 1);
+    const typename View::Raw rl = h.raw(child), rr = h.raw(child + 1);
+    const bool right = wt_le(wl, wr);
+    h.set_raw(pos, right ? wr : wl, right ? rr : rl);
+    pos = child + (right ? 1u : 0u);
     child = 2 * pos + 1;
   }
   if (child == end - 1) { h.move(pos, child); pos = child; }
-  heap_sift_up(h, 0, pos, lw, li);
+  heap_sift_up_raw(h, 0, pos, lw, lr);
 }
 
 // index_generator.rs:66-75 — reduced index -> original index
@@ -146,6 +176,7 @@ __device__ __forceinline__ unsigned select_triplets(const double* mjd /* this tr
     return mjd[identity ? i : (unsigned)keep_index(i, n_obs, P.max_keep)];
   };
   unsigned len = 0;
+  double root_w = 0.0;  // weight at the top of the heap, kept in a register (one LDS round trip less per candidate)
   for (unsigned anchor = 0; anchor + 2 < n; ++anchor) {
     // LastWindow::compute (index_generator.rs:94-114)
     const double t0 = ep(anchor);
@@ -158,28 +189,41 @@ __device__ __forceinline__ unsigned select_triplets(const double* mjd /* this tr
     for (unsigned middle = anchor + 1; middle < hi; ++middle) {
       const double tm = ep(middle);
       const double g12 = s_gap(tm - t0, P.inv_dtw);
-      for (unsigned last = lo > middle + 1 ? lo : middle + 1; last <= hi; ++last) {
-        const double w = g12 + s_gap(ep(last) - tm, P.inv_dtw);
+      unsigned last = lo > middle + 1 ? lo : middle + 1;
+      double t_last = last <= hi ? ep(last) : 0.0;
+      for (; last <= hi; ++last) {
+        const double tl = t_last;
+        if (last < hi) t_last = ep(last + 1);  // next epoch on its way while this candidate is processed
+        const double w = g12 + s_gap(tl - tm, P.inv_dtw);
         if (!isfinite(w)) continue;
         const unsigned long long id = pack_triplet(anchor, middle, last);
         if (len < P.k_cap) {
           heap_sift_up(h, 0, len, w, id);
           ++len;
-        } else if (w < h.W(0)) {
+          root_w = h.W(0);
+        } else if (w < root_w) {
           heap_pop(h, len);
           heap_sift_up(h, 0, len, w, id);
           ++len;
+          root_w = h.W(0);
         }
       }
     }
   }
-  // sort_unstable_by(weight) restated as a stable insertion sort (equal weights keep heap order)
+  // sort_unstable_by(weight) restated as a stable insertion sort (equal weights keep heap order). The insertion
+  // point is found by bisection (upper bound: after every element <= x, which is what the linear scan from the right
+  // stops at), then the tail is shifted by copies that do not wait for a comparison — the same result as the linear
+  // scan, without its ~K/4 dependent LDS round trips per element.
   for (unsigned i = 1; i < len; ++i) {
     const double xw = h.W(i);
-    const unsigned long long xi = h.I(i);
-    unsigned j = i;
-    while (j > 0 && h.W(j - 1) > xw) { h.move(j, j - 1); --j; }
-    h.set(j, xw, xi);
+    const typename View::Raw xr = h.raw(i);
+    unsigned lo = 0, hi = i;            // first position p in [0, i] with W(p) > xw (or i)
+    while (lo < hi) {
+      const unsigned mid = (lo + hi) / 2;
+      if (h.W(mid) > xw) hi = mid; else lo = mid + 1;
+    }
+    for (unsigned j = i; j > lo; --j) h.move(j, j - 1);
+    h.set_raw(lo, xw, xr);
   }
   return len;
 }

@@ -635,7 +635,7 @@ k_orbit_rms(RmsArgs a) {
 // One wave = 64 trajectories; their candidates are contiguous in the scratch arrays, so the wave stages
 // them through LDS in tiles of kSelTile candidates per trajectory (two rows of 32 contiguous words per load
 // instruction) instead of 64 lanes each walking its own row (one cache line per lane and load).
-constexpr unsigned kSelTile = 16;
+constexpr unsigned kSelTile = 32;  // 32 x 4-byte flags = one 128-byte line per trajectory row (16 fetched every line twice)
 __global__ void __launch_bounds__(64)
 k_select_best(SelectArgs a) {
   __shared__ double s_sum[64][kSelTile + 1];
