@@ -1092,8 +1092,8 @@ hipError_t launch_gauss_correct(const CorrectArgs& a, unsigned n_cu, hipStream_t
 hipError_t launch_orbit_rms(const RmsArgs& a, bool slow_list, hipStream_t s) {
   if (a.I.n_cand == 0) return hipSuccess;
   if (slow_list) {
-    // the list length lives on the device: launch for 1/8 of the candidates (far above any observed
-    // slow fraction) and fall back to a second sweep only through the grid-stride guard below
+    // the list length lives on the device: the grid covers every candidate and the lanes beyond the list return at
+    // once (156 k waves for ~6 x 10^6 instructions of useful work at 10^7 candidates: 0.16 ms)
     const unsigned grid = (unsigned)((a.I.n_cand + 255) / 256);
     hipLaunchKernelGGL(k_orbit_rms<true>, dim3(grid), dim3(256), 0, s, a);
   } else {
