@@ -242,8 +242,7 @@ __device__ __forceinline__ CandidateGeometry load_geometry(const CandidateIndex&
 // ------------------------------------------------------------------------------
 // K2a: direction matrix, 8th-degree polynomial, Aberth roots, root filter
 // ------------------------------------------------------------------------------
-template <unsigned kOcc>
-__global__ void __launch_bounds__(256, kOcc)
+__global__ void __launch_bounds__(256, 4)
 k_gauss_roots(RootsArgs a) {
   const unsigned long long lid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (lid >= a.cand_count) return;
@@ -301,8 +300,11 @@ k_gauss_roots(RootsArgs a) {
   // ---- K2a' fused: first accepted root and the cold-start values of its two universal-Kepler solves. The first
   // iteration of pos_and_vel_correction calls solve_kepuni_with_guess with psi_guess = None, i.e.
   // run_newton(prelim_kepuni(params)) (newton_solver.rs:151-161); prelim_kepuni(params) is what is stored.
-  // Everything it needs (S, S^-1, observer matrix, times) is still in registers; the filtered roots are read back
-  // from this lane's own stores (dynamic indexing of the iterates would push them to scratch).
+  // The geometry (S, S^-1, observer matrix, times) is gathered AGAIN here instead of being kept alive across the
+  // Aberth sweeps: held in registers it cost 70 spilled VGPRs at four waves per SIMD — 336 B of scratch per lane, 6 GB
+  // of HBM traffic per step (measured) — while the gathers hit L2. The filtered roots are read back from this lane's
+  // own stores (dynamic indexing of the iterates would push them to scratch).
+  const CandidateGeometry g = load_geometry(a.I, a.W, cid);
   Mat3 pos;
   Vec3 vel;
   double e_pre;
@@ -312,10 +314,10 @@ k_gauss_roots(RootsArgs a) {
 #pragma unroll 1
   for (; slot < nf; ++slot) {
     const double r2 = a.W.roots[(unsigned long long)slot * n + cid];
-    if (accept_root(obs, S, Sinv, t[1], q, a.P, r2, pos, vel, e_pre, vc)) { accepted = true; break; }
+    if (accept_root(g.obs, g.S, g.Sinv, g.t[1], g.q, a.P, r2, pos, vel, e_pre, vc)) { accepted = true; break; }
   }
   if (!accepted) { a.W.flags[cid] = (unsigned)kCauseNoRoots; return; }  // no solution at all
-  const double dt01 = t[0] - t[1], dt21 = t[2] - t[1];
+  const double dt01 = g.t[0] - g.t[1], dt21 = g.t[2] - g.t[1];
   const bool slow = !vc.ok || fabs(dt01) <= kEps || fabs(dt21) <= kEps;
   if (!slow) {
     a.W.psi0[cid] = prelim_kepuni(velocity_problem(vc, dt01, a.P.kepler_eps, a.P.math_mode));
@@ -635,7 +637,7 @@ k_orbit_rms(RmsArgs a) {
 // One wave = 64 trajectories; their candidates are contiguous in the scratch arrays, so the wave stages
 // them through LDS in tiles of kSelTile candidates per trajectory (two rows of 32 contiguous words per load
 // instruction) instead of 64 lanes each walking its own row (one cache line per lane and load).
-constexpr unsigned kSelTile = 32;  // 32 x 4-byte flags = one 128-byte line per trajectory row (16 fetched every line twice)
+constexpr unsigned kSelTile = 16;
 __global__ void __launch_bounds__(64)
 k_select_best(SelectArgs a) {
   __shared__ double s_sum[64][kSelTile + 1];
@@ -1054,10 +1056,7 @@ hipError_t launch_observer_prepass(const PrepassArgs& a, hipStream_t s) {
 hipError_t launch_gauss_roots(const RootsArgs& a, hipStream_t s) {
   if (a.cand_count == 0) return hipSuccess;
   const unsigned grid = (unsigned)((a.cand_count + 255) / 256);
-  static const int occ = [] { const char* e = std::getenv("OUTFIT_ROOTS_OCC"); return e ? std::atoi(e) : 4; }();  // tuning aid
-  if (occ == 2) hipLaunchKernelGGL(k_gauss_roots<2>, dim3(grid), dim3(256), 0, s, a);
-  else if (occ == 3) hipLaunchKernelGGL(k_gauss_roots<3>, dim3(grid), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(k_gauss_roots<4>, dim3(grid), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_gauss_roots, dim3(grid), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 // the slow list is filled by K2a (fused cold start): reset it before the first K2a slice of a chunk

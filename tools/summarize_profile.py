@@ -19,6 +19,11 @@ src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 LAUNCHES_PER_STEP = {"k_gauss_roots": 4, "k_triplet_select_lds": 4, "k_triplet_select": 4, "k_observer_prepass": 2}
 
 
+def launches_per_step(k):
+    """launches of kernel k in one step (template arguments stripped: k_gauss_roots<4u> -> k_gauss_roots)"""
+    return LAUNCHES_PER_STEP.get(k.split("<")[0], 1)
+
+
 def short(k):
     return k.replace("void ", "").replace("outfit::", "").split("(")[0]
 
@@ -69,7 +74,7 @@ hdr = "%-24s%7s" % ("kernel", "steps") + "".join("%16s" % c[:15] for c in sq_nam
 lines.append(hdr)
 for k in kernels:
     def steps(c):
-        return max(1.0, c.get(k, 0) / LAUNCHES_PER_STEP.get(k, 1))
+        return max(1.0, c.get(k, 0) / launches_per_step(k))
     row = {c: sq.get((k, c), 0.0) / steps(cs) for c in sq_names}
     row["FETCH_SIZE"] = fetch.get((k, "FETCH_SIZE"), 0.0) / steps(cf)
     row["WRITE_SIZE"] = write.get((k, "WRITE_SIZE"), 0.0) / steps(cw)
@@ -107,7 +112,7 @@ with open(out, "w") as f:
         f.write("\nfp64 instruction mix (wave-instructions per step; SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64):\n")
         tot = collections.Counter()
         for k in kernels:
-            st = max(1.0, c64.get(k, 0) / LAUNCHES_PER_STEP.get(k, 1))
+            st = max(1.0, c64.get(k, 0) / launches_per_step(k))
             row = {c: f64.get((k, c), 0.0) / st for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")}
             f.write("%-24s add %.3e  mul %.3e  fma %.3e  trans %.3e\n" % (k, *row.values()))
             if not k.startswith("k_diffcor"):
@@ -123,7 +128,7 @@ pmc = {"source": f"profiles/{name}_rocprof_summary.md (rocprofv3 --pmc FETCH_SIZ
 for k in kernels:
     r = per_step[k]
     fb, wb = r["FETCH_SIZE"] * 1024 * (fetch_factor or 1.0), r["WRITE_SIZE"] * 1024 * (write_factor or 1.0)
-    st64 = max(1.0, c64.get(k, 0) / LAUNCHES_PER_STEP.get(k, 1))
+    st64 = max(1.0, c64.get(k, 0) / launches_per_step(k))
     g = lambda c: f64.get((k, c), 0.0) / st64  # noqa: E731
     pmc["kernels"][k] = {"hbm_bytes_per_step": fb + wb, "fetch_bytes": fb, "write_bytes": wb,
                          "fp64_lane_ops_upper": 64.0 * (g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64")
