@@ -245,7 +245,27 @@ def main():
             t = time.perf_counter()
             outfit_amd.fit_full_iod_records(batch, ephem, params, n_devices=1)
             blk.append(time.perf_counter() - t)
+        # BASELINE configs[1] (1 000 objects): latency bound — 10^5 candidates do not fill 256 CUs
+        ds1 = synth.make_dataset(1000, seed=synth.DEFAULT_SEED, ephem=ephem_d)
+        b1 = outfit_amd.ObsBatch.from_dict(ds1)
+        s1 = outfit_amd.IODSession(b1, ephem, params, device=local_rank)
+        s1.run(stream=stream)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(20):
+            s1.run(stream=stream)
+        torch.cuda.synchronize()
+        small_step = (time.perf_counter() - t) / 20
+        s1.close()
+        small_blk = []
+        for _ in range(4):
+            t = time.perf_counter()
+            outfit_amd.fit_full_iod_records(b1, ephem, params, n_devices=1)
+            small_blk.append(time.perf_counter() - t)
         side = {"isolated_run_ms": 1e3 * min(iso), "blocking_call_ms": 1e3 * min(blk[1:]),
+                "configs1_1000_objects": {"ms_per_step_back_to_back": 1e3 * small_step,
+                                          "objects_per_s": 1000 / small_step,
+                                          "blocking_call_ms": 1e3 * min(small_blk[1:])},
                 "blocking_call_first_ms": 1e3 * blk[0],
                 "blocking_call_objects_per_s": n_obj / min(blk[1:]),
                 "what": "isolated_run = one session run on resident inputs with the device idle before it; "

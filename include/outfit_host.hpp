@@ -43,6 +43,36 @@ struct InvalidConversion { std::string what; };
 struct InvalidOrbit { std::string what; };
 using TrajError = std::variant<NoFeasibleTriplets, NoViableOrbit, InvalidConversion, InvalidOrbit>;
 
+// ---- math mode (include/outfit_hip.h OUTFIT_MATH_*): which bits sin/cos/sinh/cosh return where the reference calls
+// the platform libm. CorrectlyRounded (default) is platform independent; Glibc reproduces a glibc 2.35 host.
+enum class MathMode : int { CorrectlyRounded = OUTFIT_MATH_CORRECTLY_ROUNDED, Glibc = OUTFIT_MATH_GLIBC };
+inline void set_math_mode(MathMode m) {
+  if (outfit_hip_set_math_mode(static_cast<int>(m)) != OUTFIT_OK) throw InvalidIODParameter(outfit_hip_last_error());
+}
+inline MathMode math_mode() { return static_cast<MathMode>(outfit_hip_get_math_mode()); }
+
+// ---- SolverType of kepler::propagate_universal (kepler/params.rs:24-73) -----------------------------
+struct SolverType : outfit_solver_type_t {
+  SolverType() { outfit_hip_solver_type_default(this); }
+};
+struct UniversalPropagResult { double r1[3], v1[3], f_lag, g_lag, f_dot, g_dot, psy; };  // propagation.rs:66-82
+// kepler::propagate_universal for one state; throws DeviceError with the reference's error kind on failure
+inline UniversalPropagResult propagate_universal(const double position[3], const double velocity[3], double t0, double t1,
+                                                 const SolverType& solver = SolverType()) {
+  const double rv[6] = {position[0], position[1], position[2], velocity[0], velocity[1], velocity[2]};
+  double out[11];
+  int32_t st = 0;
+  if (outfit_hip_propagate_universal_ex(1, rv, &t0, &t1, &solver, out, &st) != OUTFIT_OK)
+    throw DeviceError(outfit_hip_last_error());
+  if (st == 1 || st == 3) throw DeviceError("DegenerateState");
+  if (st == 2) throw DeviceError("NewtonRaphsonKeplerConvergence");
+  if (st == 4) throw DeviceError("BrentDekkerKeplerConvergence");
+  UniversalPropagResult r;
+  for (int i = 0; i < 3; ++i) { r.r1[i] = out[i]; r.v1[i] = out[3 + i]; }
+  r.f_lag = out[6]; r.g_lag = out[7]; r.f_dot = out[8]; r.g_dot = out[9]; r.psy = out[10];
+  return r;
+}
+
 // ---- parameters -----------------------------------------------------------------------
 class IODParamsBuilder;
 struct IODParams : outfit_iod_params_t {
