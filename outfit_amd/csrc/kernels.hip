@@ -630,6 +630,63 @@ k_orbit_rms(RmsArgs a) {
   a.W.flags[cid] = flags | (err ? kFlagRmsErr : 0u);
 }
 
+// The mapping BASELINE.json's north_star names — ONE WAVEFRONT PER CANDIDATE — for the RMS stage, as a measurement
+// aid (OUTFIT_RMS_WAVE=1; never the default): lane i evaluates observation i of the window, the terms are then folded
+// left to right exactly as the reference's try_fold does (wave-uniform loop over the lanes, first Err ends it), so the
+// bytes are those of k_orbit_rms<false>. The per-candidate prologue (ccek1, to_equinoctial, frame) is evaluated
+// redundantly by the lanes. A candidate has 20 observations here: 20 of 64 lanes work. Measured: DESIGN.md §3.
+__global__ void __launch_bounds__(256, 3)
+k_orbit_rms_wave(RmsArgs a) {
+  const unsigned long long cid = (unsigned long long)blockIdx.x * 4 + threadIdx.x / 64;
+  const unsigned lane = threadIdx.x % 64;
+  if (cid >= a.I.n_cand) return;
+  const unsigned f0 = a.W.flags[cid];
+  if ((f0 & kFlagEmpty) || !(f0 & kFlagOk) || (f0 & kFlagSlow)) return;
+  const unsigned long long n = a.I.n_cand;
+  const CandidateRef c = decode_candidate(a.I, cid);
+  const Vec3 r2 = {a.W.state[0 * n + cid], a.W.state[1 * n + cid], a.W.state[2 * n + cid]};
+  const Vec3 v2 = {a.W.state[3 * n + cid], a.W.state[4 * n + cid], a.W.state[5 * n + cid]};
+  const double epoch = a.W.state[6 * n + cid];
+  const Elements el = ccek1<false>(equ_to_ecl(r2), equ_to_ecl(v2), epoch);
+  const unsigned flags = (f0 & (kFlagOk | kFlagCorrected | kFlagSlow)) | (el.kind ? kFlagCometary : 0u);
+  Equinoctial eq;
+  const int conv = to_equinoctial(el, eq);
+  if (conv != 0) {
+    if (lane == 0) a.W.flags[cid] = flags | ((unsigned)conv << kFlagConvShift);
+    return;
+  }
+  unsigned long long i_start, i_end;
+  select_rms_interval(a.I.mjd + c.base, c.n_obs, c.idx[0], c.idx[2], a.extf, a.dtmax, i_start, i_end);
+  double acc = 0.0;
+  bool err = false;
+  if (sqrt(eq.h * eq.h + eq.k * eq.k) >= 1.0) {
+    err = true;
+  } else {
+    const TwoBodyFrame F = twobody_frame(eq);
+    for (unsigned long long b0 = i_start; b0 <= i_end && !err; b0 += 64) {
+      const unsigned long long i = b0 + lane;
+      double term = 0.0;
+      int bad = 0;
+      if (i <= i_end) {
+        const unsigned long long o = c.base + i;
+        const Vec3 op = {a.obs_pos[3 * o], a.obs_pos[3 * o + 1], a.obs_pos[3 * o + 2]};
+        bad = !ephemeris_error(eq, F, a.I.mjd[o], a.I.ra[o], a.I.dec[o], a.cos_dec[o], a.I.sra[o], a.I.sdec[o], op, term,
+                               &a.sc);
+      }
+      const unsigned cnt = (unsigned)((i_end - b0 + 1) < 64 ? (i_end - b0 + 1) : 64);
+      for (unsigned k = 0; k < cnt; ++k) {  // the reference's left fold, in observation order
+        if (__shfl(bad, (int)k)) { err = true; break; }
+        acc = acc + __shfl(term, (int)k);
+      }
+    }
+  }
+  if (lane == 0) {
+    a.W.n_win[cid] = (unsigned)(i_end - i_start + 1);
+    a.W.sum[cid] = acc;
+    a.W.flags[cid] = flags | (err ? kFlagRmsErr : 0u);
+  }
+}
+
 // ------------------------------------------------------------------------------
 // K3: replay of the sequential loop of estimate_best_orbit over the candidates of
 // one trajectory, in (triplet, realisation) order.
@@ -1096,6 +1153,11 @@ hipError_t launch_orbit_rms(const RmsArgs& a, bool slow_list, hipStream_t s) {
     const unsigned grid = (unsigned)((a.I.n_cand + 255) / 256);
     hipLaunchKernelGGL(k_orbit_rms<true>, dim3(grid), dim3(256), 0, s, a);
   } else {
+    static const bool wave_per_candidate = std::getenv("OUTFIT_RMS_WAVE") != nullptr;  // measurement aid, see k_orbit_rms_wave
+    if (wave_per_candidate) {
+      hipLaunchKernelGGL(k_orbit_rms_wave, dim3((unsigned)((a.I.n_cand + 3) / 4)), dim3(256), 0, s, a);
+      return hipGetLastError();
+    }
     const unsigned grid = (unsigned)((a.I.n_cand + 255) / 256);
     hipLaunchKernelGGL(k_orbit_rms<false>, dim3(grid), dim3(256), 0, s, a);
   }
