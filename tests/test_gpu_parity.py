@@ -377,3 +377,34 @@ def test_corrupted_inputs_match_the_oracle(ephem_dict):
         if k != "iod":
             assert lsq[k].tobytes() == lref[k].tobytes(), (k, np.nonzero((lsq[k] != lref[k]).reshape(n, -1).any(1))[0][:8])
     assert obs.tobytes() == oref.tobytes()
+
+
+def test_reference_data_file_cadence():
+    """The 37 observations of the reference's own data file (tests/data/2015AB.obs: 2009-2015, nights of 3-7 exposures,
+    gaps of years) through the device and the oracle: real epochs and positions, a synthetic Earth table (DE440 is not
+    available offline) — the triplet generator, the bounded heap, the RMS window and the whole candidate pipeline on a
+    cadence no synthetic generator produced. The oracle's triplets and windows on these epochs are pinned by
+    src/trajectory.rs:566-625 (tests/test_oracle_pipeline.py::test_select_rms_interval_on_the_reference_data_file)."""
+    import json
+    import os
+    k = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_2015AB.json")))
+    obs = k["observations"]
+    mjd = np.array([o["mjd_tt"] for o in obs])
+    eph_d = synth.make_ephemeris(mjd_start=55056.0, n_blocks=64)     # 2009-08-13 .. 2015-03-23
+    helio = synth.earth_equ_au(eph_d, mjd)
+    sig = 0.5 * synth.ARCSEC
+    batch = outfit_amd.ObsBatch(np.array([0, 37], dtype=np.uint64), mjd, [o["ra"] for o in obs], [o["dec"] for o in obs],
+                                np.full(37, sig), np.full(37, sig), helio.reshape(-1), np.zeros(3 * 37), None)
+    ephem = outfit_amd.Ephemeris.from_dict(eph_d)
+    for kw in (dict(max_triplets=10, max_obs_for_triplets=37, n_noise_realizations=0),
+               dict(max_triplets=100, max_obs_for_triplets=37, n_noise_realizations=0, extf=10.0),
+               dict(max_triplets=30, max_obs_for_triplets=12, n_noise_realizations=0, extf=0.001, dtmax=3.0)):
+        params = outfit_amd.IODParams(**kw)
+        got = outfit_amd.fit_full_iod_records(batch, ephem, params, 1)
+        ref = oracle(params, batch, ephem)
+        for f in ("status", "cause", "stage", "kind", "attempts", "n_triplets", "best_triplet"):
+            assert np.array_equal(got[f], ref[f]), (kw, f, got[f], ref[f])
+        assert got["n_triplets"][0] == kw["max_triplets"]
+        if ref["status"][0] == 0:
+            assert np.array_equal(got["elem"], ref["elem"]) and np.array_equal(got["epoch"], ref["epoch"])
+            assert abs(got["rms"][0] - ref["rms"][0]) <= 1e-9 * max(1.0, ref["rms"][0])
