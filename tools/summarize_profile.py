@@ -60,6 +60,26 @@ if ccf.get(k_cal) and cal_f.get((k_cal, "FETCH_SIZE")):
     fetch_factor = CAL_BYTES / (cal_f[(k_cal, "FETCH_SIZE")] * 1024 / ccf[k_cal])
 if ccw.get(k_cal) and cal_w.get((k_cal, "WRITE_SIZE")):
     write_factor = CAL_BYTES / (cal_w[(k_cal, "WRITE_SIZE")] * 1024 / ccw[k_cal])
+# engine clock under load: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / kernel duration, from the same pass's kernel trace
+clk_lines = []
+try:
+    cyc, dur = collections.defaultdict(float), {}
+    for f in glob.glob(os.path.join(src, "pmc_clk", "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                cyc[(short(r["Kernel_Name"]), r["Dispatch_Id"])] += float(r["Counter_Value"])
+    for f in glob.glob(os.path.join(src, "pmc_clk", "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            dur[r["Dispatch_Id"]] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    agg = collections.defaultdict(lambda: [0.0, 0.0])
+    for (k, d), c in cyc.items():
+        if d in dur and not k.startswith("__amd"):
+            agg[k][0] += c
+            agg[k][1] += dur[d]
+    for k, (c, t) in sorted(agg.items()):
+        clk_lines.append("%-24s GRBM_GUI_ACTIVE %.3e cycles over %.3e ns -> %.2f GHz per XCD (sum / 8)" % (k, c, t, c / t / 8.0))
+except (OSError, KeyError, ValueError):
+    pass
 source_hash = None
 try:
     source_hash = open(os.path.join(src, "source_hash.txt")).read().strip()
@@ -120,6 +140,9 @@ with open(out, "w") as f:
         fl = (tot["SQ_INSTS_VALU_ADD_F64"] + tot["SQ_INSTS_VALU_MUL_F64"] + 2 * tot["SQ_INSTS_VALU_FMA_F64"] + tot["SQ_INSTS_VALU_TRANS_F64"]) * 64
         f.write("IOD kernels: executed fp64 lane-operations per step (add + mul + 2 fma + trans, x 64 lanes, upper bound: "
                 "inactive lanes included) %.3e = %.3e per object\n" % (fl, fl / n_obj))
+    if clk_lines:
+        f.write("\nengine clock under this load (separate pass, --pmc GRBM_GUI_ACTIVE; kernels on side streams overlap others and read high):\n")
+        f.write("\n".join(clk_lines) + "\n")
     f.write("```\n")
 pmc = {"source": f"profiles/{name}_rocprof_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_*, separate passes; "
                  "byte counters calibrated on 8-B-per-lane streams)",
