@@ -232,7 +232,7 @@ def main():
     # ---- beside the headline: one isolated run (nothing of a previous run to hide K0 under) and the blocking
     # drop-in call from host buffers (PCIe-inclusive: uploads, kernels, records back). Never `value`.
     side = None
-    if rank == 0 and not args.no_side:
+    if rank == 0 and world == 1 and not args.no_side:   # single-GPU properties; never measured inside an N > 1 job
         torch.cuda.synchronize()
         iso = []
         for _ in range(3):
