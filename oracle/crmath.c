@@ -180,14 +180,19 @@ static void sincos_dd(double x, dd *s, dd *c) {
   }
 }
 
-void orc_sincos(double x, double *s, double *c) {
-  if (LIBM(1) || !(fabs(x) < 1048576.0)) { *s = sin(x); *c = cos(x); return; }
-  if (orc_math_glibc) { *s = orc_glibc_sin(x); *c = orc_glibc_cos(x); return; }
+/* the correctly-rounded pair, whatever the math mode (the differential corrector uses it in every mode but libm) */
+static void sincos_cr(double x, double *s, double *c) {
+  if (!(fabs(x) < 1048576.0)) { *s = sin(x); *c = cos(x); return; }
   if (x == 0.0) { *s = x; *c = 1.0; return; }
   dd sd, cd;
   sincos_dd(x, &sd, &cd);
   *s = sd.hi;
   *c = cd.hi;
+}
+void orc_sincos(double x, double *s, double *c) {
+  if (LIBM(1)) { *s = sin(x); *c = cos(x); return; }
+  if (orc_math_glibc && fabs(x) < 1048576.0) { *s = orc_glibc_sin(x); *c = orc_glibc_cos(x); return; }
+  sincos_cr(x, s, c);
 }
 double orc_sin(double x) { double s, c; orc_sincos(x, &s, &c); return s; }
 double orc_cos(double x) { double s, c; orc_sincos(x, &s, &c); return c; }
@@ -228,8 +233,8 @@ double orc_atan2(double y, double x) { return LIBM(16) ? atan2(y, x) : (double)a
  * raised around the corrector (diffcor.c); orc_use_libm = 1 overrides everything to the platform libm. */
 __thread int orc_cr_scope = 0;
 static int scoped_cr(void) { return !orc_use_libm && orc_cr_scope > 0; }
-double orc_sin_s(double x) { return scoped_cr() ? orc_sin(x) : sin(x); }
-double orc_cos_s(double x) { return scoped_cr() ? orc_cos(x) : cos(x); }
+double orc_sin_s(double x) { double s, c; if (!scoped_cr()) return sin(x); sincos_cr(x, &s, &c); return s; }
+double orc_cos_s(double x) { double s, c; if (!scoped_cr()) return cos(x); sincos_cr(x, &s, &c); return c; }
 double orc_tan_s(double x) { return scoped_cr() ? (double)tanq((__float128)x) : tan(x); }
 double orc_atan2_s(double y, double x) { return scoped_cr() ? (double)atan2q((__float128)y, (__float128)x) : atan2(y, x); }
 double orc_hypot_s(double x, double y) { return scoped_cr() ? (double)hypotq((__float128)x, (__float128)y) : hypot(x, y); }

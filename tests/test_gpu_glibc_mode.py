@@ -108,3 +108,36 @@ def test_sessions_keep_the_mode_they_were_created_with():
     assert np.array_equal(a, run_device(batch, ephem, params, outfit_amd.MATH_GLIBC))
     b = run_device(batch, ephem, params, outfit_amd.MATH_CORRECTLY_ROUNDED)
     assert np.array_equal(a["status"], b["status"]) and not np.array_equal(a["elem"], b["elem"])
+
+
+def test_noisy_realisations_and_the_corrector_in_glibc_mode():
+    """Noisy realisations rebuild the direction cosines per candidate (gauss.rs:341-386 -> unit_matrix) with the mode's
+    sin/cos; the corrector stays correctly rounded in both modes. Device (glibc mode) == oracle (restated mode), bytes."""
+    eph_d = synth.make_ephemeris()
+    ds = synth.make_dataset(400, seed=31337, ephem=eph_d, topocentric=True)
+    params = outfit_amd.IODParams()                      # 10 triplets x (1 + 20 realisations)
+    ds["noise_z"] = synth.SplitMix64(5).normal(400 * params.max_triplets * params.n_noise_realizations * 6)
+    batch, ephem = outfit_amd.ObsBatch.from_dict(ds), outfit_amd.Ephemeris.from_dict(eph_d)
+    got = run_device(batch, ephem, params, outfit_amd.MATH_GLIBC)
+    ref = oracle(params, batch, ephem, glibc=1)
+    d = distance(got, ref)
+    assert d["bit_identical"] == d["orbits"] > 300, d
+    assert (got["best_realization"] > 0).sum() > 50      # noisy candidates do win
+    cfg = outfit_amd.DifferentialCorrectionConfig(rms_divergence_ratio=10.0)
+    with outfit_amd.math_mode(outfit_amd.MATH_GLIBC):
+        lsq, fit = outfit_amd.fit_lsq_records(batch, ephem, params, cfg, got, n_devices=1)
+    L = O.lib()
+    flag = C.c_int.in_dll(L, "orc_math_glibc")
+    flag.value = 1
+    try:
+        rc, lref, fref = O.fit_lsq(params.as_c(), cfg.as_c(), batch.as_c(), ephem.as_c(), got, n_threads=16)
+    finally:
+        flag.value = 0
+    assert rc == 0
+    for k in lsq.dtype.names:
+        if k == "iod":
+            continue
+        x, y = lsq[k], lref[k]
+        same = (x == y) | ((x != x) & (y != y)) if x.dtype.kind == "f" else (x == y)
+        assert same.all(), k
+    assert (lref["status"] == 0).sum() > 100
