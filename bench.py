@@ -84,7 +84,8 @@ def source_hash():
     import hashlib
     h = hashlib.sha256()
     base = os.path.join(ROOT, "outfit_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(base, "*.hip")) + glob.glob(os.path.join(base, "*.h")) +
+    # device code only: the host layer (api.hip, ephem_file.hip) changes no kernel
+    for f in sorted([os.path.join(base, "kernels.hip"), os.path.join(base, "diffcor.hip"), os.path.join(base, "kernels.h")] +
                     glob.glob(os.path.join(base, "device", "*.hpp"))):
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())

@@ -454,7 +454,8 @@ int outfit_hip_calibration_stream(uint64_t n_doubles, int repeats);
 int outfit_hip_prelim_kepuni(uint64_t n, const double *problems /* 6n */, double *out /* n */);
 /* Device memory freed by sessions and blocking calls is kept per device for the next call of a similar shape
  * (hipMalloc/hipFree of the candidate scratch cost ~10 ms per 100 k-object call); this returns it to the driver.
- * The environment variable OUTFIT_NO_CACHE=1 disables the cache. */
+ * The environment variable OUTFIT_NO_CACHE=1 disables the cache; OUTFIT_CACHE_LIMIT_MB bounds what one device may hold
+ * (default 65536 = 64 GiB; blocks beyond it are freed as before). */
 int outfit_hip_trim_cache(void);
 const char *outfit_hip_last_error(void); /* thread-local, never NULL */
 int         outfit_hip_abi_version(void);

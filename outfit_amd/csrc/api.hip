@@ -101,6 +101,11 @@ struct DeviceCache {
   std::mutex m;
   std::multimap<size_t, void*> blocks[64];
   std::vector<StreamSet> sets[64];
+  size_t parked[64] = {};  // bytes held per device; a host that keeps changing batch shapes must not grow this for ever
+  size_t limit = [] {
+    const char* e = std::getenv("OUTFIT_CACHE_LIMIT_MB");
+    return (size_t)(e ? std::max(0ll, std::atoll(e)) : 65536ll) << 20;   // default 64 GiB of the 288 GB device
+  }();
   hipError_t get_streams(StreamSet* out) {
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -145,6 +150,7 @@ struct DeviceCache {
       if (it != blocks[dev].end() && it->first <= 2 * bytes + (1u << 20)) {
         *out = it->second;
         *cap = it->first;
+        parked[dev] -= it->first;
         blocks[dev].erase(it);
         return hipSuccess;
       }
@@ -161,8 +167,15 @@ struct DeviceCache {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (disabled || dev < 0 || dev >= 64) { (void)hipFree(p); return; }
-    std::lock_guard<std::mutex> g(m);
-    blocks[dev].emplace(cap, p);
+    {
+      std::lock_guard<std::mutex> g(m);
+      if (parked[dev] + cap <= limit) {
+        blocks[dev].emplace(cap, p);
+        parked[dev] += cap;
+        return;
+      }
+    }
+    (void)hipFree(p);  // over the limit: back to the driver
   }
   void trim() {
     int cur = 0;
@@ -173,6 +186,7 @@ struct DeviceCache {
       (void)hipSetDevice(d);
       for (auto& kv : blocks[d]) (void)hipFree(kv.second);
       blocks[d].clear();
+      parked[d] = 0;
       for (auto& ss : sets[d]) destroy_streams(ss);
       sets[d].clear();
     }
