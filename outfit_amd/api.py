@@ -369,12 +369,12 @@ def fit_full_iod_records(batch, ephem, params, n_devices=0):
     L = lib()
     pc, bc = params.as_c(), batch.as_c()
     ec = ephem.as_c() if ephem is not None else None
-    out = (GaussResultC * max(batch.n_traj, 1))()
+    out = np.empty(max(batch.n_traj, 1), dtype=RESULT_DTYPE)   # the records land in the array that is returned
     rc = L.outfit_hip_fit_full_iod(C.byref(pc), C.byref(bc), C.byref(ec) if ec is not None else None,
-                                   n_devices, out)
+                                   n_devices, out.ctypes.data_as(C.POINTER(GaussResultC)))
     if rc != 0:
         _raise_rc(rc)
-    return np.frombuffer(out, dtype=RESULT_DTYPE)[:batch.n_traj].copy()
+    return out[:batch.n_traj]
 
 
 def fit_full_iod(batch, ephem, params, n_devices=0):
