@@ -197,3 +197,36 @@ def test_equinoctial_to_keplerian_known_answer():
     import platform
     if platform.libc_ver()[0] == "glibc":
         assert got == want
+
+
+def test_round2_host_entry_points_without_a_gpu(L):
+    """Host-side behaviour of the ABI v5 additions (no compute): math mode, SolverType defaults and validation, cache."""
+    from outfit_amd import _abi
+    assert L.outfit_hip_abi_version() == 5
+    prev = L.outfit_hip_get_math_mode()
+    try:
+        assert L.outfit_hip_set_math_mode(_abi_const("OUTFIT_MATH_GLIBC")) == 0 and L.outfit_hip_get_math_mode() == 1
+        assert L.outfit_hip_set_math_mode(7) == -1 and b"math mode" in L.outfit_hip_last_error()
+        assert L.outfit_hip_get_math_mode() == 1
+    finally:
+        L.outfit_hip_set_math_mode(prev)
+    st = _abi.SolverTypeC()
+    L.outfit_hip_solver_type_default(C.byref(st))        # SolverType::default(), kepler/params.rs:35-44,66-73
+    assert (st.kind, st.parabolic_solving_method, st.max_iter_prelim_kepuni, st.has_psi_guess) == (0, 0, 20, 0)
+    assert st.convergency == 100 * 2.220446049250313e-16
+    dp = C.POINTER(C.c_double)
+    st.kind = 3
+    assert L.outfit_hip_propagate_universal_ex(0, None, None, None, C.byref(st), None, None) == -1   # INVALID_PARAM
+    st.kind, st.parabolic_solving_method = 2, 5
+    assert L.outfit_hip_propagate_universal_ex(0, None, None, None, C.byref(st), None, None) == -1
+    st.parabolic_solving_method = 1
+    assert L.outfit_hip_propagate_universal_ex(0, None, None, None, C.byref(st), None, None) == 0    # nothing to do
+    assert L.outfit_hip_propagate_universal_ex(1, None, None, None, C.byref(st), None, None) == -2   # INVALID_BATCH
+    assert L.outfit_hip_trim_cache() == 0
+    assert L.outfit_hip_session_check(None) == -6                                                    # BAD_HANDLE
+
+
+def _abi_const(name):
+    import re
+    src = open(os.path.join(ROOT, "include", "outfit_hip.h")).read()
+    return int(re.search(rf"#define {name}\s+(-?\d+)", src).group(1))
