@@ -564,7 +564,7 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
   HIP_TRY(s->dirS.alloc(9 * n_cand));
   HIP_TRY(s->roots.alloc((size_t)outfit::kRootSlots * n_cand));
   HIP_TRY(s->state.alloc(7 * n_cand));
-  HIP_TRY(s->queue.alloc(2));  // [0] fast kernel, [1] general kernel
+  HIP_TRY(s->queue.alloc(3));  // [0] fast kernel, [1] general kernel, [2] k_diffcor
   HIP_TRY(s->psi0.alloc(2 * n_cand));
   HIP_TRY(s->slow_list.alloc(n_cand));
   HIP_TRY(s->slow_count.alloc(1));
@@ -853,18 +853,20 @@ int session_run_lsq(outfit_hip_session* s, const outfit_diffcor_config_t* cfg,
   a.initial = initial ? s->dc_initial.p : nullptr;
   a.cfg = make_diffcor_config(cfg);
   a.res = s->dc_res.p; a.sel = s->dc_sel.p; a.cov = s->dc_cov.p; a.qr_work = s->dc_qr.p;
-  a.out = s->dc_out.p; a.obs_fit = s->dc_fit.p;
+  a.out = s->dc_out.p; a.obs_fit = s->dc_fit.p; a.queue = s->queue.p + 2;
   {
     Stamp stamp(s, st, K_DIFFCOR);
     // lanes per trajectory: enough to split the observation loop, not more than the mean arc length pays for
-    // (measured at 20 observations per trajectory: 1 -> 2.04 ms, 2 -> 1.51, 4 -> 1.41, 8 -> 1.64 per 100k objects)
+    // (measured at 20 observations per trajectory, work-queue kernel, correctly-rounded functions:
+    //  1 -> 2.87 ms, 2 -> 1.97, 4 -> 1.82, 8 -> 2.14 per 100k objects — one lane per trajectory has the best
+    //  throughput and the longest tail: the last 11-iteration trajectory alone then takes 11 x 20 observations)
     const double mean_obs = (double)s->n_obs / (double)s->n_traj;
     unsigned group = mean_obs >= 12.0 ? 4u : (mean_obs >= 6.0 ? 2u : 1u);
     if (const char* e = std::getenv("OUTFIT_DIFFCOR_GROUP")) {  // tuning aid
       const unsigned g = (unsigned)std::atoi(e);
       if (g == 1 || g == 2 || g == 4 || g == 8) group = g;
     }
-    HIP_TRY(outfit::launch_diffcor(a, group, st));
+    HIP_TRY(outfit::launch_diffcor(a, group, s->n_cu, st));
   }
   HIP_TRY(hipEventRecord(s->ev_done, st));
   s->done_recorded = true;

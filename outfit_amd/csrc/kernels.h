@@ -164,6 +164,7 @@ struct DiffCorArgs {
   double* qr_work;                 // [42][n_traj * group]
   LsqResultRec* out;               // [n_traj]
   ObsFitRec* obs_fit;              // nullable [n_obs]
+  unsigned long long* queue;       // work-queue head (zeroed before every launch)
 };
 
 hipError_t launch_triplet_select(const TripletArgs& a, bool lds_heap, hipStream_t s);
@@ -175,7 +176,7 @@ hipError_t launch_gauss_correct(const CorrectArgs& a, unsigned n_cu, hipStream_t
 hipError_t launch_orbit_rms(const RmsArgs& a, bool slow_list, hipStream_t s);
 hipError_t launch_select_best(const SelectArgs& a, hipStream_t s);
 constexpr unsigned kDiffcorMaxGroup = 8;  // lanes that may share one trajectory in k_diffcor
-hipError_t launch_diffcor(const DiffCorArgs& a, unsigned group, hipStream_t s);
+hipError_t launch_diffcor(const DiffCorArgs& a, unsigned group, unsigned n_cu, hipStream_t s);
 hipError_t launch_observer_geometry(const GeometryArgs& a, hipStream_t s);
 hipError_t launch_device_normals(unsigned long long seed, const unsigned long long* traj_key,
                                  unsigned long long key_base, unsigned long long n_traj, unsigned k_cap,

@@ -35,3 +35,5 @@ for name, kw in [("default", {}), ("one_iteration", dict(max_newton_iterations=1
     print(f"{name:22s} {t[0] / t[1]:8.3f} ms  mean iters {it.mean():.2f}  max {it.max()}  "
           f"wave-max mean {w.max(1).mean():.2f}  lane efficiency {it.mean() / w.max(1).mean():.2f}  "
           f"converged {(r['status'] == 0).sum()}")
+    if name == "default":
+        print("   iterations histogram:", np.bincount(it)[:40].tolist())
