@@ -85,6 +85,10 @@ def test_lsq_on_given_seeds_1000_objects(ephem_dict):
     dict(rms_divergence_ratio=1e300),                      # long Newton sequences
     dict(enable_outlier_rejection=0, rms_divergence_ratio=1e300),
     dict(max_newton_iterations=1),                         # diff_cor.rs:653-690
+    dict(max_newton_iterations=0),                         # the inner loop never runs: Ok(initial elements), no fit data
+    dict(max_outlier_rejection_passes=0, convergence_before_rejection_threshold=0.0, rms_divergence_ratio=1e300,
+         chi_squared_rejection_threshold=4.0, chi_squared_recovery_threshold=1.0),   # `0..=0`: one pass, selection still updated
+    dict(max_stagnation_iterations=1, rms_stagnation_ratio=0.0, rms_divergence_ratio=1e300),   # leaves at the 2nd iteration
     dict(free_elements=[0, 1, 1, 1, 1, 1], rms_divergence_ratio=1e300),   # fixed semi-major axis
     dict(convergence_before_rejection_threshold=0.0, rms_divergence_ratio=1e300,
          chi_squared_rejection_threshold=4.0, chi_squared_recovery_threshold=1.0),   # forces rejection passes
@@ -98,7 +102,13 @@ def test_lsq_config_variants(ephem_dict, kw):
     ref, ref_obs = oracle_lsq(params, cfg, batch, ephem, seeds)
     compare_lsq(got, got_obs, ref, ref_obs, batch)
     if "chi_squared_rejection_threshold" in kw:
-        assert (ref["n_rejected"] > 0).sum() > 20 and (ref["outer_passes"] > 1).sum() > 20
+        assert (ref["n_rejected"] > 0).sum() > 20
+        if kw.get("max_outlier_rejection_passes") == 0:
+            assert (ref["outer_passes"] <= 1).all()
+        else:
+            assert (ref["outer_passes"] > 1).sum() > 20
+    if kw.get("max_newton_iterations") == 0:
+        assert (ref["total_newton_iterations"] == 0).all()
 
 
 def test_lsq_rejects_injected_outliers(ephem_dict):
