@@ -340,7 +340,12 @@ enum CorrStep { kCorrContinue = 0, kCorrSome = 1, kCorrNone = 2, kCorrSlow = 3 }
 // The eccentricity_control at the end of an iteration is evaluated on exactly the (r2, v2)
 // the next iteration starts from (gauss.rs:1385 vs velocity.rs:112), so its outcome is kept in
 // st.vc instead of being recomputed.
-template <bool kFast>
+//
+// kWarmOnly: both solves start from st.chi01 / st.chi21 whatever the has-flags say — the caller has put the
+// cold-start value prelim_kepuni(params) there before the first iteration (solve_kepuni_with_guess(None) IS
+// run_newton(prelim_kepuni(params)), and a first iteration whose solves fail ends the loop: the cold start is
+// never needed again), so the correctly-rounded cold-start code stays out of the loop body.
+template <bool kFast, bool kWarmOnly = kFast>
 __device__ __forceinline__ CorrStep correction_iteration(const Mat3& obs, const Mat3& S, const Mat3& Sinv,
                                                          double t_mid, double dt01, double dt21,
                                                          const GaussParams& P, CorrectionState& st) {
@@ -364,7 +369,7 @@ __device__ __forceinline__ CorrStep correction_iteration(const Mat3& obs, const 
     const double dt = side ? dt21 : dt01;
     const double chi = side ? st.chi21 : st.chi01;
     const KeplerProblem p = velocity_problem(st.vc, dt, P.kepler_eps, P.math_mode);
-    const KeplerSolution sol = kFast ? run_newton(p, chi) : solve_kepuni(p, side ? st.has21 : st.has01, chi);
+    const KeplerSolution sol = kWarmOnly ? run_newton(p, chi) : solve_kepuni(p, side ? st.has21 : st.has01, chi);
     const VelCorr vc = velocity_finish(sol, side ? r3 : r1, r2, st.vc.r2, dt);
     if (side) b = vc; else a = vc;
   }

@@ -444,8 +444,16 @@ k_gauss_correct(CorrectArgs a) {
   const unsigned long long n_items = *a.W.slow_count;
   auto L = [&](unsigned k) -> double& { return lds[k * bs + tid]; };
 
+  // A short list is spread over the waves of the grid instead of filling the first ones: lanes of one wave walk
+  // their roots in lockstep, so every cold start or long loop of a neighbour lengthens a candidate's own chain —
+  // which is what a small batch waits for. `quota` lanes per wave take work (64 when the list is long).
+  const unsigned long long n_waves = (unsigned long long)gridDim.x * (bs / 64u);
+  const unsigned long long per_wave = (n_items + n_waves - 1) / n_waves;
+  const unsigned quota = per_wave >= 64ull ? 64u : (per_wave < 1ull ? 1u : (unsigned)per_wave);
+  const unsigned refill_at = quota >= 4u * kRefillThreshold ? kRefillThreshold : (quota + 3u) / 4u;
+
   long long cand = -1;
-  bool exhausted = false, need_init = false, have_prelim = false;
+  bool exhausted = (tid % 64u) >= quota, need_init = false, have_prelim = false;
   unsigned slot = 0, n_filt = 0, pushes = 0;
   double t_mid = 0.0, dt01 = 0.0, dt21 = 0.0;
   GaussGeometry q{};
@@ -455,7 +463,7 @@ k_gauss_correct(CorrectArgs a) {
     const bool needy = (cand < 0) && !exhausted;
     const unsigned long long need_mask = __ballot(needy);
     const unsigned long long active_mask = __ballot(cand >= 0);
-    if (need_mask && ((unsigned)__popcll(need_mask) >= kRefillThreshold || active_mask == 0ull)) {
+    if (need_mask && ((unsigned)__popcll(need_mask) >= refill_at || active_mask == 0ull)) {
       const unsigned long long my = wave_grab(a.queue, need_mask);
       if (needy) {
         if (my >= n_items) {
@@ -506,7 +514,14 @@ k_gauss_correct(CorrectArgs a) {
           accepted = true;
           L(27) = st.pos.m[0][1]; L(28) = st.pos.m[1][1]; L(29) = st.pos.m[2][1];
           L(30) = st.vel.x; L(31) = st.vel.y; L(32) = st.vel.z; L(33) = e_pre;
-          st.epoch = 0.0; st.chi01 = 0.0; st.chi21 = 0.0; st.has01 = false; st.has21 = false; st.it = 0;
+          st.epoch = 0.0; st.has01 = false; st.has21 = false; st.it = 0;
+          // cold starts of the first iteration's two solves (newton_solver.rs:151-161), evaluated here so that the
+          // loop body below is the warm iteration only
+          st.chi01 = st.chi21 = 0.0;
+          if (st.vc.ok) {
+            st.chi01 = prelim_kepuni(velocity_problem(st.vc, dt01, a.P.kepler_eps, a.P.math_mode));
+            st.chi21 = prelim_kepuni(velocity_problem(st.vc, dt21, a.P.kepler_eps, a.P.math_mode));
+          }
           break;
         }
         ++slot;
@@ -515,7 +530,7 @@ k_gauss_correct(CorrectArgs a) {
       if (!accepted) finished = true;
       else if (fabs(dt01) <= kEps || fabs(dt21) <= kEps) step = kCorrNone;  // gauss.rs:1311-1313
     } else {
-      step = correction_iteration<false>(obs, S, Sinv, t_mid, dt01, dt21, a.P, st);
+      step = correction_iteration<false, true>(obs, S, Sinv, t_mid, dt01, dt21, a.P, st);
     }
     const unsigned long long ucand = (unsigned long long)cand;
     if (step == kCorrSome) {
