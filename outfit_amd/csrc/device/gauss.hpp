@@ -332,10 +332,11 @@ enum CorrStep { kCorrContinue = 0, kCorrSome = 1, kCorrNone = 2, kCorrSlow = 3 }
 // ONE iteration of the loop at gauss.rs:1316-1415. `continue` in the reference = return
 // kCorrContinue here (the iteration is consumed, the state is kept).
 //
-// kFast = true is the warm, regular path only: both Kepler solves start from the previous
-// iteration's chi (or the precomputed cold-start value) and every check passes; anything else
-// returns kCorrSlow and the caller hands the candidate to the general (kFast = false) kernel,
-// which replays it from its first iteration. Results are identical by construction.
+// kFast = true is the path of the persistent fast kernel, which walks ONE root: every outcome that ends or
+// continues this root's loop is handled in place (the `continue`s of the reference, Some(state) at a fixed point
+// or at the last iteration); only the rejection by eccentricity_control inside the loop — None: a PrelimOrbit is
+// pushed and the NEXT root is tried — returns kCorrSlow, and the caller hands the candidate to the general
+// (kFast = false) kernel, which replays it from its first root. Results are identical by construction.
 //
 // The eccentricity_control at the end of an iteration is evaluated on exactly the (r2, v2)
 // the next iteration starts from (gauss.rs:1385 vs velocity.rs:112), so its outcome is kept in
@@ -356,7 +357,7 @@ __device__ __forceinline__ CorrStep correction_iteration(const Mat3& obs, const 
   // and the loop ends with Some(current state) (gauss.rs:1417): return that now. This is the
   // common fate of spurious roots, which get stuck on rho2 < min_rho2 until itmax.
   // A `continue` before the chi update changes nothing at all, hence `rare` = Some directly.
-  const CorrStep rare = kFast ? kCorrSlow : kCorrSome;
+  const CorrStep rare = kCorrSome;
   const Vec3 r1 = column(st.pos, 0), r2 = column(st.pos, 1), r3 = column(st.pos, 2);
   if (!st.vc.ok) return rare;
   const bool had_both = st.has01 && st.has21;
@@ -379,10 +380,10 @@ __device__ __forceinline__ CorrStep correction_iteration(const Mat3& obs, const 
   const bool fixed_point = had_both && __double_as_longlong(a.chi) == chi01_old &&
                            __double_as_longlong(b.chi) == chi21_old;
   const CorrStep skip = (fixed_point || last) ? kCorrSome : kCorrContinue;
-  if (!isfinite(a.g) || !isfinite(b.g)) return kFast ? kCorrSlow : skip;
+  if (!isfinite(a.g) || !isfinite(b.g)) return skip;
   const Vec3 nv = {(a.v.x + b.v.x) * 0.5, (a.v.y + b.v.y) * 0.5, (a.v.z + b.v.z) * 0.5};
   const double fl = a.f * b.g - b.f * a.g;
-  if (!isfinite(fl) || fabs(fl) < kEps) return kFast ? kCorrSlow : skip;
+  if (!isfinite(fl) || fabs(fl) < kEps) return skip;
   const double inv_f = 1.0 / fl;
   const Vec3 c = {b.g * inv_f, -1.0, -a.g * inv_f};
   Mat3 np;
@@ -392,7 +393,7 @@ __device__ __forceinline__ CorrStep correction_iteration(const Mat3& obs, const 
   const EccControl ec = eccentricity_control(nr2, nv, P.max_perihelion_au, P.max_ecc);
   if (!ec.some || !ec.accepted) return kFast ? kCorrSlow : kCorrNone;
   const double denom = frob(np);
-  if (!isfinite(denom) || denom <= kEps) return kFast ? kCorrSlow : skip;
+  if (!isfinite(denom) || denom <= kEps) return skip;
   Mat3 d;
 #pragma unroll
   for (int r = 0; r < 3; ++r)

@@ -26,6 +26,8 @@ constexpr unsigned kFlagConvShift = 8;        // 3 bits: to_equinoctial error (3
 constexpr unsigned kFlagRootsShift = 12;      // 4 bits: number of filtered roots (phase A -> B)
 constexpr unsigned kFlagFirstShift = 16;      // 4 bits: slot of the first accepted root (K2a' -> K2b)
 constexpr unsigned kFlagSlow = 0x100000u;     // irregular candidate: handled by the general kernel
+constexpr unsigned kFlagFirstNone = 0x200000u;  // the fast kernel ran the first accepted root's loop to its None:
+                                                // the general kernel pushes that PrelimOrbit and goes on with the next root
 
 // same 96-byte layout as outfit_gauss_result_t (include/outfit_hip.h)
 struct GaussResultRec {

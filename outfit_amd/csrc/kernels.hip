@@ -422,7 +422,9 @@ k_gauss_correct_fast(CorrectArgs a) {
       a.W.flags[ucand] = kFlagOk | kFlagCorrected;
       cand = -1;
     } else if (step == kCorrSlow) {
-      a.W.flags[ucand] |= kFlagSlow;  // marks it for the general kernel and the second RMS pass
+      // None inside the loop (eccentricity_control rejected an iterate): the root walk continues in the general
+      // kernel, which does not replay this root's loop; kFlagSlow also selects the second RMS pass
+      a.W.flags[ucand] |= kFlagSlow | kFlagFirstNone;
       append_slow(a.W, ucand);
       cand = -1;
     }
@@ -453,7 +455,7 @@ k_gauss_correct(CorrectArgs a) {
   const unsigned refill_at = quota >= 4u * kRefillThreshold ? kRefillThreshold : (quota + 3u) / 4u;
 
   long long cand = -1;
-  bool exhausted = (tid % 64u) >= quota, need_init = false, have_prelim = false;
+  bool exhausted = (tid % 64u) >= quota, need_init = false, have_prelim = false, resume = false;
   unsigned slot = 0, n_filt = 0, pushes = 0;
   double t_mid = 0.0, dt01 = 0.0, dt21 = 0.0;
   GaussGeometry q{};
@@ -486,7 +488,11 @@ k_gauss_correct(CorrectArgs a) {
           dt21 = g.t[2] - g.t[1];
           cand = (long long)cid;
           n_filt = (f >> kFlagRootsShift) & 0xFu;
-          slot = 0; pushes = 0; have_prelim = false; need_init = true;
+          // a candidate handed over by the fast kernel resumes at its first accepted root, whose loop is known to
+          // have ended in None (the roots before it were not accepted: same inputs, same answer)
+          resume = (f & kFlagFirstNone) != 0u;
+          slot = resume ? ((f >> kFlagFirstShift) & 0xFu) : 0u;
+          pushes = 0; have_prelim = false; need_init = true;
         }
       }
     }
@@ -518,7 +524,7 @@ k_gauss_correct(CorrectArgs a) {
           // cold starts of the first iteration's two solves (newton_solver.rs:151-161), evaluated here so that the
           // loop body below is the warm iteration only
           st.chi01 = st.chi21 = 0.0;
-          if (st.vc.ok) {
+          if (st.vc.ok && !resume) {
             st.chi01 = prelim_kepuni(velocity_problem(st.vc, dt01, a.P.kepler_eps, a.P.math_mode));
             st.chi21 = prelim_kepuni(velocity_problem(st.vc, dt21, a.P.kepler_eps, a.P.math_mode));
           }
@@ -528,7 +534,9 @@ k_gauss_correct(CorrectArgs a) {
       }
       need_init = false;
       if (!accepted) finished = true;
+      else if (resume) step = kCorrNone;  // this root's loop ran in the fast kernel: PrelimOrbit, next root
       else if (fabs(dt01) <= kEps || fabs(dt21) <= kEps) step = kCorrNone;  // gauss.rs:1311-1313
+      resume = false;
     } else {
       step = correction_iteration<false, true>(obs, S, Sinv, t_mid, dt01, dt21, a.P, st);
     }

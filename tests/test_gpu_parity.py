@@ -111,6 +111,33 @@ def test_config2_1000_objects(ephem_dict):
     compare(got, ref)
 
 
+@pytest.mark.parametrize("kw", [
+    dict(max_tested_solutions=1),
+    dict(max_tested_solutions=2),
+    dict(max_ecc=0.35, max_perihelion_au=3.5),               # eccentricity_control rejects iterates inside the loop
+    dict(max_ecc=0.35, max_perihelion_au=3.5, max_tested_solutions=1),
+    dict(max_ecc=0.35, max_perihelion_au=3.5, max_tested_solutions=2, newton_max_it=7),
+])
+def test_root_walk_and_handover(ephem_dict, kw):
+    """The walk over the accepted roots (gauss.rs:1147-1197): a root whose correction loop ends in None pushes a
+    PrelimOrbit and the next root is tried, at most max_tested_solutions pushes. On the device the fast kernel
+    runs the first root's loop and, on None, hands the candidate to the general kernel, which resumes at the
+    next root without replaying the loop: tight eccentricity / perihelion limits make that path common."""
+    ds = synth.make_dataset(600, seed=31, ephem=ephem_dict)
+    batch = outfit_amd.ObsBatch.from_dict(ds)
+    ephem = outfit_amd.Ephemeris.from_dict(ephem_dict)
+    params = synth.bench_params(outfit_amd.IODParams())
+    for k, v in kw.items():
+        setattr(params, k, v)
+    got = outfit_amd.fit_full_iod_records(batch, ephem, params, n_devices=1)
+    ref = oracle(params, batch, ephem)
+    compare(got, ref)
+    if "max_ecc" in kw:   # the limits bite: prelim orbits are returned, not only corrected ones
+        ok = ref["status"] == 0
+        assert (ref["stage"][ok] == outfit_amd._abi.STAGE_PRELIM).sum() > 5
+        assert (ref["stage"][ok] == outfit_amd._abi.STAGE_CORRECTED).sum() > 5
+
+
 def test_topocentric_and_no_ephemeris(ephem_dict):
     """obs_geo_ecl != 0 exercises the Chebyshev pre-pass; ephem=None uses obs_helio_equ directly."""
     ds = synth.make_dataset(200, seed=7, ephem=ephem_dict, topocentric=True)
