@@ -78,6 +78,85 @@ def cpu_baseline(batch, ephem, params, n_obj_max, budget_s=15.0, cores=None, hoi
                       "reference"}
 
 
+def host_libm():
+    """What the oracle's `orc_use_libm = 1` mode evaluates with on this host (the reference's arithmetic when glibc)."""
+    import platform
+    name, ver = platform.libc_ver()
+    return f"{name or 'unknown'} {ver} {platform.machine()}".strip()
+
+
+def parity_vs_libm(batch, ephem, params, records_by_mode, n_sample):
+    """Sample check of the timed batch against the reference-faithful arithmetic: the oracle with the PLATFORM libm
+    (orc_use_libm = 1: bit-exact on every reference KAT on glibc) on the first n_sample objects, per device math mode.
+    Tolerance = BASELINE.json north_star: 1e-10 AU (a, e), 1e-12 rad (i, Omega, omega, M)."""
+    import numpy as np
+    import oracle_lib as O
+    sub = batch.slice(0, n_sample)
+    t = time.perf_counter()
+    with O.math_flags(libm=1):
+        rc, ref = O.fit_full_iod(params.as_c(), sub.as_c(), ephem.as_c(), n_threads=host_cores(), hoist=1)
+    assert rc == 0
+    out = {"sample": f"first {n_sample} objects of the timed batch", "oracle": "CPU restatement, platform libm (orc_use_libm=1)",
+           "host_libm": host_libm(), "oracle_seconds": time.perf_counter() - t,
+           "tolerance": {"len_AU": 1e-10, "angle_rad": 1e-12}}
+    ints = ("status", "cause", "stage", "kind", "attempts", "n_triplets", "best_triplet", "best_realization")
+    ok = ref["status"] == 0
+    for mode, recs in records_by_mode.items():
+        g = recs[:n_sample]
+        int_same = all(np.array_equal(g[k], ref[k]) for k in ints)
+        dl = np.abs(g["elem"][ok][:, :2] - ref["elem"][ok][:, :2]).max(axis=1)
+        da = np.abs(g["elem"][ok][:, 2:] - ref["elem"][ok][:, 2:])
+        da = np.minimum(da, np.abs(2 * np.pi - da)).max(axis=1)
+        rr = np.abs(g["rms"][ok] - ref["rms"][ok]) / np.maximum(1.0, ref["rms"][ok])
+        out[mode] = {"orbits": int(ok.sum()), "integer_fields_identical": bool(int_same),
+                     "bit_identical_elements": int((g["elem"][ok] == ref["elem"][ok]).all(axis=1).sum()),
+                     "beyond_1e-10_AU": int((dl > 1e-10).sum()), "beyond_1e-12_rad": int((da > 1e-12).sum()),
+                     "max_d_len": float(dl.max()), "max_d_angle": float(da.max()), "max_rel_d_rms": float(rr.max())}
+    return out
+
+
+def noise_point(label, ds, ephem, params, device, stream, steps, seed):
+    """SURVEY §8(d)'s second point: noisy realisations with HOST-drawn standard normals (gauss.rs:323-387,
+    trajectory.rs:462-477), inputs and normals resident; one warm-up, `steps` timed steps, per-kernel HIP-event times."""
+    import numpy as np
+    import torch
+    import outfit_amd
+    n_obj = int(ds["n_traj"])
+    n_z = n_obj * params.max_triplets * params.n_noise_realizations * 6
+    z = np.empty(n_z, dtype=np.float64)
+    rng = np.random.default_rng(seed)
+    step_n = 1 << 26
+    for a in range(0, n_z, step_n):      # in place, 512 MiB at a time
+        rng.standard_normal(out=z[a:a + step_n])
+    d = dict(ds)
+    d["noise_z"] = z
+    batch = outfit_amd.ObsBatch.from_dict(d)
+    t = time.perf_counter()
+    s = outfit_amd.IODSession(batch, ephem, params, device=device)
+    s.run(stream=stream)
+    torch.cuda.synchronize()
+    setup = time.perf_counter() - t
+    s.set_profiling(True)
+    t = time.perf_counter()
+    for _ in range(steps):
+        s.run(stream=stream)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / steps
+    kt = s.kernel_times()
+    s.set_profiling(False)
+    rec = s.results()
+    s.close()
+    cand = n_obj * params.max_triplets * (1 + params.n_noise_realizations)
+    return {"what": label, "objects": n_obj, "max_triplets": params.max_triplets,
+            "n_noise_realizations": params.n_noise_realizations, "candidates_per_step": cand,
+            "normals": f"{n_z} host-drawn standard normals ({n_z * 8 / 1e9:.2f} GB, numpy PCG64), resident in HBM",
+            "steps": steps, "ms_per_step": 1e3 * dt, "objects_per_s": n_obj / dt, "candidates_per_s": cand / dt,
+            "kernel_avg_ms_per_step": {k: v[0] / steps for k, v in kt.items()},
+            "orbits_found": int((rec["status"] == 0).sum()),
+            "noisy_winners": int(((rec["status"] == 0) & (rec["best_realization"] > 0)).sum()),
+            "session_build_and_first_run_s": setup}
+
+
 def source_hash():
     """Content hash of the kernel sources: ties a committed rocprof/PMC profile to the build it was taken from."""
     import glob
@@ -116,6 +195,12 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--objects", type=int, default=100000, help="objects per GPU (weak scaling)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --objects per GPU (default); strong: --total-objects split over the GPUs (BASELINE configs[3])")
+    ap.add_argument("--total-objects", type=int, default=1_000_000, help="objects of the whole job for --scaling strong")
+    ap.add_argument("--no-noise", action="store_true", help="skip the noisy-realisation side measurements (SURVEY 8d)")
+    ap.add_argument("--no-modes", action="store_true", help="skip timing the other math mode and the parity sample")
+    ap.add_argument("--parity-sample", type=int, default=2000, help="objects of the timed batch checked against the libm oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lsq", action="store_true", help="skip the differential-correction side measurement")
     ap.add_argument("--no-side", action="store_true", help="skip the isolated-run / blocking-call side measurements")
@@ -170,21 +255,41 @@ def main():
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
 
-    # ---- this rank's shard of the synthetic dataset (weak scaling: fixed objects per GPU) ----
-    n_obj = args.objects
+    # ---- this rank's shard of the synthetic dataset ----
     ephem_d = synth.make_ephemeris()
-    ds = synth.make_dataset(n_obj, seed=synth.DEFAULT_SEED + rank, ephem=ephem_d)
+    if args.scaling == "weak":        # fixed objects per GPU, another seed per rank
+        n_obj = args.objects
+        counts = [n_obj] * world
+        ds = synth.make_dataset(n_obj, seed=synth.DEFAULT_SEED + rank, ephem=ephem_d)
+    else:                             # one global dataset of 25 000-object blocks (block b = seed + b), contiguous ranges
+        blk = 25000
+        n_blocks = max(world, -(-args.total_objects // blk))
+        cuts = [n_blocks * r // world for r in range(world + 1)]
+        counts = [(cuts[r + 1] - cuts[r]) * blk for r in range(world)]
+        n_obj = counts[rank]
+        ds = synth.make_dataset_blocks(n_obj, block=blk, seed=synth.DEFAULT_SEED + cuts[rank], ephem=ephem_d)
     batch = outfit_amd.ObsBatch.from_dict(ds)
+    # every rank knows everybody's record count: `counts` follows the partition rule of the library and dist.py
+    # (contiguous ranges balanced by observation count — all trajectories have 20 observations here)
+    from outfit_amd import dist as odist
+    uniform = np.arange(0, sum(counts) + 1, dtype=np.uint64) * np.uint64(20)
+    if len(set(counts)) == 1:
+        assert odist.partition_by_observations(uniform, world) == [counts[0] * r for r in range(world + 1)]
     ephem = outfit_amd.Ephemeris.from_dict(ephem_d)
     params = synth.bench_params(outfit_amd.IODParams())
     n_obs = int(batch.traj_offset[-1])
+    n_max = max(counts)
 
-    session = outfit_amd.IODSession(batch, ephem, params, device=local_rank)
+    # the headline runs in the library's default math mode (OUTFIT_MATH_GLIBC: the reference-faithful one, §4.0)
+    mode_names = {outfit_amd.MATH_GLIBC: "glibc", outfit_amd.MATH_CORRECTLY_ROUNDED: "cr"}
+    head_mode = outfit_amd.get_math_mode()
+    session = outfit_amd.IODSession(batch, ephem, params, device=local_rank, math_mode=head_mode)
     # result buffers are double-buffered so that the gather of step i (RCCL, its own stream) overlaps the kernels
     # of step i+1; a buffer is reused only after the gather that read it has been waited for
-    out_local = [torch.empty((n_obj, BYTES_PER_RESULT), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    # (n_max rows: ranks may own different counts under --scaling strong; the gather needs equal shapes)
+    out_local = [torch.zeros((n_max, BYTES_PER_RESULT), dtype=torch.uint8, device="cuda") for _ in range(2)]
     gather_dev = "cuda" if args.backend == "nccl" else "cpu"
-    out_all = [torch.empty((world * n_obj, BYTES_PER_RESULT), dtype=torch.uint8, device=gather_dev) for _ in range(2)] \
+    out_all = [torch.empty((world * n_max, BYTES_PER_RESULT), dtype=torch.uint8, device=gather_dev) for _ in range(2)] \
         if multi else None
     # An explicit torch stream: torch's default stream has handle 0, which the C ABI reads as "the session's own
     # stream" — the collective (RCCL syncs with torch's CURRENT stream) would then not wait for the kernels.
@@ -195,13 +300,13 @@ def main():
     pending = [None, None]
     state = {"step": 0}
 
-    def step():
+    def step(sess=None):
         b = state["step"] & 1
         state["step"] += 1
         if pending[b] is not None:
             pending[b].wait()
             pending[b] = None
-        session.run(stream=stream, d_out=out_local[b].data_ptr())
+        (sess or session).run(stream=stream, d_out=out_local[b].data_ptr())
         if multi:
             if args.backend == "nccl":
                 pending[b] = dist.all_gather_into_tensor(out_all[b], out_local[b], async_op=True)
@@ -217,18 +322,47 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    session.set_profiling(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    ktimes = session.kernel_times()      # HIP events on the run's stream over the whole timed region
-    session.set_profiling(False)
-    session.check()                      # an epoch outside the ephemeris table is an error here as in the blocking API
+    def timed(sess):
+        """W warm-up steps, then exactly K steps between fences; (seconds, {kernel: (ms, launches)})."""
+        for _ in range(args.warmup):
+            step(sess)
+        fence()
+        sess.set_profiling(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(sess)
+        fence()
+        dt = time.perf_counter() - t0
+        kt = sess.kernel_times()     # HIP events on the run's stream over the whole timed region
+        sess.set_profiling(False)
+        sess.check()                 # an epoch outside the ephemeris table is an error here as in the blocking API
+        return dt, kt
+
+    elapsed, ktimes = timed(session)
+    last_b = (state["step"] - 1) & 1
+    res = np.frombuffer(out_local[last_b][:n_obj].cpu().numpy().tobytes(), dtype=outfit_amd._abi.RESULT_DTYPE).copy()
+    gathered = out_all[last_b].cpu().numpy().copy() if multi else None
+
+    # ---- the other math mode, timed the same way on the same resident batch (never `value`), and a sample of the
+    # timed batch against the reference-faithful arithmetic (the oracle with the platform libm) for both modes
+    modes = None
+    if rank == 0 and world == 1 and not args.no_modes:
+        other = outfit_amd.MATH_CORRECTLY_ROUNDED if head_mode == outfit_amd.MATH_GLIBC else outfit_amd.MATH_GLIBC
+        s2 = outfit_amd.IODSession(batch, ephem, params, device=local_rank, math_mode=other)
+        el2, kt2 = timed(s2)
+        res2 = np.frombuffer(out_local[(state["step"] - 1) & 1][:n_obj].cpu().numpy().tobytes(),
+                             dtype=outfit_amd._abi.RESULT_DTYPE).copy()
+        s2.close()
+        def mode_line(el, kt):
+            return {"value": n_obj * args.steps / el, "unit": "objects/s", "ms_per_step": 1e3 * el / args.steps,
+                    "kernel_avg_ms_per_step": {k: v[0] / args.steps for k, v in kt.items()}}
+        modes = {"headline": mode_names[head_mode],
+                 mode_names[head_mode]: mode_line(elapsed, ktimes), mode_names[other]: mode_line(el2, kt2)}
+        modes["ratio_other_over_headline"] = modes[mode_names[other]]["value"] / modes[mode_names[head_mode]]["value"]
+        if args.parity_sample > 0 and not args.no_cpu_baseline:
+            modes["parity_vs_libm"] = parity_vs_libm(batch, ephem, params,
+                                                     {mode_names[head_mode]: res, mode_names[other]: res2},
+                                                     min(args.parity_sample, n_obj))
 
     # ---- beside the headline: one isolated run (nothing of a previous run to hide K0 under) and the blocking
     # drop-in call from host buffers (PCIe-inclusive: uploads, kernels, records back). Never `value`.
@@ -272,12 +406,25 @@ def main():
                 "what": "isolated_run = one session run on resident inputs with the device idle before it; "
                         "blocking_call = outfit_hip_fit_full_iod from host buffers (upload 1 856 B/object, kernels, "
                         "96-B records back; steady state after the first call, which also creates streams and scratch)"}
+        # SURVEY §8(d)'s second reported point: noisy realisations with host-drawn normals, on the same objects
+        if not args.no_noise:
+            p_def = outfit_amd.IODParams()                 # IODParams::default(): 10 triplets x (1 + 20) realisations
+            p_8d = synth.bench_params(outfit_amd.IODParams())
+            p_8d.n_noise_realizations = 10                 # the §8(d) shape: 100 triplets x (1 + 10)
+            nsteps = max(2, min(args.steps, 5))
+            side["noise"] = {
+                "iod_params_default": noise_point("IODParams::default(): max_triplets 10, n_noise_realizations 20, "
+                                                  "max_obs_for_triplets 100 (mod.rs:308-344)", ds, ephem, p_def,
+                                                  local_rank, stream, nsteps, 20261004),
+                "survey_8d": noise_point("bench params with n_noise_realizations = 10 (SURVEY 8d: 100 triplets x 11)",
+                                         ds, ephem, p_8d, local_rank, stream, nsteps, 20261005)}
 
     # ---- next row (BASELINE configs[4]): IOD seed -> differential correction ----
     # Measured after the headline region and reported beside it, never mixed into `value`.
     lsq = None
     if not args.no_lsq:
         cfg = outfit_amd.DifferentialCorrectionConfig()
+        session.run(stream=stream)            # the seeds: this session's own IOD records
         session.run_lsq(cfg, stream=stream)   # warm-up (allocates the corrector's scratch)
         fence()
         session.set_profiling(True)
@@ -293,21 +440,30 @@ def main():
                "n_diffcor": int((lrec["status"] == 0).sum()), "n_iod_kept": int((lrec["status"] == 1).sum()),
                "mean_newton_iterations": float(lrec["total_newton_iterations"].mean())}
 
+    gather_check = None
     if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-
-    # sanity: the timed work produced orbits
-    last = out_local[(state["step"] - 1) & 1]
-    res = np.frombuffer(last.cpu().numpy().tobytes(), dtype=outfit_amd._abi.RESULT_DTYPE)
-    if multi:  # the gathered table holds this rank's records at its offset
-        mine = out_all[(state["step"] - 1) & 1][rank * n_obj:(rank + 1) * n_obj]
-        assert bytes(mine.cpu().numpy().tobytes()) == res.tobytes(), "gathered records differ from the local ones"
+        # EVERY rank checks the WHOLE gathered table of the last timed step: rank r's rows must hash to the checksum
+        # rank r computed of its own local records (exchanged with an all_gather), in the partition's order and counts
+        import zlib
+        mine = zlib.crc32(res.tobytes()) & 0xFFFFFFFF
+        sums = torch.zeros(world, dtype=torch.int64, device=gather_dev)
+        dist.all_gather_into_tensor(sums, torch.tensor([mine], dtype=torch.int64, device=gather_dev))
+        sums = [int(x) for x in sums.cpu()]
+        bad = []
+        for r in range(world):
+            rows = gathered[r * n_max: r * n_max + counts[r]]
+            if (zlib.crc32(rows.tobytes()) & 0xFFFFFFFF) != sums[r]:
+                bad.append(r)
+        assert not bad, f"rank {rank}: gathered records of rank(s) {bad} differ from what those ranks computed"
+        assert gathered[rank * n_max: rank * n_max + n_obj].tobytes() == res.tobytes()
+        gather_check = {"ranks_verified_by_every_rank": world, "records": int(sum(counts)), "crc32_per_rank": sums}
     n_ok = int((res["status"] == 0).sum())
 
     if rank == 0:
-        total_objects = world * n_obj
+        total_objects = sum(counts)
         value = total_objects * args.steps / elapsed
         # dominant kernel and its roofline (algorithmic bytes, SURVEY §8d / DESIGN.md)
         # ... among the kernels of the critical path: K0, K1 and the general correction kernel run on side
@@ -320,7 +476,7 @@ def main():
         if dom:
             total_ms, launches = ktimes[dom]
             avg_ms = total_ms / launches
-            units = n_obj * args.steps / launches          # objects one launch processes
+            units = n_obj * args.steps / launches          # objects one launch processes (rank 0's shard)
             achieved = units * bytes_per_obj / (avg_ms * 1e-3) / 1e9
             # HBM bytes of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
             # separate runs; profiles/), scaled to one launch; null when no profile matches
@@ -389,15 +545,28 @@ def main():
         line = {
             "metric": "objects/s full Gauss IOD (20 obs, 100 triplets/obj)",
             "value": value, "unit": "objects/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{n_obj} synthetic objects per GPU x 20 obs, 100 triplets each "
-                                   "(BASELINE configs[2] shape; synthetic DE440-layout table resident in HBM)",
-                       "objects_per_gpu": n_obj, "obs_per_object": n_obs / n_obj, "triplets_per_object": 100,
+            "math_mode": mode_names[head_mode],
+            "config": {"workload": (f"{n_obj} synthetic objects per GPU x 20 obs, 100 triplets each "
+                                    "(BASELINE configs[2] shape; synthetic DE440-layout table resident in HBM)")
+                       if args.scaling == "weak" else
+                       (f"{total_objects} synthetic objects x 20 obs, 100 triplets each, split over {world} GPU(s) "
+                        "(BASELINE configs[3]; synthetic DE440-layout table resident in HBM)"),
+                       "objects_per_gpu": counts, "obs_per_object": n_obs / n_obj, "triplets_per_object": 100,
                        "n_noise_realizations": 0, "orbits_found_rank0": n_ok,
+                       "math_mode": mode_names[head_mode] + " (OUTFIT_MATH_GLIBC: sin/cos/sinh/cosh with glibc 2.35's bits — "
+                                    "the reference-faithful mode and the library's default)" if head_mode == outfit_amd.MATH_GLIBC
+                       else mode_names[head_mode],
                        "parallelism": f"objects sharded over {world} GPU(s); RCCL all_gather of 96-B results, overlapped with the next step"},
             "roofline": roof,
         }
+        if modes is not None:
+            line["math_modes"] = modes
+            if "parity_vs_libm" in modes:
+                line["parity_vs_libm"] = modes["parity_vs_libm"]
+        if gather_check is not None:
+            line["gather_check"] = gather_check
         if lsq is not None:
             ms = 1e3 * lsq["elapsed"] / args.steps
             line["fit_lsq"] = {

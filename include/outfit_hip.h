@@ -22,8 +22,9 @@
  *     (outfit_hip_last_error() has the text). Per-trajectory failures are
  *     DATA (status/cause in outfit_gauss_result_t), never a call failure
  *     (mirrors obs_dataset_api.rs:63-68,159-171);
- *   - blocking entry points are re-entrant; a session is owned by one host
- *     thread at a time.
+ *   - blocking entry points are re-entrant and may run concurrently from several host
+ *     threads (each call owns its session, streams and scratch); a session is owned by
+ *     one host thread at a time.
  */
 #ifndef OUTFIT_HIP_H
 #define OUTFIT_HIP_H
@@ -34,7 +35,7 @@
 extern "C" {
 #endif
 
-#define OUTFIT_HIP_ABI_VERSION 5
+#define OUTFIT_HIP_ABI_VERSION 6
 
 /* ---- whole-call return codes --------------------------------------------- */
 #define OUTFIT_OK                 0
@@ -182,19 +183,33 @@ int  outfit_hip_iod_params_validate(const outfit_iod_params_t *p);
  * (direction cosines gauss.rs:488-502, cold starts prelim_elliptic.rs / prelim_hyperbolic.rs, the rotations of
  * orb_elem.rs:58-226). The reference calls the platform libm there, so its own results depend on that libm; the
  * loop amplifies a last-place difference to ~1e-10.
- *   OUTFIT_MATH_CORRECTLY_ROUNDED (default): every such function correctly rounded — platform independent;
- *       against a glibc run of the reference ~0.8 % of the orbits move by more than 1e-12 rad.
- *   OUTFIT_MATH_GLIBC: sin, cos, sinh, cosh return the bits of glibc 2.35 on x86-64 (restated, device/glibcmath.hpp);
- *       acos, log, atan2 stay correctly rounded (glibc's differ from that for 7e-4 / 2e-4 / 9e-4 of arguments).
+ *   OUTFIT_MATH_GLIBC (default): sin, cos, sinh, cosh return the bits of glibc 2.35 on x86-64 (restated,
+ *       device/glibcmath.hpp) — what the reference computes on the platform its known answers were recorded on;
+ *       acos, log, atan2 are correctly rounded (glibc's differ from that for 7e-4 / 2e-4 / 9e-4 of arguments).
  *       Measured against the reference's arithmetic on glibc: integer outputs identical, no orbit beyond
- *       1e-10 AU / 1e-12 rad (tests/test_gpu_glibc_mode.py).
- * Process-wide; read when a session is created (sessions keep the mode they were created with) and at the start
- * of every blocking call. The initial value comes from the environment variable OUTFIT_MATH_MODE ("glibc" / "cr").
+ *       1e-10 AU, 3 of 652 670 beyond 1e-12 rad (2-7e-12; tests/test_gpu_glibc_mode.py).
+ *   OUTFIT_MATH_CORRECTLY_ROUNDED: every such function correctly rounded — platform independent (what a reference
+ *       built against another libm would be compared with); against a glibc run of the reference ~0.8 % of the
+ *       orbits move by more than 1e-12 rad.
+ * The mode is a property of a CALL (outfit_hip_call_options_t below) or of a session (fixed at creation); the
+ * process-wide value set here is only the default for calls that do not name one. Its initial value comes from
+ * the environment variable OUTFIT_MATH_MODE ("glibc" / "cr"), else OUTFIT_MATH_GLIBC.
  * The differential corrector (fit_lsq) evaluates all its functions correctly rounded in both modes. */
+#define OUTFIT_MATH_DEFAULT           (-1) /* in call options: the process-wide default at the time of the call */
 #define OUTFIT_MATH_CORRECTLY_ROUNDED 0
 #define OUTFIT_MATH_GLIBC             1
 int outfit_hip_set_math_mode(int mode); /* 0 or OUTFIT_ERR_INVALID_PARAM */
 int outfit_hip_get_math_mode(void);
+
+/* Per-call options (ABI v6). Everything a call depends on besides its arguments lives here, so that concurrent
+ * callers with different settings do not meet in process-wide state. `struct_size` = sizeof the caller's struct:
+ * later versions append fields. NULL options = all defaults. */
+typedef struct outfit_hip_call_options {
+  uint32_t struct_size;
+  int32_t  math_mode;   /* OUTFIT_MATH_DEFAULT, OUTFIT_MATH_CORRECTLY_ROUNDED or OUTFIT_MATH_GLIBC */
+  uint64_t reserved[3]; /* zero */
+} outfit_hip_call_options_t;
+void outfit_hip_call_options_default(outfit_hip_call_options_t *o);
 
 /* ---- blocking drop-in entry point ------------------------------------------
  * Replaces the body of fit_full_iod / fit_full_iod_parallel after prepare_iod
@@ -206,6 +221,15 @@ int outfit_hip_fit_full_iod(const outfit_iod_params_t *params,
                             const outfit_ephem_t      *ephem /* nullable */,
                             int n_devices,
                             outfit_gauss_result_t     *out);
+/* The same with explicit options (nullable). Safe to call from several host threads at once, with different
+ * parameters and modes: every call owns its session, streams and scratch (tests/test_gpu_reentrancy.py; the
+ * reference's analogue is parallel == sequential, tests/test_gauss_iod.rs:170-190). */
+int outfit_hip_fit_full_iod_ex(const outfit_iod_params_t *params,
+                               const outfit_obs_batch_t  *batch,
+                               const outfit_ephem_t      *ephem /* nullable */,
+                               int n_devices,
+                               const outfit_hip_call_options_t *options /* nullable */,
+                               outfit_gauss_result_t     *out);
 
 /* ---- resident-session API (one device) --------------------------------------
  * Same computation with inputs kept in HBM between runs; what the blocking
@@ -219,6 +243,12 @@ int outfit_hip_session_create(const outfit_iod_params_t *params,
                               const outfit_ephem_t      *ephem /* nullable */,
                               int device,
                               outfit_hip_session_t     **out_session);
+int outfit_hip_session_create_ex(const outfit_iod_params_t *params,
+                                 const outfit_obs_batch_t  *batch,
+                                 const outfit_ephem_t      *ephem /* nullable */,
+                                 int device,
+                                 const outfit_hip_call_options_t *options /* nullable */,
+                                 outfit_hip_session_t     **out_session);
 /* Enqueue every kernel of the path; d_out (device memory, n_traj records) may be
  * NULL to use the session's own result buffer. Asynchronous w.r.t. the host. */
 int outfit_hip_session_run(outfit_hip_session_t *s, void *stream, void *d_out);
@@ -369,6 +399,15 @@ int outfit_hip_fit_lsq(const outfit_iod_params_t     *iod_params,
                        int n_devices,
                        outfit_lsq_result_t           *out /* n_traj */,
                        outfit_obs_fit_t              *obs_fit /* nullable, n_obs */);
+int outfit_hip_fit_lsq_ex(const outfit_iod_params_t     *iod_params,
+                          const outfit_diffcor_config_t *config,
+                          const outfit_obs_batch_t      *batch,
+                          const outfit_ephem_t          *ephem /* nullable */,
+                          const outfit_gauss_result_t   *initial_orbits /* nullable, n_traj */,
+                          int n_devices,
+                          const outfit_hip_call_options_t *options /* nullable */,
+                          outfit_lsq_result_t           *out /* n_traj */,
+                          outfit_obs_fit_t              *obs_fit /* nullable, n_obs */);
 
 /* Session form: the corrector runs on the session's resident observations. With
  * `initial_orbits` NULL the seeds are the records the last outfit_hip_session_run wrote (its
@@ -455,7 +494,9 @@ int outfit_hip_prelim_kepuni(uint64_t n, const double *problems /* 6n */, double
 /* Device memory freed by sessions and blocking calls is kept per device for the next call of a similar shape
  * (hipMalloc/hipFree of the candidate scratch cost ~10 ms per 100 k-object call); this returns it to the driver.
  * The environment variable OUTFIT_NO_CACHE=1 disables the cache; OUTFIT_CACHE_LIMIT_MB bounds what one device may hold
- * (default 65536 = 64 GiB; blocks beyond it are freed as before). */
+ * (default 16384 = 16 GiB; blocks beyond it are freed as before). Parked blocks are invisible to other allocators of the
+ * process (torch, RCCL): call this before handing the device to them. OUTFIT_CACHE_POISON=1 (debugging) fills every
+ * block handed out with 0xFF bytes. */
 int outfit_hip_trim_cache(void);
 const char *outfit_hip_last_error(void); /* thread-local, never NULL */
 int         outfit_hip_abi_version(void);

@@ -44,9 +44,16 @@ struct InvalidOrbit { std::string what; };
 using TrajError = std::variant<NoFeasibleTriplets, NoViableOrbit, InvalidConversion, InvalidOrbit>;
 
 // ---- math mode (include/outfit_hip.h OUTFIT_MATH_*): which bits sin/cos/sinh/cosh return where the reference calls
-// the platform libm. CorrectlyRounded (default) is platform independent; Glibc reproduces a glibc 2.35 host.
-enum class MathMode : int { CorrectlyRounded = OUTFIT_MATH_CORRECTLY_ROUNDED, Glibc = OUTFIT_MATH_GLIBC };
-inline void set_math_mode(MathMode m) {
+// the platform libm. Glibc (the library's default) reproduces a glibc 2.35 / x86-64 host — the platform the reference's
+// known answers were recorded on; CorrectlyRounded is platform independent. `Default` = the process-wide default.
+enum class MathMode : int { Default = OUTFIT_MATH_DEFAULT, CorrectlyRounded = OUTFIT_MATH_CORRECTLY_ROUNDED, Glibc = OUTFIT_MATH_GLIBC };
+// Per-call options (outfit_hip_call_options_t): what a call depends on besides its arguments. Calls with different
+// options may run concurrently from several host threads.
+struct CallOptions : outfit_hip_call_options_t {
+  CallOptions() { outfit_hip_call_options_default(this); }
+  explicit CallOptions(MathMode m) { outfit_hip_call_options_default(this); math_mode = static_cast<int>(m); }
+};
+inline void set_math_mode(MathMode m) {  // the process-wide default only
   if (outfit_hip_set_math_mode(static_cast<int>(m)) != OUTFIT_OK) throw InvalidIODParameter(outfit_hip_last_error());
 }
 inline MathMode math_mode() { return static_cast<MathMode>(outfit_hip_get_math_mode()); }
@@ -186,7 +193,8 @@ class FitIOD {
   // fit_full_iod (obs_dataset_api.rs:145-207) after prepare_iod. `noise_z` (optional): per trajectory, in
   // map order, max_triplets * n_noise_realizations * 6 standard normals.
   static FullOrbitResult fit_full_iod(const ObsDataset& ds, const JPLEphem& jpl, const IODParams& params,
-                                      const std::vector<double>* noise_z = nullptr, int n_devices = 0) {
+                                      const std::vector<double>* noise_z = nullptr, int n_devices = 0,
+                                      const CallOptions& options = CallOptions()) {
     if (outfit_hip_iod_params_validate(&params) != OUTFIT_OK) throw InvalidIODParameter(outfit_hip_last_error());
     Flat f = flatten(ds);
     outfit_obs_batch_t b = f.batch();
@@ -194,7 +202,7 @@ class FitIOD {
     outfit_ephem_t e{};
     if (!jpl.empty()) e = ephem(jpl);
     std::vector<outfit_gauss_result_t> out(f.ids.size());
-    const int rc = outfit_hip_fit_full_iod(&params, &b, jpl.empty() ? nullptr : &e, n_devices, out.data());
+    const int rc = outfit_hip_fit_full_iod_ex(&params, &b, jpl.empty() ? nullptr : &e, n_devices, &options, out.data());
     if (rc == OUTFIT_ERR_INVALID_PARAM) throw InvalidIODParameter(outfit_hip_last_error());
     if (rc == OUTFIT_ERR_INVALID_BATCH) throw InvalidBatch(outfit_hip_last_error());
     if (rc != OUTFIT_OK) throw DeviceError(outfit_hip_last_error());

@@ -9,6 +9,6 @@ from .api import (  # noqa: F401
     device_normals, observer_positions, lsq_record_to_result, Ephemeris, EphemerisFileError, GaussResult, IODGauss, IODParams, IODParamsBuilder, IODSession, InvalidBatch,
     InvalidConversion, InvalidIODParameter, InvalidOrbit, NoFeasibleTriplets, NoViableOrbit, ObsBatch,
     OrbitalElements, OutfitError, fit_full_iod, fit_full_iod_records, fit_iod, propagate_universal,
-    SolverType, MATH_CORRECTLY_ROUNDED, MATH_GLIBC, set_math_mode, get_math_mode, math_mode,
+    SolverType, MATH_DEFAULT, MATH_CORRECTLY_ROUNDED, MATH_GLIBC, set_math_mode, get_math_mode, math_mode,
 )
 from ._lib import NativeLibraryError, build_native  # noqa: F401

@@ -7,7 +7,7 @@ src/initial_orbit_determination/obs_dataset_api.rs:145-296).
 """
 import ctypes as C
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 OUTFIT_OK = 0
 OUTFIT_ERR_INVALID_PARAM = -1
@@ -144,6 +144,11 @@ OBS_REJECTED = 1
 OBS_FORCED_OUT = 2
 NOISE_HOST = 0
 NOISE_DEVICE = 1
+
+
+class CallOptionsC(C.Structure):
+    """outfit_hip_call_options_t (ABI v6): per-call settings; math_mode -1 = the process-wide default."""
+    _fields_ = [("struct_size", C.c_uint32), ("math_mode", C.c_int32), ("reserved", C.c_uint64 * 3)]
 
 
 class SolverTypeC(C.Structure):

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 import subprocess
 
-from ._abi import (ABI_VERSION, DeHeaderC, DiffCorConfigC, EphemC, GaussResultC, IODParamsC, LsqResultC, ObsBatchC,
+from ._abi import (ABI_VERSION, CallOptionsC, DeHeaderC, DiffCorConfigC, EphemC, GaussResultC, IODParamsC, LsqResultC, ObsBatchC,
                    ObsFitC, SolverTypeC)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -65,6 +65,12 @@ def lib():
                                           C.c_int, C.POINTER(GaussResultC)]
     L.outfit_hip_session_create.argtypes = [C.POINTER(IODParamsC), C.POINTER(ObsBatchC), C.POINTER(EphemC),
                                             C.c_int, C.POINTER(vp)]
+    L.outfit_hip_call_options_default.argtypes = [C.POINTER(CallOptionsC)]
+    L.outfit_hip_call_options_default.restype = None
+    L.outfit_hip_fit_full_iod_ex.argtypes = [C.POINTER(IODParamsC), C.POINTER(ObsBatchC), C.POINTER(EphemC),
+                                             C.c_int, C.POINTER(CallOptionsC), C.POINTER(GaussResultC)]
+    L.outfit_hip_session_create_ex.argtypes = [C.POINTER(IODParamsC), C.POINTER(ObsBatchC), C.POINTER(EphemC),
+                                               C.c_int, C.POINTER(CallOptionsC), C.POINTER(vp)]
     L.outfit_hip_session_run.argtypes = [vp, vp, vp]
     L.outfit_hip_session_results.argtypes = [vp, C.POINTER(GaussResultC)]
     L.outfit_hip_session_check.argtypes = [vp]
@@ -96,6 +102,9 @@ def lib():
     L.outfit_hip_fit_lsq.argtypes = [C.POINTER(IODParamsC), C.POINTER(DiffCorConfigC), C.POINTER(ObsBatchC),
                                      C.POINTER(EphemC), C.POINTER(GaussResultC), C.c_int,
                                      C.POINTER(LsqResultC), C.POINTER(ObsFitC)]
+    L.outfit_hip_fit_lsq_ex.argtypes = [C.POINTER(IODParamsC), C.POINTER(DiffCorConfigC), C.POINTER(ObsBatchC),
+                                        C.POINTER(EphemC), C.POINTER(GaussResultC), C.c_int, C.POINTER(CallOptionsC),
+                                        C.POINTER(LsqResultC), C.POINTER(ObsFitC)]
     L.outfit_hip_session_run_lsq.argtypes = [vp, C.POINTER(DiffCorConfigC), C.POINTER(GaussResultC), vp]
     L.outfit_hip_session_lsq_results.argtypes = [vp, C.POINTER(LsqResultC), C.POINTER(ObsFitC)]
     L.outfit_hip_ephem_open.argtypes = [C.c_char_p, C.POINTER(vp)]
@@ -120,6 +129,7 @@ EXPORTED_SYMBOLS = [
     "outfit_hip_selftest_division", "outfit_hip_selftest_crmath", "outfit_hip_crmath_eval", "outfit_hip_selftest_aberth", "outfit_hip_device_normals", "outfit_hip_observer_positions", "outfit_hip_diffcor_config_default", "outfit_hip_diffcor_config_validate",
     "outfit_hip_fit_lsq", "outfit_hip_session_run_lsq", "outfit_hip_session_lsq_results",
     "outfit_hip_solver_type_default", "outfit_hip_propagate_universal_ex", "outfit_hip_trim_cache", "outfit_hip_calibration_stream", "outfit_hip_prelim_kepuni", "outfit_hip_set_math_mode", "outfit_hip_get_math_mode",
+    "outfit_hip_call_options_default", "outfit_hip_fit_full_iod_ex", "outfit_hip_session_create_ex", "outfit_hip_fit_lsq_ex",
     "outfit_hip_ephem_open", "outfit_hip_ephem_header", "outfit_hip_ephem_view", "outfit_hip_ephem_close",
 ]
 

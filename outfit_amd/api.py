@@ -17,7 +17,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from . import _abi
-from ._abi import (DeHeaderC, DiffCorConfigC, EphemC, GaussResultC, IODParamsC, LSQ_DTYPE, LsqResultC, OBS_FIT_DTYPE,
+from ._abi import (CallOptionsC, DeHeaderC, DiffCorConfigC, EphemC, GaussResultC, IODParamsC, LSQ_DTYPE, LsqResultC, OBS_FIT_DTYPE,
                    ObsBatchC, ObsFitC, RESULT_DTYPE)
 from ._lib import NativeLibraryError, last_error, lib
 
@@ -334,12 +334,23 @@ def record_to_result(rec, batch=None, traj_index=None, params=None):
 
 
 # ----------------------------------------------------------------------------- math mode
-MATH_CORRECTLY_ROUNDED, MATH_GLIBC = 0, 1
+MATH_DEFAULT, MATH_CORRECTLY_ROUNDED, MATH_GLIBC = -1, 0, 1
+
+
+def _options(math_mode):
+    """outfit_hip_call_options_t for one call; None = all defaults (NULL pointer)."""
+    if math_mode is None:
+        return None
+    o = CallOptionsC()
+    lib().outfit_hip_call_options_default(C.byref(o))
+    o.math_mode = int(math_mode)
+    return C.byref(o)
 
 
 def set_math_mode(mode):
-    """Process-wide OUTFIT_MATH_* (include/outfit_hip.h): which bits sin/cos/sinh/cosh return in the functions that
-    feed the correction loop. Sessions keep the mode they were created with."""
+    """The process-wide DEFAULT of OUTFIT_MATH_* (include/outfit_hip.h): which bits sin/cos/sinh/cosh return in the
+    functions that feed the correction loop. Calls and sessions that name their mode (`math_mode=`) never read it;
+    sessions keep the mode they were created with."""
     rc = lib().outfit_hip_set_math_mode(int(mode))
     if rc != 0:
         _raise_rc(rc)
@@ -364,23 +375,24 @@ class math_mode:
 
 
 # ----------------------------------------------------------------------------- entry points
-def fit_full_iod_records(batch, ephem, params, n_devices=0):
-    """The blocking C-ABI call; returns the raw records (numpy structured array)."""
+def fit_full_iod_records(batch, ephem, params, n_devices=0, math_mode=None):
+    """The blocking C-ABI call; returns the raw records (numpy structured array). `math_mode`: MATH_* for this
+    call (outfit_hip_call_options_t), None = the process-wide default."""
     L = lib()
     pc, bc = params.as_c(), batch.as_c()
     ec = ephem.as_c() if ephem is not None else None
     out = np.empty(max(batch.n_traj, 1), dtype=RESULT_DTYPE)   # the records land in the array that is returned
-    rc = L.outfit_hip_fit_full_iod(C.byref(pc), C.byref(bc), C.byref(ec) if ec is not None else None,
-                                   n_devices, out.ctypes.data_as(C.POINTER(GaussResultC)))
+    rc = L.outfit_hip_fit_full_iod_ex(C.byref(pc), C.byref(bc), C.byref(ec) if ec is not None else None,
+                                      n_devices, _options(math_mode), out.ctypes.data_as(C.POINTER(GaussResultC)))
     if rc != 0:
         _raise_rc(rc)
     return out[:batch.n_traj]
 
 
-def fit_full_iod(batch, ephem, params, n_devices=0):
+def fit_full_iod(batch, ephem, params, n_devices=0, math_mode=None):
     """`FitIOD::fit_full_iod` after `prepare_iod`: {traj_id: FitOrbitResult | OutfitError}
     (`FullOrbitResult`, constants.rs:195). Per-trajectory failures are values, not raises."""
-    recs = fit_full_iod_records(batch, ephem, params, n_devices)
+    recs = fit_full_iod_records(batch, ephem, params, n_devices, math_mode)
     return {tid: record_to_result(recs[i], batch, i, params) for i, tid in enumerate(batch.traj_ids)}
 
 
@@ -400,7 +412,7 @@ def fit_iod(batch, traj_id, ephem, params):
 class IODSession:
     """Inputs resident in HBM; `run()` enqueues the kernels of the whole path on a stream."""
 
-    def __init__(self, batch, ephem, params, device=0):
+    def __init__(self, batch, ephem, params, device=0, math_mode=None):
         self._L = lib()
         self.n_traj = batch.n_traj
         self.n_obs = int(batch.traj_offset[-1]) if batch.n_traj else 0
@@ -408,8 +420,9 @@ class IODSession:
         pc, bc = params.as_c(), batch.as_c()
         ec = ephem.as_c() if ephem is not None else None
         h = C.c_void_p()
-        rc = self._L.outfit_hip_session_create(C.byref(pc), C.byref(bc),
-                                               C.byref(ec) if ec is not None else None, device, C.byref(h))
+        rc = self._L.outfit_hip_session_create_ex(C.byref(pc), C.byref(bc),
+                                                  C.byref(ec) if ec is not None else None, device,
+                                                  _options(math_mode), C.byref(h))
         if rc != 0:
             _raise_rc(rc)
         self._h = h
@@ -560,16 +573,16 @@ def _initial_c(initial, n):
     return (GaussResultC * max(n, 1)).from_buffer_copy(a.tobytes() if n else bytes(96))
 
 
-def fit_lsq_records(batch, ephem, iod_params, diff_cor_config, initial_orbits=None, n_devices=0):
-    """The blocking C-ABI call `outfit_hip_fit_lsq`; returns (records, per-observation fit data)."""
+def fit_lsq_records(batch, ephem, iod_params, diff_cor_config, initial_orbits=None, n_devices=0, math_mode=None):
+    """The blocking C-ABI call `outfit_hip_fit_lsq_ex`; returns (records, per-observation fit data)."""
     L = lib()
     pc, cc, bc = iod_params.as_c(), diff_cor_config.as_c(), batch.as_c()
     ec = ephem.as_c() if ephem is not None else None
     n, n_obs = batch.n_traj, int(batch.traj_offset[-1]) if batch.n_traj else 0
     out = (LsqResultC * max(n, 1))()
     fit = (ObsFitC * max(n_obs, 1))()
-    rc = L.outfit_hip_fit_lsq(C.byref(pc), C.byref(cc), C.byref(bc), C.byref(ec) if ec is not None else None,
-                              _initial_c(initial_orbits, n), n_devices, out, fit)
+    rc = L.outfit_hip_fit_lsq_ex(C.byref(pc), C.byref(cc), C.byref(bc), C.byref(ec) if ec is not None else None,
+                                 _initial_c(initial_orbits, n), n_devices, _options(math_mode), out, fit)
     if rc != 0:
         _raise_rc(rc)
     return (np.frombuffer(out, dtype=LSQ_DTYPE)[:n].copy(), np.frombuffer(fit, dtype=OBS_FIT_DTYPE)[:n_obs].copy())

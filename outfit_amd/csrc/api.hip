@@ -28,17 +28,32 @@ namespace {
 
 thread_local std::string g_last_error;
 
-// process-wide math mode (include/outfit_hip.h); -1 = not yet initialised from the environment
+// process-wide DEFAULT math mode (include/outfit_hip.h); -1 = not yet initialised from the environment. A call or a
+// session that names its mode (outfit_hip_call_options_t) never reads it.
 std::atomic<int> g_math_mode{-1};
 int current_math_mode() {
   int m = g_math_mode.load();
   if (m < 0) {
     const char* e = std::getenv("OUTFIT_MATH_MODE");
-    m = (e && (std::string(e) == "glibc" || std::string(e) == "1")) ? OUTFIT_MATH_GLIBC : OUTFIT_MATH_CORRECTLY_ROUNDED;
+    m = (e && (std::string(e) == "cr" || std::string(e) == "0")) ? OUTFIT_MATH_CORRECTLY_ROUNDED : OUTFIT_MATH_GLIBC;
     int expected = -1;
     if (!g_math_mode.compare_exchange_strong(expected, m)) m = expected;
   }
   return m;
+}
+// the mode one call runs in: what its options name, else the process-wide default at this moment
+int resolve_math_mode(const outfit_hip_call_options_t* o, int* out) {
+  if (!o || o->math_mode == OUTFIT_MATH_DEFAULT) { *out = current_math_mode(); return OUTFIT_OK; }
+  if (o->struct_size < sizeof(outfit_hip_call_options_t)) {
+    g_last_error = "call options: struct_size is smaller than this library's outfit_hip_call_options_t";
+    return OUTFIT_ERR_INVALID_PARAM;
+  }
+  if (o->math_mode != OUTFIT_MATH_CORRECTLY_ROUNDED && o->math_mode != OUTFIT_MATH_GLIBC) {
+    g_last_error = "call options: math_mode must be OUTFIT_MATH_DEFAULT, _CORRECTLY_ROUNDED or _GLIBC";
+    return OUTFIT_ERR_INVALID_PARAM;
+  }
+  *out = o->math_mode;
+  return OUTFIT_OK;
 }
 
 int fail(int code, const std::string& msg) {
@@ -89,7 +104,8 @@ unsigned saturate_u32(uint64_t v) {
 // device and handed to the next request of a similar size (never more than 2x + 1 MiB larger than asked), so a host
 // that calls repeatedly with batches of one shape allocates once. Owners synchronise their streams before
 // releasing (outfit_hip_session::free_all); contents are never assumed to be zero. outfit_hip_trim_cache() returns
-// everything to the driver; OUTFIT_NO_CACHE=1 disables the cache.
+// everything to the driver (call it before handing the device to another allocator — torch, RCCL — in the same
+// process: parked blocks are invisible to them); OUTFIT_NO_CACHE=1 disables the cache, OUTFIT_CACHE_LIMIT_MB bounds it.
 // A session's three streams and 18 events: creating them costs ~10 ms and destroying them ~9 ms (measured), so
 // they are parked per device like the memory blocks.
 struct StreamSet {
@@ -104,8 +120,11 @@ struct DeviceCache {
   size_t parked[64] = {};  // bytes held per device; a host that keeps changing batch shapes must not grow this for ever
   size_t limit = [] {
     const char* e = std::getenv("OUTFIT_CACHE_LIMIT_MB");
-    return (size_t)(e ? std::max(0ll, std::atoll(e)) : 65536ll) << 20;   // default 64 GiB of the 288 GB device
+    return (size_t)(e ? std::max(0ll, std::atoll(e)) : 16384ll) << 20;   // default 16 GiB: the scratch of one 10^6-object session
   }();
+  // debugging aid (OUTFIT_CACHE_POISON=1): every block handed out is first filled with 0xFF bytes (NaN doubles, huge
+  // indices), recycled or fresh, so that a kernel reading a column before its upload has landed cannot go unnoticed
+  bool poison = std::getenv("OUTFIT_CACHE_POISON") != nullptr;
   hipError_t get_streams(StreamSet* out) {
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -116,11 +135,11 @@ struct DeviceCache {
     StreamSet ss;
     for (auto& st : ss.stream) {
       hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-      if (e != hipSuccess) return e;
+      if (e != hipSuccess) { destroy_streams(ss); return e; }
     }
     for (auto& ev : ss.event) {
       hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-      if (e != hipSuccess) return e;
+      if (e != hipSuccess) { destroy_streams(ss); return e; }
     }
     ss.valid = true;
     *out = ss;
@@ -142,6 +161,13 @@ struct DeviceCache {
   }
   bool disabled = std::getenv("OUTFIT_NO_CACHE") != nullptr;
   hipError_t get(size_t bytes, void** out, size_t* cap) {
+    const hipError_t e = get_block(bytes, out, cap);
+    if (e != hipSuccess || !poison) return e;
+    hipError_t p = hipMemset(*out, 0xFF, *cap);
+    if (p == hipSuccess) p = hipDeviceSynchronize();
+    return p;
+  }
+  hipError_t get_block(size_t bytes, void** out, size_t* cap) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!disabled && dev >= 0 && dev < 64) {
@@ -266,8 +292,9 @@ struct outfit_hip_session {
   std::vector<uint64_t> perm;
   // Streamed blocking call (outfit_hip_fit_full_iod): only traj_offset and mjd are uploaded when the session is built;
   // the other columns follow in two groups while kernels that do not need them yet are already running
-  // (group 1 = ra, dec, obs_helio_equ: before K1's direction cosines and K2a; group 2 = sigma_ra, sigma_dec,
-  // obs_geo_ecl, the Chebyshev table: before K1's observer positions and K2c). See session_run.
+  // (group 1 = ra, dec, obs_helio_equ — and sigma_ra, sigma_dec when noisy realisations are drawn: before K1's
+  // direction cosines and K2a; group 2 = sigma_ra, sigma_dec otherwise, obs_geo_ecl, the Chebyshev table: before K1's
+  // observer positions and K2c). See session_run.
   struct Deferred { DevBuf<double>* d; const double* src; size_t rows; unsigned width; int group; bool use_perm; };
   std::vector<Deferred> deferred;
   bool streaming = false;
@@ -282,12 +309,12 @@ struct outfit_hip_session {
   hipStream_t k0_stream = nullptr;   // triplet selection, ahead of the candidate kernels (and of the previous run's tail)
   hipEvent_t ev_k3[2] = {nullptr, nullptr};  // last consumer of triplet buffer b has finished
   bool k3_recorded[2] = {false, false};
-  hipEvent_t ev_unit_free[2] = {nullptr, nullptr};  // last K2a reading unit buffer b has finished
+  hipEvent_t ev_unit_free[2] = {nullptr, nullptr};  // the last reader of unit buffer b (K2a, both correction kernels) has finished
   bool unit_free_recorded[2] = {false, false};
   unsigned long long chunk_seq = 0, run_seq = 0;
   hipEvent_t ev_start = nullptr, ev_prepass = nullptr, ev_fast = nullptr, ev_general = nullptr, ev_unit = nullptr;
   hipEvent_t ev_sub[8] = {};
-  hipStream_t last_stream = nullptr;
+  hipStream_t last_stream = nullptr;  // informational only: never synchronised (it is the caller's handle)
   hipEvent_t ev_done = nullptr;  // recorded after the last kernel of every run / run_lsq, on the stream it went to
   bool done_recorded = false;
   bool profiling = false;
@@ -325,6 +352,13 @@ struct outfit_hip_session {
 };
 
 namespace {
+
+// Wait for the last run / run_lsq. The stream it went to is the CALLER's handle and may no longer exist (a torch
+// stream of a finished step): the wait goes through the session's own event, recorded behind the last kernel.
+hipError_t wait_last_run(outfit_hip_session* s) {
+  if (s->ev_done && s->done_recorded) return hipEventSynchronize(s->ev_done);
+  return s->own_stream ? hipStreamSynchronize(s->own_stream) : hipSuccess;
+}
 
 int check_batch(const outfit_iod_params_t* params, const outfit_obs_batch_t* b, const outfit_ephem_t* eph) {
   if (!b) return fail(OUTFIT_ERR_INVALID_BATCH, "batch is NULL");
@@ -460,8 +494,7 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
     for (hipEvent_t& e : s->ev_sub) e = ss.event[k++];  // 1 + 2 + 2 + 5 + 8 = 18
   }
   g_trace.mark("  streams+events");
-  s->params = *params;
-  s->math_mode = current_math_mode();
+  s->params = *params;  // (s->math_mode was fixed by session_create)
   s->n_traj = b->n_traj;
   const uint64_t o0 = b->n_traj ? b->traj_offset[0] : 0;
   s->n_obs = b->n_traj ? b->traj_offset[b->n_traj] - o0 : 0;
@@ -483,8 +516,11 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
   TRY_RC(put_rows(s, s->mjd, n ? b->mjd_tt + o0 : nullptr, n, 1, 0));
   TRY_RC(put_rows(s, s->ra, n ? b->ra + o0 : nullptr, n, 1, 1));
   TRY_RC(put_rows(s, s->dec, n ? b->dec + o0 : nullptr, n, 1, 1));
-  TRY_RC(put_rows(s, s->sra, n ? b->sigma_ra + o0 : nullptr, n, 1, 2));
-  TRY_RC(put_rows(s, s->sdec, n ? b->sigma_dec + o0 : nullptr, n, 1, 2));
+  // the uncertainties are first read by K2c — unless there are noisy realisations: gather_angles (K2a) scales the
+  // draws with them (gauss.rs:355-364), so they must be resident before the first K2a slice (group 1)
+  const int sigma_group = params->n_noise_realizations > 0 ? 1 : 2;
+  TRY_RC(put_rows(s, s->sra, n ? b->sigma_ra + o0 : nullptr, n, 1, sigma_group));
+  TRY_RC(put_rows(s, s->sdec, n ? b->sigma_dec + o0 : nullptr, n, 1, sigma_group));
   const bool device_geometry = b->obs_body_fixed && b->mjd_ut1 && eph;
   if (device_geometry) HIP_TRY(s->helio.alloc(3 * n));
   else TRY_RC(put_rows(s, s->helio, n ? b->obs_helio_equ + 3 * o0 : nullptr, n, 3, 1));
@@ -642,7 +678,7 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
   // right after its upload group, while K0 / the candidate kernels already run (see `Deferred`).
   const bool streamed = s->streaming && !s->deferred.empty();
   auto launch_unit = [&]() -> int {
-    // the buffer's previous readers: the K2a launches of the run before the previous one
+    // the buffer's previous readers: the candidate kernels of the run before the previous one
     if (s->unit_free_recorded[ub]) HIP_TRY(hipStreamWaitEvent(s->k0_stream, s->ev_unit_free[ub], 0));
     pa.parts = outfit::kPrepassUnit;
     Stamp stamp(s, s->k0_stream, K_PREPASS);
@@ -731,8 +767,6 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
       Stamp stamp(s, st, K_ROOTS);
       HIP_TRY(outfit::launch_gauss_roots(ra, st));
     }
-    HIP_TRY(hipEventRecord(s->ev_unit_free[ub], st));  // last K2a of this run so far: unit[ub] may be rewritten after it
-    s->unit_free_recorded[ub] = true;
     const outfit::CorrectArgs ca{ci, w, s->gp, s->queue.p};
     {
       Stamp stamp(s, st, K_CORRECT_FAST);
@@ -778,6 +812,10 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
     HIP_TRY(hipEventRecord(s->ev_k3[tb], st));
     s->k3_recorded[tb] = true;
   }
+  // unit[ub] is read by K2a and, through load_geometry, by both correction kernels (the general one on aux, joined
+  // into `st` before the slow-list RMS pass): only now may the direction-cosine prepass of run N+2 rewrite it
+  HIP_TRY(hipEventRecord(s->ev_unit_free[ub], st));
+  s->unit_free_recorded[ub] = true;
   HIP_TRY(hipEventRecord(s->ev_done, st));
   s->done_recorded = true;
   return OUTFIT_OK;
@@ -985,17 +1023,30 @@ int outfit_hip_device_count(void) {
 }  // extern "C"
 namespace {
 int session_create(const outfit_iod_params_t* params, const outfit_obs_batch_t* batch, const outfit_ephem_t* ephem,
-                   int device, bool streaming, outfit_hip_session_t** out);
+                   int device, bool streaming, int math_mode, outfit_hip_session_t** out);
 }
 extern "C" {
+void outfit_hip_call_options_default(outfit_hip_call_options_t* o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof *o);
+  o->struct_size = (uint32_t)sizeof *o;
+  o->math_mode = OUTFIT_MATH_DEFAULT;
+}
+int outfit_hip_session_create_ex(const outfit_iod_params_t* params, const outfit_obs_batch_t* batch,
+                                 const outfit_ephem_t* ephem, int device, const outfit_hip_call_options_t* options,
+                                 outfit_hip_session_t** out) {
+  int mode = 0;
+  TRY_RC(resolve_math_mode(options, &mode));
+  return session_create(params, batch, ephem, device, /*streaming=*/false, mode, out);
+}
 int outfit_hip_session_create(const outfit_iod_params_t* params, const outfit_obs_batch_t* batch,
                               const outfit_ephem_t* ephem, int device, outfit_hip_session_t** out) {
-  return session_create(params, batch, ephem, device, /*streaming=*/false, out);
+  return outfit_hip_session_create_ex(params, batch, ephem, device, nullptr, out);
 }
 }  // extern "C"
 namespace {
 int session_create(const outfit_iod_params_t* params, const outfit_obs_batch_t* batch, const outfit_ephem_t* ephem,
-                   int device, bool streaming, outfit_hip_session_t** out) {
+                   int device, bool streaming, int math_mode, outfit_hip_session_t** out) {
   if (!out) return fail(OUTFIT_ERR_BAD_HANDLE, "out_session is NULL");
   *out = nullptr;
   TRY_RC(outfit_hip_iod_params_validate(params));
@@ -1007,6 +1058,7 @@ int session_create(const outfit_iod_params_t* params, const outfit_obs_batch_t* 
   auto* s = new outfit_hip_session();
   s->device = device;
   s->streaming = streaming;
+  s->math_mode = math_mode;
   const int rc = session_build(s, params, batch, ephem);
   if (rc != OUTFIT_OK) {
     s->free_all();
@@ -1028,7 +1080,7 @@ int outfit_hip_session_run(outfit_hip_session_t* s, void* stream, void* d_out) {
 int outfit_hip_session_results(outfit_hip_session_t* s, outfit_gauss_result_t* out) {
   if (!s || !out) return fail(OUTFIT_ERR_BAD_HANDLE, "session or out is NULL");
   HIP_TRY(hipSetDevice(s->device));
-  HIP_TRY(hipStreamSynchronize(s->last_stream ? s->last_stream : s->own_stream));
+  HIP_TRY(wait_last_run(s));
   int flag = 0;
   HIP_TRY(hipMemcpy(&flag, s->error_flag.p, sizeof(int), hipMemcpyDeviceToHost));
   if (flag) return fail(OUTFIT_ERR_EPHEM_RANGE, "an observation epoch lies outside the ephemeris table");
@@ -1046,7 +1098,7 @@ int outfit_hip_trim_cache(void) {
 int outfit_hip_session_check(outfit_hip_session_t* s) {
   if (!s) return fail(OUTFIT_ERR_BAD_HANDLE, "session is NULL");
   HIP_TRY(hipSetDevice(s->device));
-  HIP_TRY(hipStreamSynchronize(s->last_stream ? s->last_stream : s->own_stream));
+  HIP_TRY(wait_last_run(s));
   int flag = 0;
   HIP_TRY(hipMemcpy(&flag, s->error_flag.p, sizeof(int), hipMemcpyDeviceToHost));
   if (flag) return fail(OUTFIT_ERR_EPHEM_RANGE, "an observation epoch lies outside the ephemeris table");
@@ -1089,13 +1141,22 @@ void outfit_hip_session_destroy(outfit_hip_session_t* s) {
 
 int outfit_hip_fit_full_iod(const outfit_iod_params_t* params, const outfit_obs_batch_t* batch,
                             const outfit_ephem_t* ephem, int n_devices, outfit_gauss_result_t* out) {
+  return outfit_hip_fit_full_iod_ex(params, batch, ephem, n_devices, nullptr, out);
+}
+
+int outfit_hip_fit_full_iod_ex(const outfit_iod_params_t* params, const outfit_obs_batch_t* batch,
+                               const outfit_ephem_t* ephem, int n_devices, const outfit_hip_call_options_t* options,
+                               outfit_gauss_result_t* out) {
   TRY_RC(outfit_hip_iod_params_validate(params));
   TRY_RC(check_batch(params, batch, ephem));
   if (!out && batch->n_traj) return fail(OUTFIT_ERR_INVALID_BATCH, "out is NULL");
+  int mode = 0;
+  TRY_RC(resolve_math_mode(options, &mode));  // once per call: every shard runs in the same mode
+  static const bool streamed_upload = std::getenv("OUTFIT_NO_STREAMED_UPLOAD") == nullptr;
   return run_sharded(params, batch, n_devices, [&](int d, const outfit_obs_batch_t& sub, uint64_t t0) {
     outfit_hip_session_t* s = nullptr;
     g_trace.mark("(start)");
-    int r = session_create(params, &sub, ephem, d, /*streaming=*/std::getenv("OUTFIT_NO_STREAMED_UPLOAD") == nullptr, &s);
+    int r = session_create(params, &sub, ephem, d, /*streaming=*/streamed_upload, mode, &s);
     g_trace.mark("session_create");
     if (r == OUTFIT_OK) r = outfit_hip_session_run(s, nullptr, nullptr);
     g_trace.mark("session_run (enqueue)");
@@ -1139,7 +1200,7 @@ int outfit_hip_session_lsq_results(outfit_hip_session_t* s, outfit_lsq_result_t*
   if (!s || !out) return fail(OUTFIT_ERR_BAD_HANDLE, "session or out is NULL");
   if (!s->lsq_ran) return fail(OUTFIT_ERR_BAD_HANDLE, "outfit_hip_session_run_lsq has not been called");
   HIP_TRY(hipSetDevice(s->device));
-  HIP_TRY(hipStreamSynchronize(s->last_stream ? s->last_stream : s->own_stream));
+  HIP_TRY(wait_last_run(s));
   int flag = 0;
   HIP_TRY(hipMemcpy(&flag, s->error_flag.p, sizeof(int), hipMemcpyDeviceToHost));
   if (flag) return fail(OUTFIT_ERR_EPHEM_RANGE, "an observation epoch lies outside the ephemeris table");
@@ -1161,16 +1222,25 @@ int outfit_hip_fit_lsq(const outfit_iod_params_t* params, const outfit_diffcor_c
                        const outfit_obs_batch_t* batch, const outfit_ephem_t* ephem,
                        const outfit_gauss_result_t* initial, int n_devices, outfit_lsq_result_t* out,
                        outfit_obs_fit_t* obs_fit) {
+  return outfit_hip_fit_lsq_ex(params, config, batch, ephem, initial, n_devices, nullptr, out, obs_fit);
+}
+
+int outfit_hip_fit_lsq_ex(const outfit_iod_params_t* params, const outfit_diffcor_config_t* config,
+                          const outfit_obs_batch_t* batch, const outfit_ephem_t* ephem,
+                          const outfit_gauss_result_t* initial, int n_devices, const outfit_hip_call_options_t* options,
+                          outfit_lsq_result_t* out, outfit_obs_fit_t* obs_fit) {
   TRY_RC(outfit_hip_iod_params_validate(params));
   TRY_RC(outfit_hip_diffcor_config_validate(config));
   TRY_RC(check_batch(params, batch, ephem));
   if (!out && batch->n_traj) return fail(OUTFIT_ERR_INVALID_BATCH, "out is NULL");
+  int mode = 0;
+  TRY_RC(resolve_math_mode(options, &mode));
   return run_sharded(params, batch, n_devices, [&](int d, const outfit_obs_batch_t& sub, uint64_t t0) {
     // the IOD runs only when some trajectory has no usable seed (obs_dataset_api.rs:118-120, mod.rs:86)
     bool need_iod = initial == nullptr;
     for (uint64_t t = t0; t < t0 + sub.n_traj && !need_iod; ++t) need_iod = initial[t].status != OUTFIT_TRAJ_OK;
     outfit_hip_session_t* s = nullptr;
-    int r = outfit_hip_session_create(params, &sub, ephem, d, &s);
+    int r = session_create(params, &sub, ephem, d, /*streaming=*/false, mode, &s);
     if (r == OUTFIT_OK && need_iod) r = outfit_hip_session_run(s, nullptr, nullptr);
     if (r == OUTFIT_OK) r = outfit_hip_session_run_lsq(s, config, initial ? initial + t0 : nullptr, nullptr);
     if (r == OUTFIT_OK)

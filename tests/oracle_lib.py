@@ -191,6 +191,28 @@ def lib():
     return _lib
 
 
+class math_flags:
+    """Context manager for the oracle's elementary-function switches (oracle.h): `libm` = orc_use_libm (platform libm
+    everywhere: the reference-faithful mode on a glibc host), `glibc` = orc_math_glibc (sin/cos/sinh/cosh restated
+    from glibc 2.35, what the device's OUTFIT_MATH_GLIBC computes). None leaves a switch as it is; both are restored."""
+
+    def __init__(self, libm=None, glibc=None):
+        self.want = {"orc_use_libm": libm, "orc_math_glibc": glibc}
+
+    def __enter__(self):
+        self.prev = {}
+        for name, v in self.want.items():
+            f = C.c_int.in_dll(lib(), name)
+            self.prev[name] = f.value
+            if v is not None:
+                f.value = int(v)
+        return self
+
+    def __exit__(self, *exc):
+        for name, v in self.prev.items():
+            C.c_int.in_dll(lib(), name).value = v
+
+
 def default_params():
     p = IODParamsC()
     lib().orc_iod_params_default(C.byref(p))

@@ -68,16 +68,12 @@ def kat_cases():
 def test_hyperbolic_cold_start_kat_is_bit_exact_in_the_restated_mode(L):
     """kepler/params.rs:689-725 asserts equality with values recorded on glibc; the restated mode reproduces all three
     branches bit for bit WITHOUT calling the platform's sin/cos/sinh/cosh."""
-    flag = C.c_int.in_dll(L, "orc_math_glibc")
-    flag.value = 1
-    try:
+    with O.math_flags(libm=0, glibc=1):
         for c in kat_cases():
             kp = O.KeplerParams(dt=c["dt"], r0=c["r0"], sig0=c["sig0"], mu=c["mu"], alpha=c["alpha"], e0=c["e0"],
                                 convergency=c["convergency"], has_guess=0, psi_guess=0.0, max_iter_prelim_kepuni=20,
                                 kind=0)
             assert L.orc_prelim_kepuni(C.byref(kp)) == c["psi"], c
-    finally:
-        flag.value = 0
 
 
 @pytest.mark.gpu
@@ -109,7 +105,7 @@ def test_device_functions_equal_the_restatement_bit_for_bit(L):
 @pytest.mark.gpu
 def test_hyperbolic_cold_start_kat_through_the_abi_in_glibc_mode():
     """The device reproduces the reference's libm-dependent KAT bit for bit in OUTFIT_MATH_GLIBC, and to <= 4 ulp
-    (hyperbolic branch only) in the correctly-rounded default."""
+    (hyperbolic branch only) in the correctly-rounded mode."""
     import math
     import outfit_amd
     from outfit_amd import _lib
@@ -122,7 +118,8 @@ def test_hyperbolic_cold_start_kat_through_the_abi_in_glibc_mode():
     with outfit_amd.math_mode(outfit_amd.MATH_GLIBC):
         assert H.outfit_hip_prelim_kepuni(len(cases), prob.ctypes.data_as(dp), out.ctypes.data_as(dp)) == 0
     assert [float(x) for x in out] == [c["psi"] for c in cases]
-    assert H.outfit_hip_prelim_kepuni(len(cases), prob.ctypes.data_as(dp), out.ctypes.data_as(dp)) == 0
+    with outfit_amd.math_mode(outfit_amd.MATH_CORRECTLY_ROUNDED):
+        assert H.outfit_hip_prelim_kepuni(len(cases), prob.ctypes.data_as(dp), out.ctypes.data_as(dp)) == 0
     for got, c in zip(out, cases):
         if c["alpha"] > 0.0:
             assert abs(got - c["psi"]) <= 4 * math.ulp(c["psi"])

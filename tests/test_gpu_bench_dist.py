@@ -1,0 +1,56 @@
+"""The N > 1 code path of bench.py on the one GPU of the test box — needs an MI355X.
+
+`bench.py --force-dist` creates the RCCL process group (backend "nccl"), runs the step with the all_gather of the
+96-byte records on RCCL's stream (double-buffered, overlapped with the next step), the barrier / max-over-ranks
+timing and the whole-table check every rank makes (per-rank CRC exchanged with a second all_gather) — with
+world_size 1, which is what one GPU allows. The scaling curve itself (N = 1, 2, 4, 8) is the driver's to measure;
+the reference analogue of the gather is the Rayon reduce of per-thread maps (obs_dataset_api.rs:191-205).
+The child is a fresh interpreter: nothing has touched the GPU before the process group comes up.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*extra, port="29541"):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-side", "--no-lsq", "--no-modes", *extra],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-1500:]          # ONE JSON line on stdout (RCCL's banner must not land there)
+    return json.loads(lines[0])
+
+
+def test_rccl_gather_path_with_one_rank():
+    line = run_bench("--force-dist", "--objects", "20000")
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["scaling"] == "weak"
+    assert line["math_mode"] == "glibc"
+    assert line["config"]["orbits_found_rank0"] > 19000
+    gc = line["gather_check"]
+    assert gc["ranks_verified_by_every_rank"] == 1 and gc["records"] == 20000 and len(gc["crc32_per_rank"]) == 1
+    assert line["roofline"]["kernel"].startswith("k_") and line["value"] > 1e5
+
+
+def test_strong_scaling_shape_with_one_rank():
+    """--scaling strong: one global dataset of 25 000-object blocks split into contiguous ranges (configs[3] is
+    10^6 objects over 8 GPUs; here 50 000 over the one GPU, through the same code)."""
+    line = run_bench("--force-dist", "--scaling", "strong", "--total-objects", "50000", port="29542")
+    assert line["scaling"] == "strong" and line["config"]["objects_per_gpu"] == [50000]
+    assert line["gather_check"]["records"] == 50000
+    assert abs(line["value"] - 50000 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
+
+
+def test_world_size_must_match_gpus():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], env=env, capture_output=True,
+                       text=True, timeout=300, cwd=ROOT)
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)

@@ -32,13 +32,8 @@ def ang_diff(a, b):
 
 
 def oracle(params, batch, ephem, libm=0, glibc=0, threads=16):
-    L = O.lib()
-    f1, f2 = C.c_int.in_dll(L, "orc_use_libm"), C.c_int.in_dll(L, "orc_math_glibc")
-    f1.value, f2.value = libm, glibc
-    try:
+    with O.math_flags(libm=libm, glibc=glibc):
         rc, ref = O.fit_full_iod(params.as_c(), batch.as_c(), ephem.as_c(), n_threads=threads, hoist=1)
-    finally:
-        f1.value, f2.value = 0, 0
     assert rc == 0
     return ref
 
@@ -57,8 +52,7 @@ def distance(got, ref):
 
 
 def run_device(batch, ephem, params, mode):
-    with outfit_amd.math_mode(mode):
-        return outfit_amd.fit_full_iod_records(batch, ephem, params, n_devices=1)
+    return outfit_amd.fit_full_iod_records(batch, ephem, params, n_devices=1, math_mode=mode)  # per-call option
 
 
 CASES = [("configs[1]: 1000 objects", 1000, {}), ("slice of configs[2]: 12000 objects", 12000, {"seed": 424242}),
@@ -99,9 +93,15 @@ def test_sessions_keep_the_mode_they_were_created_with():
     ds = synth.make_dataset(300, ephem=eph_d)
     batch, ephem = outfit_amd.ObsBatch.from_dict(ds), outfit_amd.Ephemeris.from_dict(eph_d)
     params = synth.bench_params(outfit_amd.IODParams())
-    with outfit_amd.math_mode(outfit_amd.MATH_GLIBC):
-        s = outfit_amd.IODSession(batch, ephem, params)
-    assert outfit_amd.get_math_mode() == outfit_amd.MATH_CORRECTLY_ROUNDED
+    assert outfit_amd.get_math_mode() == outfit_amd.MATH_GLIBC          # the drop-in default (ABI v6)
+    with outfit_amd.math_mode(outfit_amd.MATH_CORRECTLY_ROUNDED):
+        s_cr = outfit_amd.IODSession(batch, ephem, params)                # takes the process default of this moment
+        s = outfit_amd.IODSession(batch, ephem, params, math_mode=outfit_amd.MATH_GLIBC)   # named: never reads it
+    assert outfit_amd.get_math_mode() == outfit_amd.MATH_GLIBC
+    s_cr.run()
+    a_cr = s_cr.results()
+    s_cr.close()
+    assert np.array_equal(a_cr, run_device(batch, ephem, params, outfit_amd.MATH_CORRECTLY_ROUNDED))
     s.run()
     a = s.results()
     s.close()
@@ -124,15 +124,9 @@ def test_noisy_realisations_and_the_corrector_in_glibc_mode():
     assert d["bit_identical"] == d["orbits"] > 300, d
     assert (got["best_realization"] > 0).sum() > 50      # noisy candidates do win
     cfg = outfit_amd.DifferentialCorrectionConfig(rms_divergence_ratio=10.0)
-    with outfit_amd.math_mode(outfit_amd.MATH_GLIBC):
-        lsq, fit = outfit_amd.fit_lsq_records(batch, ephem, params, cfg, got, n_devices=1)
-    L = O.lib()
-    flag = C.c_int.in_dll(L, "orc_math_glibc")
-    flag.value = 1
-    try:
+    lsq, fit = outfit_amd.fit_lsq_records(batch, ephem, params, cfg, got, n_devices=1, math_mode=outfit_amd.MATH_GLIBC)
+    with O.math_flags(libm=0, glibc=1):
         rc, lref, fref = O.fit_lsq(params.as_c(), cfg.as_c(), batch.as_c(), ephem.as_c(), got, n_threads=16)
-    finally:
-        flag.value = 0
     assert rc == 0
     for k in lsq.dtype.names:
         if k == "iod":

@@ -36,14 +36,9 @@ def big():
     return batch, ephem, params
 
 
-def oracle_iod(params, batch, ephem, libm=0, glibc=0):
-    L = O.lib()
-    f1, f2 = C.c_int.in_dll(L, "orc_use_libm"), C.c_int.in_dll(L, "orc_math_glibc")
-    f1.value, f2.value = libm, glibc
-    try:
+def oracle_iod(params, batch, ephem, libm=None, glibc=None):   # None: as conftest set it (= the device's default mode)
+    with O.math_flags(libm=libm, glibc=glibc):
         rc, ref = O.fit_full_iod(params.as_c(), batch.as_c(), ephem.as_c(), n_threads=16, hoist=1)
-    finally:
-        f1.value, f2.value = 0, 0
     assert rc == 0
     return ref
 
@@ -88,20 +83,19 @@ def test_config3_million_objects_iod(big):
     m = ref["status"] == 0
     assert np.array_equal(a["elem"][idx][m], ref["elem"][m]) and np.array_equal(a["epoch"][idx][m], ref["epoch"][m])
     assert (np.abs(a["rms"][idx][m] - ref["rms"][m]) <= 1e-9 * np.maximum(1.0, ref["rms"][m])).all()
-    # the same 10^6 objects in the glibc-faithful mode, against the restated oracle and the platform libm
-    with outfit_amd.math_mode(outfit_amd.MATH_GLIBC):
-        g = outfit_amd.fit_full_iod_records(batch, ephem, params, 1)
+    if host_is_glibc_x86_64():   # the default (glibc-faithful) mode against the platform libm = the reference's arithmetic here
+        refl = oracle_iod(params, sub, ephem, libm=1)
+        for k in INT_FIELDS:
+            assert np.array_equal(a[k][idx], refl[k]), k
+        d = np.abs(a["elem"][idx][m] - refl["elem"][m])
+        assert d[:, :2].max() <= 1e-10 and d[:, 2:].max() <= 1e-12
+    # the same 10^6 objects in the other (correctly-rounded) mode, against the oracle's default mode
+    g = outfit_amd.fit_full_iod_records(batch, ephem, params, 1, math_mode=outfit_amd.MATH_CORRECTLY_ROUNDED)
     assert np.array_equal(g["status"], a["status"])
-    refg = oracle_iod(params, sub, ephem, glibc=1)
+    refg = oracle_iod(params, sub, ephem, libm=0, glibc=0)
     for k in INT_FIELDS:
         assert np.array_equal(g[k][idx], refg[k]), k
     assert np.array_equal(g["elem"][idx][m], refg["elem"][m])
-    if host_is_glibc_x86_64():
-        refl = oracle_iod(params, sub, ephem, libm=1)
-        for k in INT_FIELDS:
-            assert np.array_equal(g[k][idx], refl[k]), k
-        d = np.abs(g["elem"][idx][m] - refl["elem"][m])
-        assert d[:, :2].max() <= 1e-10 and d[:, 2:].max() <= 1e-12
 
 
 def test_config4_million_objects_iod_then_lsq(big):

@@ -202,8 +202,9 @@ def test_equinoctial_to_keplerian_known_answer():
 def test_round2_host_entry_points_without_a_gpu(L):
     """Host-side behaviour of the ABI v5 additions (no compute): math mode, SolverType defaults and validation, cache."""
     from outfit_amd import _abi
-    assert L.outfit_hip_abi_version() == 5
+    assert L.outfit_hip_abi_version() == 6
     prev = L.outfit_hip_get_math_mode()
+    assert prev == _abi_const("OUTFIT_MATH_GLIBC")        # the drop-in default (unless OUTFIT_MATH_MODE=cr)
     try:
         assert L.outfit_hip_set_math_mode(_abi_const("OUTFIT_MATH_GLIBC")) == 0 and L.outfit_hip_get_math_mode() == 1
         assert L.outfit_hip_set_math_mode(7) == -1 and b"math mode" in L.outfit_hip_last_error()
@@ -229,4 +230,27 @@ def test_round2_host_entry_points_without_a_gpu(L):
 def _abi_const(name):
     import re
     src = open(os.path.join(ROOT, "include", "outfit_hip.h")).read()
-    return int(re.search(rf"#define {name}\s+(-?\d+)", src).group(1))
+    return int(re.search(rf"#define {name}\s+\(?(-?\d+)\)?", src).group(1))
+
+
+def test_call_options_abi_v6_without_a_gpu(L):
+    """outfit_hip_call_options_t: defaults, and rejection of a bad mode / a short struct before any device work."""
+    from outfit_amd import _abi
+    import outfit_amd
+    from outfit_amd import synth
+    o = _abi.CallOptionsC()
+    L.outfit_hip_call_options_default(C.byref(o))
+    assert o.struct_size == C.sizeof(_abi.CallOptionsC) == 32 and o.math_mode == _abi_const("OUTFIT_MATH_DEFAULT") == -1
+    ds = synth.make_dataset(4)
+    batch, ephem = outfit_amd.ObsBatch.from_dict(ds), outfit_amd.Ephemeris.from_dict(ds["ephem"])
+    params = synth.bench_params(outfit_amd.IODParams())
+    pc, bc, ec = params.as_c(), batch.as_c(), ephem.as_c()
+    out = (_abi.GaussResultC * 4)()
+    o.math_mode = 7
+    assert L.outfit_hip_fit_full_iod_ex(C.byref(pc), C.byref(bc), C.byref(ec), 1, C.byref(o), out) == -1
+    assert b"math_mode" in L.outfit_hip_last_error()
+    o.math_mode, o.struct_size = 1, 8
+    assert L.outfit_hip_fit_full_iod_ex(C.byref(pc), C.byref(bc), C.byref(ec), 1, C.byref(o), out) == -1
+    assert b"struct_size" in L.outfit_hip_last_error()
+    h = C.c_void_p()
+    assert L.outfit_hip_session_create_ex(C.byref(pc), C.byref(bc), C.byref(ec), 0, C.byref(o), C.byref(h)) == -1

@@ -8,7 +8,7 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-B="--no-cpu-baseline --no-side"
+B="--no-cpu-baseline --no-side --no-modes"
 # 1) kernel trace + stats
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/trace -- python3 $R/bench.py --steps 3 --warmup 1 $B "$@" > $R/$OUT/bench_trace.log 2>&1
 # 2) PMC passes (separate runs; FETCH_SIZE and WRITE_SIZE do not fit one pass)
