@@ -83,6 +83,10 @@ void orc_select_rms_interval(const double *mjd, size_t n_obs, const uint32_t idx
 /* debug counters: residual terms evaluated with the reference's pruning vs without it */
 uint64_t orc_dbg_rms_terms = 0, orc_dbg_rms_terms_full = 0;
 const double *orc_dbg_initial_best = 0; /* pruning study: a per-trajectory starting bound */
+/* near-tie census (tools/rms_near_tie_census.py): when set, [2 * traj + {0, 1}] receive the two smallest UNPRUNED
+ * candidate RMS values of the trajectory (the argmin key of trajectory.rs:523-526 and its runner-up); +inf when
+ * fewer candidates reach the RMS stage. NULL in normal use; results are not affected. */
+double *orc_dbg_two_smallest = 0;
 
 typedef struct {
   const outfit_iod_params_t *ip;
@@ -210,6 +214,7 @@ void orc_estimate_best_orbit(const outfit_iod_params_t *ip, const outfit_obs_bat
   }
 
   double best_rms = orc_dbg_initial_best ? orc_dbg_initial_best[traj] : INFINITY; /* study hook, NULL in normal use */
+  double census[2] = {INFINITY, INFINITY};
   int have_best = 0, last_error = 0;
   orc_gauss_result best;
   uint32_t attempts = 0, best_t = 0, best_r = 0;
@@ -255,6 +260,13 @@ void orc_estimate_best_orbit(const outfit_iod_params_t *ip, const outfit_obs_bat
         aborted = 1;
         break;
       }
+      if (orc_dbg_two_smallest) {
+        double full = rms_orbit_error(&c, base, n_obs, &g, &eq, INFINITY, hoist_buf);
+        if (isfinite(full)) {
+          if (full < census[0]) { census[1] = census[0]; census[0] = full; }
+          else if (full < census[1]) census[1] = full;
+        }
+      }
       double rms = rms_orbit_error(&c, base, n_obs, &g, &eq, best_rms, hoist_buf);
       if (!isfinite(rms)) { last_error = OUTFIT_CAUSE_NON_FINITE_SCORE; continue; }
       if (rms < best_rms) {
@@ -282,6 +294,7 @@ void orc_estimate_best_orbit(const outfit_iod_params_t *ip, const outfit_obs_bat
       out->cause = last_error;
     }
   }
+  if (orc_dbg_two_smallest) { orc_dbg_two_smallest[2 * traj] = census[0]; orc_dbg_two_smallest[2 * traj + 1] = census[1]; }
   free(hoist_buf);
   free(tidx);
 }

@@ -37,12 +37,14 @@ def test_generator_and_oracle_regression_fixture(ds64):
     """tests/golden/synth64_oracle.json pins the dataset bytes and the oracle's outputs bit for bit."""
     g = json.load(open(os.path.join(HERE, "golden", "synth64_oracle.json")))
     assert synth.dataset_sha256(ds64) == g["dataset_sha256"]
-    res = run(ds64, synth.bench_params(O.default_params()))
-    for r, e in zip(res, g["records"]):
-        for k in ("status", "cause", "stage", "kind", "attempts", "best_triplet", "n_triplets"):
-            assert int(r[k]) == e[k], k
-        assert float(r["epoch"]).hex() == e["epoch"] and float(r["rms"]).hex() == e["rms"]
-        assert [float(x).hex() for x in r["elem"]] == e["elem"]
+    for key, glibc in (("records", 0), ("records_glibc", 1)):
+        with O.math_flags(libm=0, glibc=glibc):
+            res = run(ds64, synth.bench_params(O.default_params()))
+        for r, e in zip(res, g[key]):
+            for k in ("status", "cause", "stage", "kind", "attempts", "best_triplet", "n_triplets"):
+                assert int(r[k]) == e[k], k
+            assert float(r["epoch"]).hex() == e["epoch"] and float(r["rms"]).hex() == e["rms"]
+            assert [float(x).hex() for x in r["elem"]] == e["elem"]
 
 
 def test_recovers_the_truth_orbits(ds64):
@@ -316,3 +318,42 @@ def test_reference_index_generator_cases_and_properties():
         hi = {(i, j, m) for i, j, m in itertools.combinations(range(n), 3)
               if ip.dt_min - 1e-12 <= t[m] - t[i] <= ip.dt_max_triplet + 1e-12}
         assert lo <= set(got) <= hi                                            # prop_matches_brute_force
+
+
+def test_near_tie_census_hook_and_committed_census():
+    """The argmin key of estimate_best_orbit (trajectory.rs:523-526) is the one output the device does not reproduce
+    bit for bit (device-vs-libm `rms` difference, median 6e-12 relative, worst seen 2.8e-7).
+    `orc_dbg_two_smallest` records the winner's and the runner-up's unpruned RMS; it must not change a result, the
+    winner must be the smallest value, and the committed census (tools/rms_near_tie_census.py, 2 x 10^5 + 5 x 10^4
+    objects) must show what the exposure claim in DESIGN.md rests on: no exact ties, and a gap distribution that is
+    flat near zero — P(gap < g) ~ 45 g to 75 g — so that the expected number of selection flips per object is
+    ~50 x E|d rms| ~ 50 x 1.5e-11 < 1e-9 (one in ~10^9 objects)."""
+    L = O.lib()
+    ds = synth.make_dataset(300, seed=4242)
+    batch = outfit_amd.ObsBatch.from_dict(ds)
+    ephem = outfit_amd.Ephemeris.from_dict(ds["ephem"])
+    params = synth.bench_params(O.default_params())
+    rc, plain = O.fit_full_iod(params, batch.as_c(), ephem.as_c(), 4, 1)
+    assert rc == 0
+    two = np.full(2 * 300, np.inf)
+    ptr = C.c_void_p.in_dll(L, "orc_dbg_two_smallest")
+    ptr.value = two.ctypes.data
+    try:
+        rc, hooked = O.fit_full_iod(params, batch.as_c(), ephem.as_c(), 4, 1)
+    finally:
+        ptr.value = None
+    assert rc == 0 and hooked.tobytes() == plain.tobytes()
+    two = two.reshape(300, 2)
+    ok = plain["status"] == 0
+    assert ok.sum() > 280 and np.array_equal(two[ok, 0], plain["rms"][ok]) and (two[ok, 1] >= two[ok, 0]).all()
+    gap = (two[ok, 1] - two[ok, 0]) / two[ok, 0]
+    assert (gap > 1e-9).all()
+    census = json.load(open(os.path.join(HERE, "..", "profiles", "round03_rms_near_tie_census.json")))
+    b = census["bench_workload"]
+    assert b["trajectories"] >= 100000 and b["with_a_runner_up"] > 0.99 * b["orbits"]
+    n = census["default_params_with_noise"]
+    assert n["trajectories"] >= 30000
+    for c in (b, n):
+        assert c["exact_ties"] == 0 and c["relative_gap_below"]["1e-08"] == 0
+        for edge in ("1e-07", "1e-06", "1e-05", "0.0001"):   # flat density: at most 100 g of the orbits below a gap g
+            assert c["relative_gap_below"][edge] <= max(1, 100 * float(edge) * c["with_a_runner_up"]), edge
