@@ -422,7 +422,7 @@ int outfit_hip_session_lsq_results(outfit_hip_session_t *s, outfit_lsq_result_t 
 
 /* ==== next row: legacy JPL DE binary reader -> outfit_ephem_t =================
  * Host-side only (no GPU needed). Replaces HorizonData::read_horizon_file
- * (jpl_ephem/horizon/horizon_data.rs:533-642) for what the path consumes: the header and the
+ * (jpl_ephem/horizon/horizon_data.rs:598-684) for what the path consumes: the header and the
  * Chebyshev segments of EMB, Moon and Sun (IPT rows 2, 9, 10). Little-endian files
  * (the "Linux" distribution the reference downloads, horizon_version.rs). */
 typedef struct outfit_de_header {       /* HorizonHeader (horizon_data.rs:130-160) + what sizes the file */
@@ -444,6 +444,13 @@ int  outfit_hip_ephem_open(const char *path, outfit_ephem_file_t **out);
 int  outfit_hip_ephem_header(const outfit_ephem_file_t *e, outfit_de_header_t *header);
 /* `view->coef` points into the handle and stays valid until outfit_hip_ephem_close. */
 int  outfit_hip_ephem_view(const outfit_ephem_file_t *e, outfit_ephem_t *view);
+/* `extract_body_records` (horizon_data.rs:468-491) for ANY IPT row (0..14) and one data block, read on demand: the
+ * block's n_sub HorizonRecords (each x[n_coeffs], y[n_coeffs], z[n_coeffs]; 2 / 1 axes for rows 11 / 14) into `out`,
+ * its [start_jd, end_jd] into jd_range (nullable). Returns the number of doubles written (> 0) or a negative code.
+ * Not needed by the path (which consumes rows 2, 9, 10 only): it lets the reference's record known answers for
+ * other bodies (horizon_data.rs:898-1003) be checked through this reader. */
+int  outfit_hip_ephem_body_record(const outfit_ephem_file_t *e, uint32_t ipt_row, uint64_t block,
+                                  double *jd_range /* [2], nullable */, double *out, uint64_t capacity);
 void outfit_hip_ephem_close(outfit_ephem_file_t *e);
 
 /* Observer::pvobs + helio_position for n observations: geocentric position in the ecliptic

@@ -151,7 +151,7 @@ struct JPLEphem {  // legacy-DE subset, layout of outfit_ephem_t; empty = use th
   std::uint32_t ncoef[3] = {13, 13, 11}, nsub[3] = {2, 8, 2};
   std::vector<double> coef;
   bool empty() const { return coef.empty(); }
-  // HorizonData::read_horizon_file (jpl_ephem/horizon/horizon_data.rs:533-642): a little-endian legacy-DE binary
+  // HorizonData::read_horizon_file (jpl_ephem/horizon/horizon_data.rs:598-684): a little-endian legacy-DE binary
   static JPLEphem from_file(const std::string& path) {
     outfit_ephem_file_t* h = nullptr;
     if (outfit_hip_ephem_open(path.c_str(), &h) != OUTFIT_OK) throw OutfitError(outfit_hip_last_error());

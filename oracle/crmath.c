@@ -194,6 +194,14 @@ void orc_sincos(double x, double *s, double *c) {
   if (orc_math_glibc && fabs(x) < 1048576.0) { *s = orc_glibc_sin(x); *c = orc_glibc_cos(x); return; }
   sincos_cr(x, s, c);
 }
+/* The Earth-rotation pre-pass (earthrot.c, row n2) evaluates its ~170 sin/cos per observation correctly rounded in
+ * BOTH math modes, like the corrector: its nutation series is a table summed in another order than the reference's
+ * hand-expanded text (agreement 1e-15, not bits), so glibc's last places would pin nothing there; the device does the
+ * same (device/earthrot.hpp). orc_use_libm = 1 still selects the platform libm. */
+void orc_sincos_prepass(double x, double *s, double *c) {
+  if (LIBM(1)) { *s = sin(x); *c = cos(x); return; }
+  sincos_cr(x, s, c);
+}
 double orc_sin(double x) { double s, c; orc_sincos(x, &s, &c); return s; }
 double orc_cos(double x) { double s, c; orc_sincos(x, &s, &c); return c; }
 

@@ -18,6 +18,10 @@
 #include "oracle.h"
 #include "nutation_table.h"
 
+/* correctly rounded in both math modes (crmath.c, orc_sincos_prepass) */
+static double er_sin(double x) { double s, c; orc_sincos_prepass(x, &s, &c); return s; }
+static double er_cos(double x) { double s, c; orc_sincos_prepass(x, &s, &c); return c; }
+
 #define T2000 51544.5
 #define RADEG (ORC_PI / 180.0)
 #define RADSEC (ORC_PI / 648000.0)
@@ -47,12 +51,12 @@ void orc_nutn80(double tjm, double *dpsi, double *deps) {
   for (int i = 0; i < NUT80_N_DPSI; ++i) {
     double a = 0.0;
     for (int j = 0; j < 5; ++j) a += (double)NUT80_DPSI_K[i][j] * arg[j];
-    sp += (NUT80_DPSI_A[i][0] + NUT80_DPSI_A[i][1] * t) * orc_sin(a);
+    sp += (NUT80_DPSI_A[i][0] + NUT80_DPSI_A[i][1] * t) * er_sin(a);
   }
   for (int i = 0; i < NUT80_N_DEPS; ++i) {
     double a = 0.0;
     for (int j = 0; j < 5; ++j) a += (double)NUT80_DEPS_K[i][j] * arg[j];
-    se += (NUT80_DEPS_A[i][0] + NUT80_DEPS_A[i][1] * t) * orc_cos(a);
+    se += (NUT80_DEPS_A[i][0] + NUT80_DEPS_A[i][1] * t) * er_cos(a);
   }
   *dpsi = sp * 1e-4;
   *deps = se * 1e-4;
@@ -61,7 +65,7 @@ void orc_nutn80(double tjm, double *dpsi, double *deps) {
 /* ref_system.rs:453-462: Rotation3::from_axis_angle about coordinate axis k (m[row][col]) */
 void orc_rotmt(double alpha, int k, double m[3][3]) {
   double s, c;
-  orc_sincos(alpha, &s, &c);
+  orc_sincos_prepass(alpha, &s, &c);
   memset(m, 0, 9 * sizeof(double));
   int a = (k + 1) % 3, b = (k + 2) % 3;
   m[k][k] = 1.0;
@@ -99,7 +103,7 @@ void orc_rnut80(double tjm, double m[3][3]) {
 double orc_equequ(double tjm) {
   double oblm = orc_obleq(tjm), dpsi, deps;
   orc_nutn80(tjm, &dpsi, &deps);
-  return RADSEC * dpsi * orc_cos(oblm);
+  return RADSEC * dpsi * er_cos(oblm);
 }
 
 /* earth_orientation.rs:561-592 */

@@ -56,6 +56,7 @@ double orc_glibc_cosh(double x);
 void   orc_glibc_compare_with_host(uint64_t n, uint64_t seed, uint64_t *counts /* [6] */);
 extern const double orc_aberth_cos_sin[8][2];
 void   orc_sincos(double x, double *s, double *c);
+void   orc_sincos_prepass(double x, double *s, double *c); /* earthrot.c: correctly rounded in both math modes */
 double orc_sin(double x);
 double orc_cos(double x);
 double orc_acos(double x);

@@ -110,6 +110,8 @@ def lib():
     L.outfit_hip_ephem_open.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.outfit_hip_ephem_header.argtypes = [vp, C.POINTER(DeHeaderC)]
     L.outfit_hip_ephem_view.argtypes = [vp, C.POINTER(EphemC)]
+    L.outfit_hip_ephem_body_record.argtypes = [vp, C.c_uint32, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                               C.c_uint64]
     L.outfit_hip_ephem_close.argtypes = [vp]
     L.outfit_hip_ephem_close.restype = None
     L.outfit_hip_calibration_stream.argtypes = [C.c_uint64, C.c_int]
@@ -130,7 +132,7 @@ EXPORTED_SYMBOLS = [
     "outfit_hip_fit_lsq", "outfit_hip_session_run_lsq", "outfit_hip_session_lsq_results",
     "outfit_hip_solver_type_default", "outfit_hip_propagate_universal_ex", "outfit_hip_trim_cache", "outfit_hip_calibration_stream", "outfit_hip_prelim_kepuni", "outfit_hip_set_math_mode", "outfit_hip_get_math_mode",
     "outfit_hip_call_options_default", "outfit_hip_fit_full_iod_ex", "outfit_hip_session_create_ex", "outfit_hip_fit_lsq_ex",
-    "outfit_hip_ephem_open", "outfit_hip_ephem_header", "outfit_hip_ephem_view", "outfit_hip_ephem_close",
+    "outfit_hip_ephem_open", "outfit_hip_ephem_header", "outfit_hip_ephem_view", "outfit_hip_ephem_close", "outfit_hip_ephem_body_record",
 ]
 
 

@@ -46,7 +46,7 @@ class HipRuntimeError(OutfitError):
 
 
 class EphemerisFileError(OutfitError):
-    """The DE file cannot be opened or parsed (the reference panics: horizon_data.rs:546-553)."""
+    """The DE file cannot be opened or parsed (the reference panics: horizon_data.rs:622-629)."""
 
 
 @dataclass
@@ -167,7 +167,7 @@ class Ephemeris:
 
     @classmethod
     def from_file(cls, path):
-        """`HorizonData::read_horizon_file` (horizon_data.rs:533-642) through `outfit_hip_ephem_open`: the
+        """`HorizonData::read_horizon_file` (horizon_data.rs:598-684) through `outfit_hip_ephem_open`: the
         EMB / Moon / Sun segments of a little-endian legacy-DE binary. Sets `.header` (dict)."""
         L = lib()
         h = C.c_void_p()
@@ -187,6 +187,28 @@ class Ephemeris:
                         "period_lenght": hd.period_length, "recsize": hd.recsize,
                         "earth_moon_mass_ratio": hd.earth_moon_mass_ratio, "ncon": hd.ncon, "n_blocks": hd.n_blocks}
             return e
+        finally:
+            L.outfit_hip_ephem_close(h)
+
+    @staticmethod
+    def body_records(path, ipt_row, block):
+        """`HorizonData.records[block][ipt_row]` through `outfit_hip_ephem_body_record`: (array [n_sub, axes, n_coeffs],
+        (start_jd, end_jd)) — any body of the file, not only the three the path consumes."""
+        L = lib()
+        h = C.c_void_p()
+        rc = L.outfit_hip_ephem_open(str(path).encode(), C.byref(h))
+        if rc != 0:
+            _raise_rc(rc)
+        try:
+            hd = DeHeaderC()
+            L.outfit_hip_ephem_header(h, C.byref(hd))
+            nc, ns = int(hd.ipt[ipt_row][1]), int(hd.ipt[ipt_row][2])
+            buf = np.empty(max(1, 3 * nc * ns))
+            jd = (C.c_double * 2)()
+            n = L.outfit_hip_ephem_body_record(h, ipt_row, block, jd, buf.ctypes.data_as(_dp), buf.size)
+            if n < 0:
+                _raise_rc(n)
+            return buf[:n].reshape(ns, n // (ns * nc), nc).copy(), (jd[0], jd[1])
         finally:
             L.outfit_hip_ephem_close(h)
 

@@ -600,7 +600,7 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
   HIP_TRY(s->dirS.alloc(9 * n_cand));
   HIP_TRY(s->roots.alloc((size_t)outfit::kRootSlots * n_cand));
   HIP_TRY(s->state.alloc(7 * n_cand));
-  HIP_TRY(s->queue.alloc(3));  // [0] fast kernel, [1] general kernel, [2] k_diffcor
+  HIP_TRY(s->queue.alloc(16));  // [0] fast kernel, [1] general kernel, [2] k_diffcor; [8..15] diagnostic builds
   HIP_TRY(s->psi0.alloc(2 * n_cand));
   HIP_TRY(s->slow_list.alloc(n_cand));
   HIP_TRY(s->slow_count.alloc(1));

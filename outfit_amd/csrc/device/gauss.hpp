@@ -350,6 +350,7 @@ template <bool kFast, bool kWarmOnly = kFast>
 __device__ __forceinline__ CorrStep correction_iteration(const Mat3& obs, const Mat3& S, const Mat3& Sinv,
                                                          double t_mid, double dt01, double dt21,
                                                          const GaussParams& P, CorrectionState& st) {
+  KSTAT(3);
   st.it += 1;
   const bool last = st.it >= P.newton_max_it;
   // An iteration is a pure function of (pos, vel, chi01, chi21, has01, has21). If it ends in a
@@ -374,6 +375,7 @@ __device__ __forceinline__ CorrStep correction_iteration(const Mat3& obs, const 
     const VelCorr vc = velocity_finish(sol, side ? r3 : r1, r2, st.vc.r2, dt);
     if (side) b = vc; else a = vc;
   }
+  KSTAT(4);
   if (!(a.ok && b.ok)) return rare;
   st.has01 = true; st.chi01 = a.chi;
   st.has21 = true; st.chi21 = b.chi;
@@ -388,7 +390,9 @@ __device__ __forceinline__ CorrStep correction_iteration(const Mat3& obs, const 
   const Vec3 c = {b.g * inv_f, -1.0, -a.g * inv_f};
   Mat3 np;
   double ne;
+  KSTAT(5);
   if (!position_and_epoch(obs, S, Sinv, t_mid, c, P.min_rho2_au, np, ne)) return skip;  // common
+  KSTAT(6);
   const Vec3 nr2 = column(np, 1);
   const EccControl ec = eccentricity_control(nr2, nv, P.max_perihelion_au, P.max_ecc);
   if (!ec.some || !ec.accepted) return kFast ? kCorrSlow : kCorrNone;

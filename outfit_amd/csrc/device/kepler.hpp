@@ -11,11 +11,26 @@
 // the results follow the Rust code to the last bit.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "crmath.hpp"
 #include "glibcmath.hpp"
 #include "fastdiv.hpp"
 
 namespace outfit {
+
+#ifdef OUTFIT_K2B_STATS  // diagnostic build: (wave passes, active lanes) at a few program points of the correction loop
+__device__ unsigned long long g_kstat[32];
+#define KSTAT(slot)                                                                 \
+  do {                                                                              \
+    const unsigned long long m__ = __ballot(true);                                  \
+    if (__lane_id() == (unsigned)__ffsll((long long)m__) - 1u) {                    \
+      atomicAdd(&g_kstat[2 * (slot)], 1ull);                                        \
+      atomicAdd(&g_kstat[2 * (slot) + 1], (unsigned long long)__popcll(m__));       \
+    }                                                                               \
+  } while (0)
+#else
+#define KSTAT(slot) do { } while (0)
+#endif
 
 constexpr double kPi = 3.14159265358979323846;
 constexpr double kTwoPi = 6.283185307179586476925286766559;  // constants.rs:31
@@ -64,10 +79,11 @@ __device__ __forceinline__ Stumpff s_funct(double psi, double alpha) {
     // term j divides by the integer constants (2j+1)(2j+2) and (2j+2)(2j+3): exact quotient
     // from the tabulated correctly-rounded reciprocal (fastdiv.hpp), same bits as `/`
     const bool fast = fdiv::in_window(beta);
-    auto term = [&](int j) -> bool {  // adds term j; true = the series has converged (or overflowed)
+    auto term = [&](int j, auto fast_tag) -> bool {  // adds term j; true = the series has converged (or overflowed)
+      KSTAT(1);
       const double d2 = fdiv::kSeries.d2[j], d3 = fdiv::kSeries.d3[j];
       double x2, x3;
-      if (fast) {
+      if (decltype(fast_tag)::value) {
         const double rc2 = fdiv::kSeries.r2[j], rc3 = fdiv::kSeries.r3[j];
         const double q2 = beta * rc2, q3 = beta * rc3;
         x2 = fma(fma(-q2, d2, beta), rc2, q2);
@@ -83,21 +99,48 @@ __device__ __forceinline__ Stumpff s_funct(double psi, double alpha) {
       const double a2 = fabs(t2), a3 = fabs(t3);
       return (a2 < tol && a3 < tol) || a2 > ovf || a3 > ovf;
     };
-    // The first terms are unrolled so that their four constants are literals: inside a rolled loop each
-    // term paid two scalar table loads (address arithmetic + memory latency) for six arithmetic
-    // instructions. The orbit-sized arguments of this path converge within 5-6 terms.
+    using yes = std::true_type;
+    using no = std::false_type;
+#ifndef OUTFIT_SFUNCT_PER_TERM_WINDOW
+    // The window test is hoisted out of the terms (one branch per evaluation instead of one per term: the compiler
+    // does not unswitch it, and each per-term branch cost ~8 scalar instructions of exec bookkeeping). Outside the
+    // window (beta == 0 for a parabolic alpha, or denormal) the plain divisions run, rolled: the same operations.
+    if (fast) {
+      // The first terms are unrolled so that their four constants are literals: inside a rolled loop each
+      // term paid two scalar table loads (address arithmetic + memory latency) for six arithmetic
+      // instructions. The orbit-sized arguments of this path converge within 5-6 terms.
+      constexpr int kUnrolled = 8;
+      bool done = false;
+#pragma unroll
+      for (int j = 1; j <= kUnrolled; ++j) {
+        if (!done) done = term(j, yes{});
+      }
+      if (!done) {
+#pragma unroll 1
+        for (int j = kUnrolled + 1; j <= 70; ++j) {
+          if (term(j, yes{})) break;
+        }
+      }
+    } else {
+#pragma unroll 1
+      for (int j = 1; j <= 70; ++j) {
+        if (term(j, no{})) break;
+      }
+    }
+#else
     constexpr int kUnrolled = 8;
     bool done = false;
 #pragma unroll
     for (int j = 1; j <= kUnrolled; ++j) {
-      if (!done) done = term(j);
+      if (!done) done = fast ? term(j, yes{}) : term(j, no{});
     }
     if (!done) {
 #pragma unroll 1
       for (int j = kUnrolled + 1; j <= 70; ++j) {
-        if (term(j)) break;
+        if (fast ? term(j, yes{}) : term(j, no{})) break;
       }
     }
+#endif
     return {1.0 + alpha * s2, psi + alpha * s3, s2, s3};
   }
   double rp = psi, rb = beta;
@@ -308,6 +351,7 @@ __device__ __forceinline__ KeplerSolution run_newton(const KeplerProblem& p, dou
   out.psi = psi;
   out.s = {1.0, 0.0, 0.0, 0.0};
   for (int it = 0; it < 50; ++it) {
+    KSTAT(0);
     if (!isfinite(psi)) { psi = 0.5; continue; }
     const Stumpff s = s_funct(psi, p.alpha);
     const double residual = p.r0 * s.s1 + p.sig0 * s.s2 + s.s3 - sqrt_mu * p.dt;
@@ -323,6 +367,7 @@ __device__ __forceinline__ KeplerSolution run_newton(const KeplerProblem& p, dou
       out.psi = psi; out.s = s; out.ok = true; break;
     }
     if (sa <= p.convergency * (1.0 + fabs(psi))) {
+      KSTAT(2);
       out.psi = psi; out.s = s_funct(psi, p.alpha); out.ok = true; break;
     }
   }

@@ -1,9 +1,9 @@
 // ephem_file.hip — host-side reader of a legacy JPL DE binary ("Horizons" little-endian file,
 // e.g. linux_p1550p2650.440) into the table the kernels consume (outfit_ephem_t).
 // SURVEY §8f row n3. Replaces HorizonData::read_horizon_file
-// (src/jpl_ephem/horizon/horizon_data.rs:533-642) with parse_ipt :284-305, read_ipt_13_14 :323-347,
-// compute_recsize :239-251, parse_all_blocks :422-460 and extract_body_records /
-// HorizonRecord::new (:362-392, horizon_records.rs:132-171) for the three bodies that
+// (src/jpl_ephem/horizon/horizon_data.rs:598-684) with parse_ipt :284-305, read_ipt_13_14 :382-405,
+// compute_recsize :239-251, parse_all_blocks :527-565 and extract_body_records /
+// HorizonRecord::new (:468-491, horizon_records.rs:132-171) for the three bodies that
 // HorizonData::ephemeris(Earth, Sun) reads (:810-849): IPT rows 2 (EMB), 9 (Moon), 10 (Sun).
 // No device code: pure file parsing, usable without a GPU.
 #include <cstdint>
@@ -21,6 +21,7 @@ int set_last_error(int code, const std::string& msg);  // api.hip
 struct outfit_ephem_file {
   outfit_de_header_t header{};
   std::vector<double> coef;  // n_blocks * sum_b 3*ncoef[b]*nsub[b], the packing of outfit_ephem_t
+  std::string path;          // for outfit_hip_ephem_body_record (any IPT row, read on demand)
 };
 
 namespace {
@@ -38,9 +39,9 @@ double le_f64(const unsigned char* p) {
 // horizon_data.rs:204-213
 unsigned dimension(unsigned i) { return i <= 10 ? 3u : (i == 11 ? 2u : (i <= 13 ? 3u : (i == 14 ? 1u : 0u))); }
 
-constexpr long kOffSS = 252 + 2400;        // after TTL (14*3 char6) and CNAM (400 char6): horizon_data.rs:557-571
-constexpr long kOffIpt = 2696;             // :585
-constexpr long kOff400thName = 2856;       // :332
+constexpr long kOffSS = 252 + 2400;        // after TTL (14*3 char6) and CNAM (400 char6): horizon_data.rs:612-637
+constexpr long kOffIpt = 2696;             // :646
+constexpr long kOff400thName = 2856;       // :391
 constexpr int kBodies[3] = {2, 9, 10};     // EMB, Moon, Sun (horizon_ids.rs / horizon_data.rs:810-849)
 
 }  // namespace
@@ -57,21 +58,21 @@ int outfit_hip_ephem_open(const char* path, outfit_ephem_file_t** out) {
     std::fclose(f);
     return outfit::set_last_error(OUTFIT_ERR_EPHEM_FILE, std::string(path) + ": " + m);
   };
-  unsigned char head[4096];  // the reference reads 1 << 12 bytes up front (:551-553)
+  unsigned char head[4096];  // the reference reads 1 << 12 bytes up front (:627-629)
   if (std::fread(head, 1, sizeof head, f) != sizeof head) return fail("shorter than the 4096-byte header");
   outfit_de_header_t h{};
   h.start_period = le_f64(head + kOffSS);
   h.end_period = le_f64(head + kOffSS + 8);
   h.period_length = le_f64(head + kOffSS + 16);
   h.ncon = (int32_t)le_u32(head + kOffSS + 24);
-  h.au_km = le_f64(head + kOffSS + 28);                    // skipped by the reference (:575-576)
+  h.au_km = le_f64(head + kOffSS + 28);                    // skipped by the reference (:641-642)
   h.earth_moon_mass_ratio = le_f64(head + kOffSS + 36);
   for (int i = 0; i < 36; ++i) h.ipt[i / 3][i % 3] = le_u32(head + kOffIpt + 4 * i);  // parse_ipt :284-305
   h.numde = le_u32(head + kOffIpt + 144);
   for (int c = 0; c < 3; ++c) h.ipt[12][c] = le_u32(head + kOffIpt + 148 + 4 * c);    // LPT
   // the header is untrusted input: bound everything that feeds an offset or a size before using it
   if (h.ncon < 0 || h.ncon > 10000) return fail("implausible NCON (not a little-endian DE file?)");
-  // IPT rows 13/14 follow the constant names beyond the 400th (read_ipt_13_14 :323-347). The reference keys
+  // IPT rows 13/14 follow the constant names beyond the 400th (read_ipt_13_14 :382-405). The reference keys
   // this on the DE version named by the caller (>= DE440); the file's own NUMDE is used here.
   if (h.numde >= 440 && h.ncon > 400) {
     const long off = kOff400thName + ((long)h.ncon - 400) * 6;
@@ -96,10 +97,11 @@ int outfit_hip_ephem_open(const char* path, outfit_ephem_file_t** out) {
   if (std::fseek(f, 0, SEEK_END) != 0) return fail("seek failed");
   const long size = std::ftell(f);
   if (size < (long)(2 * h.recsize)) return fail("no data records");
-  h.n_blocks = ((uint64_t)size - 2 * h.recsize) / h.recsize;  // parse_all_blocks :428-437
+  h.n_blocks = ((uint64_t)size - 2 * h.recsize) / h.recsize;  // parse_all_blocks :527-565
   if (h.n_blocks == 0) return fail("no data records");
   auto* e = new outfit_ephem_file();
   e->header = h;
+  e->path = path;
   e->coef.resize((size_t)h.n_blocks * per_block);
   std::vector<unsigned char> rec((size_t)h.recsize);
   if (std::fseek(f, (long)(2 * h.recsize), SEEK_SET) != 0) { delete e; return fail("seek failed"); }
@@ -142,6 +144,34 @@ int outfit_hip_ephem_view(const outfit_ephem_file_t* e, outfit_ephem_t* view) {
   view->n_blocks = h.n_blocks;
   view->coef = e->coef.data();
   return OUTFIT_OK;
+}
+
+// extract_body_records (horizon_data.rs:468-491) for ANY IPT row and one data block, read from the file on demand:
+// what `HorizonData.records[block][body]` holds — n_sub HorizonRecords of 3 x n_coeffs coefficients (x, y, z), in
+// that order — plus the block's [start_jd, end_jd]. Lets the reference's record known answers for bodies the path
+// does not consume (Mercury, Jupiter, Mars: horizon_data.rs:898-1003,1101-1140) be checked through this reader.
+int outfit_hip_ephem_body_record(const outfit_ephem_file_t* e, uint32_t ipt_row, uint64_t block, double* jd_range,
+                                 double* out, uint64_t capacity) {
+  if (!e || !out) return outfit::set_last_error(OUTFIT_ERR_BAD_HANDLE, "handle or out is NULL");
+  const outfit_de_header_t& h = e->header;
+  if (ipt_row >= 15 || block >= h.n_blocks) return outfit::set_last_error(OUTFIT_ERR_INVALID_BATCH, "IPT row or block out of range");
+  const uint32_t* r = h.ipt[ipt_row];
+  const uint64_t n = (uint64_t)dimension(ipt_row) * r[1] * r[2];
+  if (n == 0) return outfit::set_last_error(OUTFIT_ERR_INVALID_BATCH, "this IPT row holds no coefficients");
+  if (capacity < n) return outfit::set_last_error(OUTFIT_ERR_INVALID_BATCH, "out is too small for this body's record");
+  if (r[0] < 3 || (uint64_t)r[0] - 1 + n > h.recsize / 8)
+    return outfit::set_last_error(OUTFIT_ERR_EPHEM_FILE, "IPT row points outside the record");
+  FILE* f = std::fopen(e->path.c_str(), "rb");
+  if (!f) return outfit::set_last_error(OUTFIT_ERR_EPHEM_FILE, "cannot reopen " + e->path);
+  std::vector<unsigned char> rec((size_t)h.recsize);
+  const bool ok = std::fseek(f, (long)((2 + block) * h.recsize), SEEK_SET) == 0 &&
+                  std::fread(rec.data(), 1, rec.size(), f) == rec.size();
+  std::fclose(f);
+  if (!ok) return outfit::set_last_error(OUTFIT_ERR_EPHEM_FILE, e->path + ": truncated data record");
+  if (jd_range) { jd_range[0] = le_f64(rec.data()); jd_range[1] = le_f64(rec.data() + 8); }
+  const unsigned char* src = rec.data() + 8 * ((size_t)r[0] - 1);
+  for (uint64_t k = 0; k < n; ++k) out[k] = le_f64(src + 8 * k);
+  return (int)n;
 }
 
 void outfit_hip_ephem_close(outfit_ephem_file_t* e) { delete e; }

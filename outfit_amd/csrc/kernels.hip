@@ -22,6 +22,7 @@
 //
 // Compiled with -ffp-contract=off: the reference (Rust) never fuses a*b+c.
 #include <hip/hip_runtime.h>
+#include <cstdio>
 #include <cstdlib>
 #include "kernels.h"
 #include "device/ephem.hpp"
@@ -333,7 +334,10 @@ k_gauss_roots(RootsArgs a) {
 // precomputed cold-start values, and runs warm iterations until the loop ends (Some). Any
 // irregular event hands the candidate to the general kernel through the slow list.
 // ------------------------------------------------------------------------------
-constexpr unsigned kRefillThreshold = 16;  // idle lanes per wave before the queue is touched
+#ifndef OUTFIT_K2B_THRESHOLD
+#define OUTFIT_K2B_THRESHOLD 24  // measured (round 3, 100 000 objects): 8 -> 7.48 ms, 16 -> 6.64, 24 -> 6.50, 32 -> 6.57
+#endif
+constexpr unsigned kRefillThreshold = OUTFIT_K2B_THRESHOLD;  // idle lanes per wave before the queue is touched
 
 // wave-wide grab of the next queue entries for the lanes in need_mask
 __device__ __forceinline__ unsigned long long wave_grab(unsigned long long* queue, unsigned long long need_mask) {
@@ -359,12 +363,20 @@ k_gauss_correct_fast(CorrectArgs a) {
   bool exhausted = false;
   double t_mid = 0.0, dt01 = 0.0, dt21 = 0.0;
   CorrectionState st{};
+#ifdef OUTFIT_K2B_STATS  // diagnostic build only (tools/perf_k2b_stats.py): where a wave's time goes
+  unsigned long long st_trips = 0, st_refills = 0, st_active = 0, st_needy = 0, st_cyc_refill = 0;
+  const unsigned long long st_t0 = clock64();
+#endif
 
   for (;;) {
     const bool needy = (cand < 0) && !exhausted;
     const unsigned long long need_mask = __ballot(needy);
     const unsigned long long active_mask = __ballot(cand >= 0);
     if (need_mask && ((unsigned)__popcll(need_mask) >= kRefillThreshold || active_mask == 0ull)) {
+#ifdef OUTFIT_K2B_STATS
+      const unsigned long long st_r0 = clock64();
+      st_refills += 1; st_needy += (unsigned)__popcll(need_mask);
+#endif
       const unsigned long long my = wave_grab(a.queue, need_mask);
       if (needy) {
         if (my >= n) {
@@ -396,8 +408,14 @@ k_gauss_correct_fast(CorrectArgs a) {
           }
         }
       }
+#ifdef OUTFIT_K2B_STATS
+      st_cyc_refill += clock64() - st_r0;
+#endif
     }
     if (__ballot(cand >= 0) == 0ull && __ballot(!exhausted) == 0ull) break;
+#ifdef OUTFIT_K2B_STATS
+    st_trips += 1; st_active += (unsigned)__popcll(__ballot(cand >= 0));
+#endif
     if (cand < 0) continue;
 
     Mat3 S, Sinv, obs;
@@ -429,6 +447,13 @@ k_gauss_correct_fast(CorrectArgs a) {
       cand = -1;
     }
   }
+#ifdef OUTFIT_K2B_STATS
+  if (__lane_id() == 0) {  // a.queue[8..15]: waves, trips, refills, active lanes, needy lanes, cycles in refill, cycles
+    atomicAdd(a.queue + 8, 1ull); atomicAdd(a.queue + 9, st_trips); atomicAdd(a.queue + 10, st_refills);
+    atomicAdd(a.queue + 11, st_active); atomicAdd(a.queue + 12, st_needy); atomicAdd(a.queue + 13, st_cyc_refill);
+    atomicAdd(a.queue + 14, (unsigned long long)(clock64() - st_t0));
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------
@@ -593,19 +618,10 @@ __device__ __forceinline__ void select_rms_interval(const double* mjd, unsigned 
   i_end = e;
 }
 
-// kSlowList = false: every candidate of the chunk except those marked kFlagSlow (their state is
-// being produced concurrently by the general correction kernel); true: exactly the slow list.
+// One candidate of K2c. kSlowList = false skips the candidates marked kFlagSlow (their state is being produced
+// concurrently by the general correction kernel); true handles exactly those.
 template <bool kSlowList>
-__global__ void __launch_bounds__(256, 3)
-k_orbit_rms(RmsArgs a) {
-  const unsigned long long lid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long cid = lid;
-  if (kSlowList) {
-    if (lid >= *a.W.slow_count) return;
-    cid = a.W.slow_list[lid];
-  } else if (lid >= a.I.n_cand) {
-    return;
-  }
+__device__ __forceinline__ void rms_candidate(const RmsArgs& a, unsigned long long cid) {
   const unsigned f0 = a.W.flags[cid];
   if ((f0 & kFlagEmpty) || !(f0 & kFlagOk)) return;
   if (!kSlowList && (f0 & kFlagSlow)) return;
@@ -651,6 +667,22 @@ k_orbit_rms(RmsArgs a) {
   }
   a.W.sum[cid] = acc;
   a.W.flags[cid] = flags | (err ? kFlagRmsErr : 0u);
+}
+
+// kSlowList = false: every candidate of the chunk, one lane each. true: exactly the slow list — its length lives on
+// the device, so a modest grid strides over it (a grid sized for every candidate, whose lanes beyond the list return
+// at once, cost 0.16 ms of launch and wave scheduling per step for ~6 x 10^6 useful instructions).
+template <bool kSlowList>
+__global__ void __launch_bounds__(256, 3)
+k_orbit_rms(RmsArgs a) {
+  const unsigned long long lid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (!kSlowList) {
+    if (lid < a.I.n_cand) rms_candidate<false>(a, lid);
+    return;
+  }
+  const unsigned long long n_items = *a.W.slow_count;
+  for (unsigned long long i = lid; i < n_items; i += (unsigned long long)gridDim.x * blockDim.x)
+    rms_candidate<true>(a, a.W.slow_list[i]);
 }
 
 // The mapping BASELINE.json's north_star names — ONE WAVEFRONT PER CANDIDATE — for the RMS stage, as a measurement
@@ -1153,7 +1185,32 @@ hipError_t launch_gauss_correct_fast(const CorrectArgs& a, unsigned n_cu, hipStr
   const size_t lds = (size_t)27 * kFastBlock * sizeof(double);
   hipError_t e = hipMemsetAsync(a.queue, 0, sizeof(unsigned long long), s);
   if (e != hipSuccess) return e;
+#ifdef OUTFIT_K2B_STATS
+  e = hipMemsetAsync(a.queue + 8, 0, 8 * sizeof(unsigned long long), s);
+  if (e != hipSuccess) return e;
+  {
+    static const unsigned long long zero[32] = {};
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_kstat), zero, sizeof zero);
+  }
+#endif
   hipLaunchKernelGGL(k_gauss_correct_fast, dim3(grid), dim3(kFastBlock), lds, s, a);
+#ifdef OUTFIT_K2B_STATS
+  {
+    unsigned long long h[8] = {};
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h, a.queue + 8, sizeof h, hipMemcpyDeviceToHost);
+    if (h[0]) fprintf(stderr, "[k2b stats] waves %llu  trips/wave %.1f  refills/wave %.1f  active lanes/trip %.2f  needy lanes/refill %.2f  "
+                      "refill cycle share %.3f  cycles/wave %.3e\n", h[0], (double)h[1] / h[0], (double)h[2] / h[0],
+                      (double)h[3] / h[1], (double)h[4] / (h[2] ? h[2] : 1), (double)h[5] / h[6], (double)h[6] / h[0]);
+    unsigned long long k[32] = {};
+    (void)hipMemcpyFromSymbol(k, HIP_SYMBOL(g_kstat), sizeof k);
+    const char* names[7] = {"newton round", "series term", "re-evaluation", "iteration entry", "after both solves", "before position_and_epoch", "tail (ecc control ..)"};
+    for (int i = 0; i < 7; ++i)
+      fprintf(stderr, "[k2b stats]   %-28s wave passes/trip %7.3f   lanes/pass %5.2f\n", names[i], (double)k[2 * i] / h[1],
+              k[2 * i] ? (double)k[2 * i + 1] / k[2 * i] : 0.0);
+  }
+#endif
   return hipGetLastError();
 }
 hipError_t launch_gauss_correct(const CorrectArgs& a, unsigned n_cu, hipStream_t s) {
@@ -1171,9 +1228,9 @@ hipError_t launch_gauss_correct(const CorrectArgs& a, unsigned n_cu, hipStream_t
 hipError_t launch_orbit_rms(const RmsArgs& a, bool slow_list, hipStream_t s) {
   if (a.I.n_cand == 0) return hipSuccess;
   if (slow_list) {
-    // the list length lives on the device: the grid covers every candidate and the lanes beyond the list return at
-    // once (156 k waves for ~6 x 10^6 instructions of useful work at 10^7 candidates: 0.16 ms)
-    const unsigned grid = (unsigned)((a.I.n_cand + 255) / 256);
+    // the list length lives on the device: a grid of at most 8 workgroups per CU strides over it
+    const unsigned long long want = (a.I.n_cand + 255) / 256;
+    const unsigned grid = (unsigned)(want < 2048ull ? want : 2048ull);
     hipLaunchKernelGGL(k_orbit_rms<true>, dim3(grid), dim3(256), 0, s, a);
   } else {
     static const bool wave_per_candidate = std::getenv("OUTFIT_RMS_WAVE") != nullptr;  // measurement aid, see k_orbit_rms_wave

@@ -1,5 +1,5 @@
 """Writes a legacy-DE ("Horizons" binary, little-endian) file around a synthetic EMB/Moon/Sun table, for the
-reader tests. Layout as parsed by the reference (src/jpl_ephem/horizon/horizon_data.rs:284-347,533-642):
+reader tests. Layout as parsed by the reference (src/jpl_ephem/horizon/horizon_data.rs:284-405,598-684):
 record 1 = TTL, CNAM, SS, NCON, AU, EMRAT, IPT(12 rows), NUMDE, LPT[, extra constant names, IPT rows 13/14];
 record 2 = constant values; then one record per 32-day block: JD0, JD1, Chebyshev coefficients per body."""
 import struct

@@ -1,10 +1,23 @@
-"""Known answers that need the real DE440 file (src/jpl_ephem/horizon/horizon_data.rs:863-1173, transcribed into
-tests/golden/reference_kats_de440.json). They run when a little-endian DE440 binary (JPL `linux_p1550p2650.440`,
-~100 MB) is reachable — environment variable OUTFIT_DE440_FILE, or one of the conventional places below — and are
-skipped otherwise (no network in the build and test boxes). Host-only except the last test."""
+"""Known answers that need the real DE440 file — ALL of src/jpl_ephem/horizon/horizon_data.rs:863-1173
+(test_jpl_reader_from_horizon, test_get_record_from_horizon, test_get_record_index, test_interpolation_from_horizon,
+test_target_center_interpolation), transcribed into tests/golden/reference_kats_de440.json by
+tools/transcribe_de440_kats.py. They run when a little-endian DE440 binary (JPL `linux_p1550p2650.440`, ~100 MB)
+is reachable — environment variable OUTFIT_DE440_FILE, or one of the conventional places below — and are skipped
+otherwise (no network in the build and test boxes; README.md says how to point the driver at a file).
+
+What goes through which code:
+  * header, record count, the Mercury / Jupiter records      -> the product reader (outfit_hip_ephem_open /
+    outfit_hip_ephem_body_record) and the numpy restatement oracle/de_reader.py, both against the reference's values;
+  * record index / tau, Sun positions, Earth-Sun vectors     -> reader -> table -> oracle (C) AND reader -> table -> K1
+    on the device (outfit_hip_observer_positions, the kernel the hot path uses), bit for bit;
+  * velocities, accelerations, Mars                          -> oracle/de_reader.py `interpolate` / `ephemeris` on the
+    records the product reader returns (the hot path evaluates positions only: horizon_data.rs:810-849 with
+    compute_velocity = compute_acceleration = false).
+"""
 import ctypes as C
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -13,13 +26,23 @@ import oracle_lib as O
 import outfit_amd
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+import de_reader  # noqa: E402
+
 K = json.load(open(os.path.join(HERE, "golden", "reference_kats_de440.json")))
 CANDIDATES = [os.environ.get("OUTFIT_DE440_FILE", ""), os.path.join(HERE, "data", "linux_p1550p2650.440"),
               os.path.expanduser("~/.cache/outfit/jpl_ephem/jpl_horizon/DE440.bsp"),
               os.path.expanduser("~/.cache/outfit/linux_p1550p2650.440"), "/data/linux_p1550p2650.440"]
 DE440 = next((p for p in CANDIDATES if p and os.path.isfile(p)), None)
 pytestmark = pytest.mark.skipif(DE440 is None, reason="no DE440 file (set OUTFIT_DE440_FILE)")
-AU = 149597870.7
+
+
+def test_the_transcription_is_complete():
+    """(runs without the file too when selected explicitly) every assert_eq! of :863-1173 has its datum."""
+    assert K["header"]["n_records"] == 12556 and K["header"]["sum_of_bodies_per_record"] == 150672
+    assert len(K["first_record"]["record"]["x"]) == 14 and len(K["record_at_epoch"]["record"]["z"]) == 8
+    assert len(K["sun_wrt_ssb_km"]) == 3 and all(len(c["acceleration"]) == 3 for c in K["sun_wrt_ssb_km"])
+    assert [c["target"] for c in K["target_wrt_center_au"]] == ["Earth", "Mars", "Earth"]
 
 
 @pytest.fixture(scope="module")
@@ -27,50 +50,83 @@ def ephem():
     return outfit_amd.Ephemeris.from_file(DE440)
 
 
-def test_header_matches_the_reference(ephem):
+@pytest.fixture(scope="module")
+def hdr():
+    return de_reader.read(DE440)
+
+
+def test_header_matches_the_reference(ephem, hdr):
     h, want = ephem.header, K["header"]
     assert h["jpl_version"] == want["jpl_version"]
-    assert [list(r) for r in h["ipt"]] == want["ipt"]
-    assert h["start_period"] == want["start_period"] and h["end_period"] == want["end_period"]
-    assert ephem.block_days == want["period_lenght"] and ephem.emrat == want["earth_moon_mass_ratio"]
-    assert h["recsize"] == want["recsize"] and ephem.n_blocks == want["n_records"]
+    assert [list(r) for r in h["ipt"]] == want["ipt"] == [list(int(v) for v in r) for r in hdr["ipt"]]
+    assert h["start_period"] == want["start_period"] == hdr["jd_start"] and h["end_period"] == want["end_period"]
+    assert ephem.block_days == want["period_lenght"] and ephem.emrat == want["earth_moon_mass_ratio"] == hdr["emrat"]
+    assert h["recsize"] == want["recsize"] == hdr["recsize"] and ephem.n_blocks == want["n_records"] == hdr["n_blocks"]
     assert tuple(ephem.ncoef) == (13, 13, 11) and tuple(ephem.nsub) == (2, 8, 2)
+    # `records.iter().fold(0, |acc, x| acc + x.len())`: bodies with coefficients per block (12 for DE440) x blocks
+    assert sum(1 for r in want["ipt"] if r[1] and r[2]) * ephem.n_blocks == want["sum_of_bodies_per_record"]
+    assert ephem.coef.tobytes() == hdr["coef"].tobytes()          # product reader == numpy restatement, whole table
 
 
-def test_record_index_and_tau(ephem):
+def _check_record(case, block):
+    want = case["record"]
+    for reader in (outfit_amd.Ephemeris.body_records, de_reader.body_records):
+        recs, (j0, j1) = reader(DE440, case["ipt_row"], block)
+        sub = case.get("sub_interval")
+        if sub is None:
+            ns = recs.shape[0]
+            sub = int(min(np.floor(case["tau"] * ns), ns - 1.0))
+        assert (j0, j1) == (want["start_jd"], want["end_jd"])
+        for ax, name in enumerate("xyz"):
+            assert list(recs[sub][ax]) == want[name], (reader.__module__, name)
+
+
+def test_first_record_of_the_file(hdr):
+    _check_record(K["first_record"], 0)                        # records[0].get(&0)[0]: Mercury, :898-957
+
+
+def test_record_at_an_epoch(hdr):
+    c = K["record_at_epoch"]                                   # get_record_horizon(4, ..): Jupiter, :959-1004
+    nr, tau = de_reader.record_index(hdr, c["mjd_tt"])
+    assert tau == c["tau"]
+    _check_record(c, nr)
+
+
+def test_record_index_and_tau(ephem, hdr):
     k = K["record_index"]
+    assert de_reader.record_index(hdr, k["mjd_tt"]) == (k["index"], k["tau"])
     et = np.trunc(k["mjd_tt"])
     nr = int(np.floor((2400000.5 + et - ephem.jd_start) / ephem.block_days))
     tau = ((2400000.5 + et - (nr * ephem.block_days + ephem.jd_start)) + (k["mjd_tt"] - et)) / ephem.block_days
     assert nr == k["index"] and tau == k["tau"]
 
 
-def _sun_km(ephem, mjd):
-    """explicit evaluation of the Sun segment of the loaded table (position path of horizon_records.rs:204-298)"""
+def test_sun_interpolation_position_velocity_acceleration(hdr):
+    for case in K["sun_wrt_ssb_km"]:                           # record.interpolate(tau, true, true, 2), :1016-1071
+        pos, vel, acc = de_reader.body_state(DE440, hdr, 10, case["mjd_tt"])
+        assert pos == case["position"] and vel == case["velocity"] and acc == case["acceleration"]
+
+
+def test_sun_positions_from_the_product_table(ephem):
+    """the same positions from the table the kernels consume (outfit_ephem_t packing), explicit evaluation"""
     per = sum(3 * c * s for c, s in zip(ephem.ncoef, ephem.nsub))
-    et = np.trunc(mjd)
-    nr = int(np.floor((2400000.5 + et - ephem.jd_start) / ephem.block_days))
-    tau = ((2400000.5 + et - (nr * ephem.block_days + ephem.jd_start)) + (mjd - et)) / ephem.block_days
     nc, ns = ephem.ncoef[2], ephem.nsub[2]
     off = 3 * ephem.ncoef[0] * ephem.nsub[0] + 3 * ephem.ncoef[1] * ephem.nsub[1]
-    si = min(int(np.floor(tau * ns)), ns - 1)
-    seg = ephem.coef[nr * per + off + si * 3 * nc: nr * per + off + (si + 1) * 3 * nc].reshape(3, nc)
-    tc = 2.0 * (np.mod(ns * tau, 1.0) + np.trunc(tau)) - 1.0
-    t = [1.0, tc]
-    for i in range(2, nc):
-        t.append((tc + tc) * t[i - 1] - t[i - 2])
-    out = []
-    for ax in range(3):
-        s = 0.0
-        for c, b in zip(seg[ax], t):   # left-to-right iterator sum, as the reference
-            s += c * b
-        out.append(s)
-    return out
-
-
-def test_sun_positions_bit_exact(ephem):
     for case in K["sun_wrt_ssb_km"]:
-        assert _sun_km(ephem, case["mjd_tt"]) == case["position"]
+        mjd = case["mjd_tt"]
+        et = np.trunc(mjd)
+        nr = int(np.floor((2400000.5 + et - ephem.jd_start) / ephem.block_days))
+        tau = ((2400000.5 + et - (nr * ephem.block_days + ephem.jd_start)) + (mjd - et)) / ephem.block_days
+        si = min(int(np.floor(tau * ns)), ns - 1)
+        seg = ephem.coef[nr * per + off + si * 3 * nc: nr * per + off + (si + 1) * 3 * nc].reshape(3, nc)
+        pos, _, _ = de_reader.interpolate(seg, 0.0, 32.0, tau, ns)
+        assert pos == case["position"]
+
+
+def test_target_center_states(hdr):
+    for case in K["target_wrt_center_au"]:                     # ephemeris(target, center, .., true, true).to_au(), :1074-1172
+        pos, vel, acc = de_reader.ephemeris(DE440, hdr, case["target_row"], case["center_row"], case["mjd_tt"])
+        assert pos == case["position"] and vel == case["velocity"] and acc == case["acceleration"], case["target"]
 
 
 def test_earth_sun_vector_oracle(ephem):
@@ -83,7 +139,27 @@ def test_earth_sun_vector_oracle(ephem):
 
 @pytest.mark.gpu
 def test_earth_sun_vector_device(ephem):
+    """reader -> outfit_ephem_t -> K1's Chebyshev evaluation on the device (zero site vector: heliocentric = Earth)"""
     m = np.array([c["mjd_tt"] for c in K["earth_wrt_sun_au"]])
     geo, helio = outfit_amd.observer_positions(ephem, m, m, np.zeros(3 * len(m)))
     for got, case in zip(helio, K["earth_wrt_sun_au"]):
         assert list(got) == case["position"]
+
+
+@pytest.mark.gpu
+def test_iod_on_the_real_table_equals_the_oracle(ephem):
+    """the whole path with the real DE440 Earth: synthetic objects observed from the geocentre over 2023-2024,
+    device == oracle in every integer field and in the elements (the Chebyshev blocks staged through LDS by K1)."""
+    from outfit_amd import synth
+    table = {"jd_start": ephem.jd_start, "jd_end": ephem.jd_end, "block_days": ephem.block_days, "emrat": ephem.emrat,
+             "ncoef": ephem.ncoef, "nsub": ephem.nsub, "n_blocks": ephem.n_blocks, "coef": ephem.coef}
+    ds = synth.make_dataset(500, seed=440, ephem=table, topocentric=True)
+    batch = outfit_amd.ObsBatch.from_dict(ds)
+    params = synth.bench_params(outfit_amd.IODParams())
+    got = outfit_amd.fit_full_iod_records(batch, ephem, params, 1)
+    rc, ref = O.fit_full_iod(params.as_c(), batch.as_c(), ephem.as_c(), n_threads=8, hoist=1)
+    assert rc == 0
+    for k in ("status", "cause", "stage", "kind", "attempts", "n_triplets", "best_triplet", "best_realization"):
+        assert np.array_equal(got[k], ref[k]), k
+    ok = ref["status"] == 0
+    assert ok.sum() > 450 and np.array_equal(got["elem"][ok], ref["elem"][ok])

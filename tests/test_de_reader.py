@@ -62,7 +62,7 @@ def test_reader_matches_oracle_and_source_table(tmp_path, table):
 
 
 def test_pre_de440_layout_has_no_rows_13_14(tmp_path, table):
-    """read_ipt_13_14 (horizon_data.rs:323-347): rows 13/14 only for DE440+ with more than 400 constants."""
+    """read_ipt_13_14 (horizon_data.rs:382-405): rows 13/14 only for DE440+ with more than 400 constants."""
     ipt = [r[:] for r in DE440_IPT]
     ipt[13], ipt[14] = [0, 0, 0], [0, 0, 0]
     for numde, ncon in ((430, 572), (440, 400)):
@@ -106,6 +106,57 @@ def test_reader_errors(tmp_path, table):
     junk.write_bytes(bytes(range(256)) * 64)          # IPT rows point outside any plausible record
     with pytest.raises(outfit_amd.EphemerisFileError):
         outfit_amd.Ephemeris.from_file(junk)
+
+
+def test_body_records_of_any_ipt_row(tmp_path, table):
+    """`outfit_hip_ephem_body_record` (extract_body_records, horizon_data.rs:468-491) against the numpy restatement:
+    every body of the file, first / last block; the three bodies of the path equal the table's segments; the
+    restated `interpolate` (horizon_records.rs:204-298) reproduces the C oracle's Earth on the same file and its
+    velocity / acceleration are the derivatives of its position (central differences)."""
+    path = tmp_path / "bodies.440"
+    de_writer.write_de(path, table)
+    hdr = de_reader.read(path)
+    for row in range(13):
+        for block in (0, table["n_blocks"] - 1):
+            a, ja = outfit_amd.Ephemeris.body_records(path, row, block)
+            b, jb = de_reader.body_records(path, row, block)
+            assert a.shape == b.shape == (DE440_IPT[row][2], 2 if row == 11 else 3, DE440_IPT[row][1])
+            assert a.tobytes() == b.tobytes() and ja == jb == (table["jd_start"] + 32.0 * block, table["jd_start"] + 32.0 * block + 32.0)
+    per = sum(3 * c * s for c, s in zip(table["ncoef"], table["nsub"]))
+    coef = np.asarray(table["coef"]).reshape(table["n_blocks"], per)
+    o = 0
+    for b, row in enumerate((2, 9, 10)):
+        n = 3 * table["ncoef"][b] * table["nsub"][b]
+        assert outfit_amd.Ephemeris.body_records(path, row, 2)[0].reshape(-1).tobytes() == coef[2, o:o + n].tobytes()
+        o += n
+    with pytest.raises(outfit_amd.InvalidBatch):
+        outfit_amd.Ephemeris.body_records(path, 13, 0)           # row 13 holds no coefficients in DE440
+    with pytest.raises(outfit_amd.InvalidBatch):
+        outfit_amd.Ephemeris.body_records(path, 2, table["n_blocks"])
+    eph = outfit_amd.Ephemeris.from_file(path)
+    for mjd in (59990.25, 60050.0, 60100.123456):
+        want = O.D3()
+        assert O.lib().orc_earth_ephemeris(C.byref(eph.as_c()), mjd, want) == 0
+        pos, vel, acc = de_reader.ephemeris(path, hdr, 2, 10, mjd)
+        assert pos == list(want)
+        h = 1e-3
+        p1, v1, _ = de_reader.ephemeris(path, hdr, 2, 10, mjd + h)
+        p0, v0, _ = de_reader.ephemeris(path, hdr, 2, 10, mjd - h)
+        assert np.allclose((np.array(p1) - np.array(p0)) / (2 * h), vel, rtol=1e-6, atol=1e-12)
+        assert np.allclose((np.array(v1) - np.array(v0)) / (2 * h), acc, rtol=1e-5, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_reader_suite_runs_in_gputest(tmp_path):
+    """The host-only reader checks above, collected under -m gpu as well so that they execute on the GPU box's
+    toolchain and filesystem in the round-end run (they need no device)."""
+    table = synth.make_ephemeris(n_blocks=5)
+    test_reference_header_kat_recsize()
+    for i, fn in enumerate((test_reader_matches_oracle_and_source_table, test_pre_de440_layout_has_no_rows_13_14,
+                            test_rows_13_14_change_the_record_size, test_reader_errors, test_body_records_of_any_ipt_row)):
+        d = tmp_path / f"case{i}"
+        d.mkdir()
+        fn(d, table)
 
 
 @pytest.mark.gpu

