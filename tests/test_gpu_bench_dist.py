@@ -54,3 +54,25 @@ def test_world_size_must_match_gpus():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], env=env, capture_output=True,
                        text=True, timeout=300, cwd=ROOT)
     assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
+
+
+def test_two_ranks_share_the_gpu_through_gloo_unequal_shards():
+    """World size 2 on the one GPU (rehearsal mode: gloo gathers host copies, both ranks use GPU 0): the barrier /
+    max-over-ranks timing, the padded gather of UNEQUAL shards (75 000 objects as 3 blocks over 2 ranks: 25 000 +
+    50 000) and the whole-table check on every rank — each rank verifies both shards against the CRCs exchanged."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29543", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--single-device",
+                        "--scaling", "strong", "--total-objects", "75000", "--no-cpu-baseline", "--no-lsq"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-1500:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["objects_per_gpu"] == [25000, 50000]
+    gc = line["gather_check"]
+    assert gc["ranks_verified_by_every_rank"] == 2 and gc["records"] == 75000 and len(set(gc["crc32_per_rank"])) == 2
+    assert abs(line["value"] - 75000 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]

@@ -17,6 +17,8 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$OUT/pmc_wri
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_LDS --output-format csv -d $R/$OUT/pmc_sq -- python3 $R/bench.py --steps 1 --warmup 0 $B "$@" > $R/$OUT/bench_pmc_sq.log 2>&1
 # 3) fp64 instruction mix, when the counters exist on this device
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 --output-format csv -d $R/$OUT/pmc_f64 -- python3 $R/bench.py --steps 1 --warmup 0 $B "$@" > $R/$OUT/bench_pmc_f64.log 2>&1
+# 3a) lane utilisation: active lanes per VALU instruction = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU
+rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES --output-format csv -d $R/$OUT/pmc_lanes -- python3 $R/bench.py --steps 1 --warmup 0 $B "$@" > $R/$OUT/bench_pmc_lanes.log 2>&1
 # 3b) engine clock under this load: GRBM_GUI_ACTIVE counts GPU clock cycles while the kernel runs (cycles / duration)
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $R/$OUT/pmc_clk -- python3 $R/bench.py --steps 1 --warmup 0 $B "$@" > $R/$OUT/bench_pmc_clk.log 2>&1
 # 4) calibration of the byte counters for 8-byte-per-lane streams
