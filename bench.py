@@ -110,6 +110,8 @@ def parity_vs_libm(batch, ephem, params, records_by_mode, n_sample):
         rr = np.abs(g["rms"][ok] - ref["rms"][ok]) / np.maximum(1.0, ref["rms"][ok])
         out[mode] = {"orbits": int(ok.sum()), "integer_fields_identical": bool(int_same),
                      "bit_identical_elements": int((g["elem"][ok] == ref["elem"][ok]).all(axis=1).sum()),
+                     "bit_identical_rms": int((g["rms"][ok] == ref["rms"][ok]).sum()),
+                     "byte_identical_records": int(sum(g[i].tobytes() == ref[i].tobytes() for i in range(len(ref)))),
                      "beyond_1e-10_AU": int((dl > 1e-10).sum()), "beyond_1e-12_rad": int((da > 1e-12).sum()),
                      "max_d_len": float(dl.max()), "max_d_angle": float(da.max()), "max_rel_d_rms": float(rr.max())}
     return out

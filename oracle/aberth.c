@@ -81,8 +81,8 @@ int orc_aberth9(const double poly[9], uint32_t max_iter, double eps, double re[8
   const double frac_pi_2n = (ORC_PI / 2.0) / (double)N;
   for (int k = 0; k < N; ++k) {
     double theta = fma(frac_2pi_n, (double)k, frac_pi_2n);
-    double ct = (orc_use_libm || (orc_libm_mask & 32)) ? cos(theta) : orc_aberth_cos_sin[k][0];
-    double st = (orc_use_libm || (orc_libm_mask & 32)) ? sin(theta) : orc_aberth_cos_sin[k][1];
+    double ct = orc_aberth_cos_sin[k][0], st = orc_aberth_cos_sin[k][1];
+    if (orc_use_libm || (orc_libm_mask & 32)) sincos(theta, &st, &ct); /* both results used: stays one sincos call */ /* theta.cos(), theta.sin(): one sincos call */
     zs[k].re = fma(r0, ct, a);
     zs[k].im = r0 * st;
   }

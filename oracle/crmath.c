@@ -189,10 +189,31 @@ static void sincos_cr(double x, double *s, double *c) {
   *s = sd.hi;
   *c = cd.hi;
 }
+/* PAIRED sites — x.sin() and x.cos() of the same operand in one basic block of the reference: rustc/LLVM emits ONE
+ * call of sincos() there on *-linux-gnu (glibcmath.c explains; glibc's sincos and its standalone sin / cos return
+ * different last bits for 0.07 % of arguments). The platform-libm mode therefore calls sincos() explicitly (it used
+ * to write sin(x); cos(x) and relied on gcc merging them), the restated mode the sincos-equivalent restatement. */
+static void (*volatile libm_sincos)(double, double *, double *) = sincos; /* volatile: gcc turns a sincos() whose
+                                          other result is unused back into a standalone sin() / cos() call */
 void orc_sincos(double x, double *s, double *c) {
-  if (LIBM(1)) { *s = sin(x); *c = cos(x); return; }
+  if (LIBM(1)) { libm_sincos(x, s, c); return; }
   if (orc_math_glibc && fabs(x) < 1048576.0) { *s = orc_glibc_sin(x); *c = orc_glibc_cos(x); return; }
   sincos_cr(x, s, c);
+}
+/* ISOLATED sites — a sin or a cos whose partner is not evaluated on the same operand (prelim_elliptic.rs:97): the
+ * standalone libm entry point, which on FMA hardware is glibc's contracted variant (orc_glibc_sin1 / cos1). The
+ * calls go through volatile pointers so that this file's own compiler cannot pair them. */
+static double (*volatile libm_sin)(double) = sin;
+static double (*volatile libm_cos)(double) = cos;
+double orc_sin1(double x) {
+  if (LIBM(1)) return libm_sin(x);
+  if (orc_math_glibc && fabs(x) < 1048576.0) return orc_glibc_sin1(x);
+  double s, c; sincos_cr(x, &s, &c); return s;
+}
+double orc_cos1(double x) {
+  if (LIBM(1)) return libm_cos(x);
+  if (orc_math_glibc && fabs(x) < 1048576.0) return orc_glibc_cos1(x);
+  double s, c; sincos_cr(x, &s, &c); return c;
 }
 /* The Earth-rotation pre-pass (earthrot.c, row n2) evaluates its ~170 sin/cos per observation correctly rounded in
  * BOTH math modes, like the corrector: its nutation series is a table summed in another order than the reference's
@@ -232,7 +253,9 @@ double orc_cosh(double x) { return LIBM(4) ? cosh(x) : orc_math_glibc ? orc_glib
 double orc_log(double x) { return LIBM(8) ? log(x) : (double)logq((__float128)x); }
 /* atan2 of the state -> elements conversion (orb_elem.rs:58-226): a last-place difference of i or Omega is
  * amplified ~a/r in a near-parabolic 1/a and ~1/e in omega, M of a near-circular orbit. */
-double orc_atan2(double y, double x) { return LIBM(16) ? atan2(y, x) : (double)atan2q((__float128)y, (__float128)x); }
+double orc_atan2(double y, double x) {
+  return LIBM(16) ? atan2(y, x) : orc_math_glibc ? orc_glibc_atan2(y, x) : (double)atan2q((__float128)y, (__float128)x);
+}
 
 /* ---- scoped selection: the differential corrector evaluates ALL its elementary functions correctly rounded
  * (its ill-conditioned normal equations amplify a last place up to 1e13 times; the device does the same and is
@@ -241,8 +264,28 @@ double orc_atan2(double y, double x) { return LIBM(16) ? atan2(y, x) : (double)a
  * raised around the corrector (diffcor.c); orc_use_libm = 1 overrides everything to the platform libm. */
 __thread int orc_cr_scope = 0;
 static int scoped_cr(void) { return !orc_use_libm && orc_cr_scope > 0; }
-double orc_sin_s(double x) { double s, c; if (!scoped_cr()) return sin(x); sincos_cr(x, &s, &c); return s; }
-double orc_cos_s(double x) { double s, c; if (!scoped_cr()) return cos(x); sincos_cr(x, &s, &c); return c; }
-double orc_tan_s(double x) { return scoped_cr() ? (double)tanq((__float128)x) : tan(x); }
-double orc_atan2_s(double y, double x) { return scoped_cr() ? (double)atan2q((__float128)y, (__float128)x) : atan2(y, x); }
-double orc_hypot_s(double x, double y) { return scoped_cr() ? (double)hypotq((__float128)x, (__float128)y) : hypot(x, y); }
+/* Outside the corrector's scope — the RMS stage of the IOD (ccek1's caller chain, to_equinoctial, propagate_twobody,
+ * ephemeris_error) — the reference's platform libm is what counts: in the restated-glibc mode these are glibc 2.35's
+ * functions restated (glibcmath.c, glibcmath2.c: the `rms` field and the selection then follow a glibc run bit for
+ * bit without calling glibc); in the default mode and with orc_use_libm the platform's. */
+static int restated_glibc(void) { return orc_math_glibc && !orc_use_libm; }
+/* paired sites of the RMS stage (to_equinoctial, the Kepler-equation closures, the position formulas): sincos */
+static void sincos_rms(double x, double *s, double *c) {
+  if (restated_glibc() && fabs(x) < 1048576.0) { *s = orc_glibc_sin(x); *c = orc_glibc_cos(x); return; }
+  libm_sincos(x, s, c);
+}
+double orc_sin_s(double x) { double s, c; if (scoped_cr()) sincos_cr(x, &s, &c); else sincos_rms(x, &s, &c); return s; }
+double orc_cos_s(double x) { double s, c; if (scoped_cr()) sincos_cr(x, &s, &c); else sincos_rms(x, &s, &c); return c; }
+/* the one isolated cosine of the RMS stage: cos(dec_obs) in ephemeris_error (observation_ephemeris.rs:412) */
+double orc_cos1_s(double x) {
+  double s, c;
+  if (scoped_cr()) { sincos_cr(x, &s, &c); return c; }
+  return restated_glibc() && fabs(x) < 1048576.0 ? orc_glibc_cos1(x) : libm_cos(x);
+}
+double orc_tan_s(double x) { return scoped_cr() ? (double)tanq((__float128)x) : restated_glibc() ? orc_glibc_tan(x) : tan(x); }
+double orc_atan2_s(double y, double x) {
+  return scoped_cr() ? (double)atan2q((__float128)y, (__float128)x) : restated_glibc() ? orc_glibc_atan2(y, x) : atan2(y, x);
+}
+double orc_hypot_s(double x, double y) {
+  return scoped_cr() ? (double)hypotq((__float128)x, (__float128)y) : restated_glibc() ? orc_glibc_hypot(x, y) : hypot(x, y);
+}

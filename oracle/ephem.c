@@ -90,9 +90,9 @@ void orc_topocentric_radec(const double ast_pos[3], const double ast_vel[3], con
   for (int i = 0; i < 3; ++i) rel[i] = ast_pos[i] - obs_pos[i];
   double dt = sqrt((rel[0] * rel[0] + rel[1] * rel[1]) + rel[2] * rel[2]) / VLIGHT_AU;
   for (int i = 0; i < 3; ++i) cor[i] = rel[i] - dt * ast_vel[i];
-  double rho_xy = hypot(cor[0], cor[1]);
-  *dec = atan2(cor[2], rho_xy);
-  double a = fmod(atan2(cor[1], cor[0]), ORC_DPI); /* rem_euclid(TAU) */
+  double rho_xy = orc_hypot_s(cor[0], cor[1]); /* platform libm, or glibc restated in that mode (crmath.c) */
+  *dec = orc_atan2_s(cor[2], rho_xy);
+  double a = fmod(orc_atan2_s(cor[1], cor[0]), ORC_DPI); /* rem_euclid(TAU) */
   if (a < 0.0) a += ORC_DPI;
   *ra = a;
 }
@@ -112,7 +112,7 @@ int orc_ephemeris_error(const orc_equinoctial *eq, double mjd, double ra, double
   double da = fmod(ra - alpha, ORC_DPI); /* Rust `%` keeps the sign of the dividend (quirk Q6) */
   if (da > ORC_PI) da -= ORC_DPI;
   double dd = dec - delta;
-  double t1 = cos(dec) * (da / sra);
+  double t1 = orc_cos1_s(dec) * (da / sra); /* isolated cos: observation_ephemeris.rs:412 */
   double t2 = dd / sdec;
   *term = t1 * t1 + t2 * t2;
   return 0;

@@ -114,6 +114,83 @@ double orc_glibc_cos(double x) {
   return cos(x);
 }
 
+/* ---- sin / cos as the STANDALONE entry points return them --------------------------------------------------
+ * Found in round 3: glibc 2.35 x86-64 does NOT return the same bits from sin(x) / cos(x) and from sincos(x).
+ * `sincos` has one variant (SSE2, no fused operation) — what the functions above restate; `sin` and `cos` are
+ * IFUNCs whose FMA/AVX2 variants (__sin_fma, __cos_fma) are the same s_sin.c compiled with contraction: every
+ * a*b+c of do_sin / do_cos / TAYLOR_SIN / reduce_sincos that GCC could fuse IS fused. The two differ in the last
+ * bit for 0.07 % of arguments (tools/glibc_pin2.c). Which one the reference calls is decided by LLVM per call
+ * site: x.sin() and x.cos() of the SAME operand in one basic block become ONE call of sincos on *-linux-gnu
+ * (SelectionDAG's FSINCOS combine; Rust's f64::sin / cos are the llvm.sin / llvm.cos intrinsics), an isolated
+ * x.sin() or x.cos() calls the standalone function. On the path the isolated ones are `u0.sin()` of the elliptic cold
+ * start (prelim_elliptic.rs:97) and `dec.cos()` of the residual (observation_ephemeris.rs:412); every other site
+ * pairs (unit_vector gauss.rs:464-469 after inlining, the Newton loops prelim_elliptic.rs:125-126 and
+ * equinoctial_element.rs:332-337, :659-660, :295-300, orb_elem.rs:166-171, nalgebra's sin_cos in the rotations).
+ * Operation order below: read off the machine code of __sin_fma / __cos_fma (Ubuntu GLIBC 2.35-0ubuntu3.12). */
+static inline double taylor_sin_fma(double xx, double x, double dx) {
+  double p = fma(fma(fma(fma(S5, xx, S4), xx, S3), xx, S2), xx, S1);
+  double t = fma(fma(p, x, -(0.5 * dx)), xx, dx);
+  return x + t;
+}
+static inline double do_cos_fma(double x, double dx) {
+  if (x < 0) dx = -dx;
+  double u = BIG + fabs(x);
+  x = fabs(x) - (u - BIG) + dx;
+  const double *T = kGlibcSinCosTab + loword(u) * 4;
+  double xx = x * x;
+  double s = fma(x * xx, fma(xx, SN5, SN3), x);
+  double c = xx * fma(xx, fma(xx, CS6, CS4), CS2);
+  double cor = fma(-s, T[0], fma(-c, T[2], fma(-s, T[1], T[3])));
+  return T[2] + cor;
+}
+static inline double do_sin_fma(double x, double dx) {
+  double xold = x;
+  if (fabs(x) < 0.126) return taylor_sin_fma(x * x, x, dx);
+  if (x <= 0) dx = -dx;
+  double u = BIG + fabs(x);
+  x = fabs(x) - (u - BIG);
+  const double *T = kGlibcSinCosTab + loword(u) * 4;
+  double xx = x * x;
+  double s = x + fma(x * xx, fma(xx, SN5, SN3), dx);
+  double c = fma(x, dx, xx * fma(xx, fma(xx, CS6, CS4), CS2));
+  double cor = fma(s, T[2], fma(-c, T[0], fma(s, T[3], T[1])));
+  return copysign(T[0] + cor, xold);
+}
+static inline int reduce_sincos_fma(double x, double *a, double *da) {
+  double t = fma(x, HPINV, TOINT);
+  double xn = t - TOINT;
+  double y = fma(-xn, MP2, fma(-xn, MP1, x));
+  int n = loword(t) & 3;
+  double t2 = fma(-xn, PP3, y), db = fma(-xn, PP3, y - t2);
+  double b = fma(-xn, PP4, t2);
+  db += fma(-xn, PP4, t2 - b);
+  *a = b;
+  *da = db;
+  return n;
+}
+static inline double do_sincos_fma(double a, double da, int n) {
+  double r = (n & 1) ? do_cos_fma(a, da) : do_sin_fma(a, da);
+  return (n & 2) ? -r : r;
+}
+double orc_glibc_sin1(double x) {
+  uint32_t k = hiword(x) & 0x7fffffff;
+  double a, da;
+  if (k < 0x3e500000) return x;
+  if (k < 0x3feb6000) return do_sin_fma(x, 0);
+  if (k < 0x400368fd) return copysign(do_cos_fma(HP0 - fabs(x), HP1), x);
+  if (k < 0x419921FB) { int n = reduce_sincos_fma(x, &a, &da); return do_sincos_fma(a, da, n); }
+  return sin(x);
+}
+double orc_glibc_cos1(double x) {
+  uint32_t k = hiword(x) & 0x7fffffff;
+  double a, da;
+  if (k < 0x3e400000) return 1.0;
+  if (k < 0x3feb6000) return do_cos_fma(x, 0);
+  if (k < 0x400368fd) { double y = HP0 - fabs(x); a = y + HP1; da = (y - a) + HP1; return do_sin_fma(a, da); }
+  if (k < 0x419921FB) { int n = reduce_sincos_fma(x, &a, &da); return do_sincos_fma(a, da, n + 1); }
+  return cos(x);
+}
+
 /* ---- expm1 (0x1p-54 <= |x| < 56 ln 2) --------------------------------------------------------------------- */
 static const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10,
                     INVLN2 = 1.44269504088896338700e+00, Q1 = -3.33333333333331316428e-02,

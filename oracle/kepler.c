@@ -106,7 +106,7 @@ double orc_prelim_elliptic(const orc_kepler_params *p) {
   double n = sqrt(p->mu) * sqrt(-powi3(p->alpha));
   if (p->e0 < contr) return n * p->dt / sqrt(-p->alpha);
   double u0 = initial_ecc_anomaly(p->r0, a0, p->e0, p->sig0);
-  double m0 = orc_principal_angle(u0 - p->e0 * orc_sin(u0));
+  double m0 = orc_principal_angle(u0 - p->e0 * orc_sin1(u0)); /* isolated sin: prelim_elliptic.rs:97 */
   double m = m0 + n * p->dt;
   double u = m;
   for (int i = 0; i < p->max_iter_prelim_kepuni; ++i) {

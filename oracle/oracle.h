@@ -56,6 +56,14 @@ double orc_glibc_cosh(double x);
 void   orc_glibc_compare_with_host(uint64_t n, uint64_t seed, uint64_t *counts /* [6] */);
 extern const double orc_aberth_cos_sin[8][2];
 void   orc_sincos(double x, double *s, double *c);
+double orc_glibc_sin1(double x);   /* glibcmath.c: the standalone sin / cos entry points (glibc's FMA variants) */
+double orc_glibc_cos1(double x);
+double orc_sin1(double x);         /* crmath.c: an ISOLATED sin / cos of the reference (no partner on the same operand) */
+double orc_cos1(double x);
+double orc_cos1_s(double x);
+double orc_glibc_atan2(double y, double x);   /* glibcmath2.c: glibc 2.35's atan2 / tan / hypot, restated */
+double orc_glibc_tan(double x);
+double orc_glibc_hypot(double x, double y);
 void   orc_sincos_prepass(double x, double *s, double *c); /* earthrot.c: correctly rounded in both math modes */
 double orc_sin(double x);
 double orc_cos(double x);

@@ -114,6 +114,8 @@ def lib():
                                                C.c_uint64]
     L.outfit_hip_ephem_close.argtypes = [vp]
     L.outfit_hip_ephem_close.restype = None
+    L.outfit_hip_glibc_eval.argtypes = [C.c_int, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                        C.POINTER(C.c_double)]
     L.outfit_hip_calibration_stream.argtypes = [C.c_uint64, C.c_int]
     L.outfit_hip_prelim_kepuni.argtypes = [C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.outfit_hip_set_math_mode.argtypes = [C.c_int]
@@ -130,7 +132,7 @@ EXPORTED_SYMBOLS = [
     "outfit_hip_last_error", "outfit_hip_abi_version", "outfit_hip_device_count",
     "outfit_hip_selftest_division", "outfit_hip_selftest_crmath", "outfit_hip_crmath_eval", "outfit_hip_selftest_aberth", "outfit_hip_device_normals", "outfit_hip_observer_positions", "outfit_hip_diffcor_config_default", "outfit_hip_diffcor_config_validate",
     "outfit_hip_fit_lsq", "outfit_hip_session_run_lsq", "outfit_hip_session_lsq_results",
-    "outfit_hip_solver_type_default", "outfit_hip_propagate_universal_ex", "outfit_hip_trim_cache", "outfit_hip_calibration_stream", "outfit_hip_prelim_kepuni", "outfit_hip_set_math_mode", "outfit_hip_get_math_mode",
+    "outfit_hip_solver_type_default", "outfit_hip_propagate_universal_ex", "outfit_hip_trim_cache", "outfit_hip_calibration_stream", "outfit_hip_glibc_eval", "outfit_hip_prelim_kepuni", "outfit_hip_set_math_mode", "outfit_hip_get_math_mode",
     "outfit_hip_call_options_default", "outfit_hip_fit_full_iod_ex", "outfit_hip_session_create_ex", "outfit_hip_fit_lsq_ex",
     "outfit_hip_ephem_open", "outfit_hip_ephem_header", "outfit_hip_ephem_view", "outfit_hip_ephem_close", "outfit_hip_ephem_body_record",
 ]

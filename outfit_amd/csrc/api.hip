@@ -789,7 +789,7 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
       HIP_TRY(outfit::launch_gauss_correct(cg, s->n_cu, aux));
     }
     HIP_TRY(hipEventRecord(s->ev_general, aux));
-    const outfit::RmsArgs rm{ci, w, obs_pos, s->cos_dec.p, s->params.extf, s->params.dtmax, outfit::sincos_consts()};
+    const outfit::RmsArgs rm{ci, w, obs_pos, s->cos_dec.p, s->params.extf, s->params.dtmax, outfit::sincos_consts(), s->math_mode};
     HIP_TRY(hipStreamWaitEvent(st, s->ev_prepass, 0));
     {
       Stamp stamp(s, st, K_RMS);
@@ -1383,6 +1383,27 @@ int outfit_hip_crmath_eval(int fn, uint64_t n, const double* x, double* out) {
   if (e == hipSuccess) e = hipMemcpy(out, dy.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
   dx.release();
   dy.release();
+  if (e != hipSuccess) return fail(OUTFIT_ERR_HIP, hipGetErrorString(e));
+  return OUTFIT_OK;
+}
+
+int outfit_hip_glibc_eval(int fn, uint64_t n, const double* x, const double* y, double* out) {
+  if (fn < 0 || fn > 4) return fail(OUTFIT_ERR_INVALID_PARAM, "fn: 0 sin1, 1 cos1, 2 tan, 3 atan2(x, y), 4 hypot(x, y)");
+  if (n && (!x || !out || (fn >= 3 && !y))) return fail(OUTFIT_ERR_INVALID_BATCH, "NULL argument");
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+    return fail(OUTFIT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+  if (n == 0) return OUTFIT_OK;
+  DevBuf<double> dx, dy, dz;
+  TRY_RC(upload(dx, x, (size_t)n));
+  if (fn >= 3) TRY_RC(upload(dy, y, (size_t)n));
+  HIP_TRY(dz.alloc((size_t)n));
+  hipError_t e = outfit::launch_glibc_eval(fn, n, dx.p, dy.p, dz.p, nullptr);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(out, dz.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+  dx.release();
+  dy.release();
+  dz.release();
   if (e != hipSuccess) return fail(OUTFIT_ERR_HIP, hipGetErrorString(e));
   return OUTFIT_OK;
 }

@@ -372,6 +372,9 @@ __device__ __forceinline__ CorrStep correction_iteration(const Mat3& obs, const 
     const double chi = side ? st.chi21 : st.chi01;
     const KeplerProblem p = velocity_problem(st.vc, dt, P.kepler_eps, P.math_mode);
     const KeplerSolution sol = kWarmOnly ? run_newton(p, chi) : solve_kepuni(p, side ? st.has21 : st.has01, chi);
+#ifdef OUTFIT_K2B_STATS  // histogram of Newton rounds per solve: first iteration of a candidate (cold start) / later ones
+    atomicAdd(&g_kstat[(st.it == 1 ? 24 : 16) + (sol.rounds < 7 ? sol.rounds : 7)], 1ull);
+#endif
     const VelCorr vc = velocity_finish(sol, side ? r3 : r1, r2, st.vc.r2, dt);
     if (side) b = vc; else a = vc;
   }

@@ -90,10 +90,82 @@ __device__ __forceinline__ double cos(double x) {
   if (k < 0x419921FBu) { double a, da; const int n = reduce_sincos(x, a, da); return do_sincos(a, da, n + 1); }
   return ::cos(x);
 }
-// f64::sin_cos is (sin, cos) evaluated separately (library/std/src/f64.rs)
+// x.sin() and x.cos() of one operand = ONE sincos() call of the platform libm (see sin1 / cos1 below): these two are
+// its restatement, bit for bit
 __device__ __forceinline__ void sincos(double x, double& s, double& c) {
   s = sin(x);
   c = cos(x);
+}
+
+// ---- sin / cos as the STANDALONE libm entry points return them (round 3) -------------------------------------
+// glibc 2.35 x86-64: sincos() (one SSE2 variant, nothing fused: the functions above) and sin() / cos() (IFUNCs whose
+// FMA variants are the same source compiled with contraction) differ in the last bit for 0.07 % of arguments. The
+// reference calls sincos wherever x.sin() and x.cos() of one operand share a basic block (LLVM's FSINCOS combine on
+// *-linux-gnu) and the standalone function at an isolated call: on the path `u0.sin()` in prelim_elliptic.rs:97 and
+// `dec.cos()` in observation_ephemeris.rs:412. Operation for operation as orc_glibc_sin1 / cos1 (oracle/glibcmath.c),
+// which are pinned against the installed libm's sin / cos.
+__device__ __forceinline__ double taylor_sin_fma(double xx, double x, double dx) {
+  const double p = fma(fma(fma(fma(-0x1.ADDFFC2FCDF59p-26, xx, 0x1.71DE27B9A7ED9p-19), xx, -0x1.A01A019DB08B8p-13), xx,
+                           0x1.1111111110ECEp-7), xx, -0x1.5555555555555p-3);
+  const double t = fma(fma(p, x, -(0.5 * dx)), xx, dx);
+  return x + t;
+}
+__device__ __forceinline__ double do_cos_fma(double x, double dx) {
+  if (x < 0) dx = -dx;
+  const double u = kBig + fabs(x);
+  x = fabs(x) - (u - kBig) + dx;
+  const double* T = kGlibcSinCosTab + __double2loint(u) * 4;
+  const double xx = x * x;
+  const double s = fma(x * xx, fma(xx, kSn5, kSn3), x);
+  const double c = xx * fma(xx, fma(xx, kCs6, kCs4), kCs2);
+  const double cor = fma(-s, T[0], fma(-c, T[2], fma(-s, T[1], T[3])));
+  return T[2] + cor;
+}
+__device__ __forceinline__ double do_sin_fma(double x, double dx) {
+  const double xold = x;
+  if (fabs(x) < 0.126) return taylor_sin_fma(x * x, x, dx);
+  if (x <= 0) dx = -dx;
+  const double u = kBig + fabs(x);
+  x = fabs(x) - (u - kBig);
+  const double* T = kGlibcSinCosTab + __double2loint(u) * 4;
+  const double xx = x * x;
+  const double s = x + fma(x * xx, fma(xx, kSn5, kSn3), dx);
+  const double c = fma(x, dx, xx * fma(xx, fma(xx, kCs6, kCs4), kCs2));
+  const double cor = fma(s, T[2], fma(-c, T[0], fma(s, T[3], T[1])));
+  return copysign(T[0] + cor, xold);
+}
+__device__ __forceinline__ int reduce_sincos_fma(double x, double& a, double& da) {
+  const double t = fma(x, 0x1.45F306DC9C883p-1, 0x1.8p52);
+  const double xn = t - 0x1.8p52;
+  const double y = fma(-xn, -0x1.DDE973C000000p-27, fma(-xn, 0x1.921FB58000000p0, x));
+  const int n = __double2loint(t) & 3;
+  const double t2 = fma(-xn, -0x1.CB3B398000000p-55, y);
+  double db = fma(-xn, -0x1.CB3B398000000p-55, y - t2);
+  const double b = fma(-xn, -0x1.d747f23e32ed7p-83, t2);
+  db += fma(-xn, -0x1.d747f23e32ed7p-83, t2 - b);
+  a = b;
+  da = db;
+  return n;
+}
+__device__ __forceinline__ double do_sincos_fma(double a, double da, int n) {
+  const double r = (n & 1) ? do_cos_fma(a, da) : do_sin_fma(a, da);
+  return (n & 2) ? -r : r;
+}
+__device__ __forceinline__ double sin1(double x) {
+  const unsigned k = (unsigned)__double2hiint(x) & 0x7fffffffu;
+  if (k < 0x3e500000u) return x;
+  if (k < 0x3feb6000u) return do_sin_fma(x, 0.0);
+  if (k < 0x400368fdu) return copysign(do_cos_fma(kHp0 - fabs(x), kHp1), x);
+  if (k < 0x419921FBu) { double a, da; const int n = reduce_sincos_fma(x, a, da); return do_sincos_fma(a, da, n); }
+  return ::sin(x);
+}
+__device__ __forceinline__ double cos1(double x) {
+  const unsigned k = (unsigned)__double2hiint(x) & 0x7fffffffu;
+  if (k < 0x3e400000u) return 1.0;
+  if (k < 0x3feb6000u) return do_cos_fma(x, 0.0);
+  if (k < 0x400368fdu) { const double y = kHp0 - fabs(x), a = y + kHp1, da = (y - a) + kHp1; return do_sin_fma(a, da); }
+  if (k < 0x419921FBu) { double a, da; const int n = reduce_sincos_fma(x, a, da); return do_sincos_fma(a, da, n + 1); }
+  return ::cos(x);
 }
 
 __device__ __forceinline__ double add_exponent(double y, int k) {

@@ -1,0 +1,219 @@
+// glibcmath2.hpp — atan2, tan, hypot with the bits glibc 2.35 (x86-64, FMA-capable CPU) returns. Companion of
+// glibcmath.hpp (sin, cos, sinh, cosh).
+//
+// Why: the RMS stage of the path (ccek1 -> to_equinoctial -> propagate_twobody -> ephemeris_error; reference
+// orb_elem.rs:58-226, orbit_type/mod.rs:399-443, equinoctial_element.rs:809-867, observation_ephemeris.rs:222-275,388-416)
+// calls atan2 / hypot / tan / sin / cos of the platform libm per candidate and per observation; its sum is the `rms` field
+// and the key of the selection. With these three functions next to sin/cos the whole chain runs on glibc's bits in
+// OUTFIT_MATH_GLIBC: `rms` and the selection are then bit-identical to a glibc run, not merely within 1e-6.
+//
+// Operation for operation as in oracle/glibcmath2.c (which is pinned bit for bit against the installed libm on 2e9
+// arguments per function and documents where the algorithm, the fused operations and the tables come from). This
+// translation unit is compiled with -ffp-contract=off: only the explicit fma() calls below are fused — exactly the
+// operations glibc's FMA variants fuse. Outside the restated range (|x| > 25 for tan) the platform function is used;
+// the path's call site (tan of half an inclination) never gets there.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "glibc_tables2.hpp"
+
+namespace outfit {
+namespace glm {
+
+// ---- atan2 (sysdeps/ieee754/dbl-64/e_atan2.c, the FMA variant) ------------------------------------------------
+constexpr double kHpi = 0x1.921fb54442d18p+0, kOpi = 0x1.921fb54442d18p+1, kQpi = 0x1.921fb54442d18p-1,
+                 kTqpi = 0x1.2d97c7f3321d2p+1, kHpi1 = 0x1.1a62633145c07p-54, kOpi1 = 0x1.1a62633145c07p-53;
+
+__device__ __forceinline__ double atan_poly(double v) {
+  return fma(fma(fma(fma(fma(0x1.375f08b31cbcep-4, v, -0x1.7458022b13c25p-4), v, 0x1.c71c6e5129a3bp-4), v,
+                     -0x1.24924923f7603p-3), v, 0x1.99999999997fdp-3), v, -0x1.5555555555555p-2);
+}
+__device__ __forceinline__ double cij_poly(const double* c, double v) {
+  return fma(fma(fma(fma(c[6], v, c[5]), v, c[4]), v, c[3]), v, c[2]);
+}
+__device__ __forceinline__ int cij_index(double u) { return (int)(fma(u, 256.0, 0x1p52) - 0x1p52) - 16; }
+
+__device__ __forceinline__ double atan2(double y, double x) {
+  const unsigned ux = (unsigned)__double2hiint(x), dx = (unsigned)__double2loint(x);
+  const unsigned uy = (unsigned)__double2hiint(y), dy = (unsigned)__double2loint(y);
+  if ((ux & 0x7ff00000u) == 0x7ff00000u && (((ux & 0x000fffffu) | dx) != 0)) return x + y;
+  if ((uy & 0x7ff00000u) == 0x7ff00000u && (((uy & 0x000fffffu) | dy) != 0)) return y + y;
+  if (uy == 0x00000000u) { if (dy == 0) return (ux & 0x80000000u) == 0 ? 0.0 : kOpi; }
+  else if (uy == 0x80000000u) { if (dy == 0) return (ux & 0x80000000u) == 0 ? -0.0 : -kOpi; }
+  if (x == 0.0) return (uy & 0x80000000u) == 0 ? kHpi : -kHpi;
+  if (ux == 0x7ff00000u) {
+    if (dx == 0) {
+      if (uy == 0x7ff00000u) { if (dy == 0) return kQpi; }
+      else if (uy == 0xfff00000u) { if (dy == 0) return -kQpi; }
+      else return (uy & 0x80000000u) == 0 ? 0.0 : -0.0;
+    }
+  } else if (ux == 0xfff00000u) {
+    if (dx == 0) {
+      if (uy == 0x7ff00000u) { if (dy == 0) return kTqpi; }
+      else if (uy == 0xfff00000u) { if (dy == 0) return -kTqpi; }
+      else return (uy & 0x80000000u) == 0 ? kOpi : -kOpi;
+    }
+  }
+  if (uy == 0x7ff00000u) { if (dy == 0) return kHpi; }
+  else if (uy == 0xfff00000u) { if (dy == 0) return -kHpi; }
+
+  double ax = x < 0.0 ? -x : x, ay = y < 0.0 ? -y : y;
+  const int de = (int)(uy & 0x7ff00000u) - (int)(ux & 0x7ff00000u);
+  if (de >= 59768832) return y > 0.0 ? kHpi : -kHpi;
+  if (de <= -59768832) {
+    if (x > 0.0) return copysign(ay / ax, y);
+    return y > 0.0 ? kOpi : -kOpi;
+  }
+  if (ax < 0x1p-500 || ay < 0x1p-500) { ax *= 0x1p500; ay *= 0x1p500; }
+  if (ax > 0x1p500 || ay > 0x1p500) { ax *= 0x1p-500; ay *= 0x1p-500; }
+
+  double u, du;
+  if (ay < ax) {
+    u = ay / ax;
+    const double v = ax * u, vv = fma(ax, u, -v);
+    du = ((ay - v) - vv) / ax;
+  } else {
+    u = ax / ay;
+    const double v = ay * u, vv = fma(ay, u, -v);
+    du = ((ax - v) - vv) / ay;
+  }
+  double z;
+  if (x > 0.0) {
+    if (ay < ax) {
+      if (u < 0.0625) {
+        const double v = u * u;
+        z = u + fma(u * v, atan_poly(v), du);
+      } else {
+        const double* c = kCij[cij_index(u)];
+        const double t3 = u - c[0], v = t3 + du;
+        const double dv = fabs(t3) > fabs(du) ? (t3 - v) + du : (du - v) + t3;
+        const double c2 = c[2];
+        const double p = fma(fma(fma(c[6], v, c[5]), v, c[4]), v, c[3]);
+        z = fma(v, c2, fma(dv, c2, (v * v) * p)) + c[1];
+      }
+    } else {
+      if (u < 0.0625) {
+        const double v = u * u, zz = (u * v) * atan_poly(v);
+        const double t2 = kHpi - u;
+        const double cor = kHpi > fabs(u) ? (kHpi - t2) - u : kHpi - (u + t2);
+        z = (((cor + kHpi1) - du) - zz) + t2;
+      } else {
+        const double* c = kCij[cij_index(u)];
+        const double v = (u - c[0]) + du;
+        z = (kHpi - c[1]) + fma(-cij_poly(c, v), v, kHpi1);
+      }
+    }
+  } else if (ax < ay) {
+    if (u < 0.0625) {
+      const double v = u * u, zz = (v * u) * atan_poly(v);
+      const double t2 = u + kHpi;
+      const double cor = kHpi > fabs(u) ? (kHpi - t2) + u : (u - t2) + kHpi;
+      z = (((cor + kHpi1) + du) + zz) + t2;
+    } else {
+      const double* c = kCij[cij_index(u)];
+      const double v = (u - c[0]) + du;
+      z = (kHpi + c[1]) + fma(cij_poly(c, v), v, kHpi1);
+    }
+  } else {
+    if (u < 0.0625) {
+      const double v = u * u, zz = (v * u) * atan_poly(v);
+      const double t2 = kOpi - u;
+      const double cor = kOpi > fabs(u) ? (kOpi - t2) - u : kOpi - (t2 + u);
+      z = (((cor + kOpi1) - du) - zz) + t2;
+    } else {
+      const double* c = kCij[cij_index(u)];
+      const double v = (u - c[0]) + du;
+      z = (kOpi - c[1]) + fma(-cij_poly(c, v), v, kOpi1);
+    }
+  }
+  return copysign(z, y);
+}
+
+// ---- tan (sysdeps/ieee754/dbl-64/s_tan.c, the FMA variant), |x| <= 25 -----------------------------------------
+__device__ __forceinline__ double tan_poly(double x2) {
+  return fma(fma(fma(fma(0x1.2385a3cf2e4eap-7, x2, 0x1.664ed49cfc666p-6), x2, 0x1.ba1ba1cdb8745p-5), x2,
+                 0x1.11111111107c6p-3), x2, 0x1.5555555555555p-2);
+}
+__device__ __forceinline__ double tan(double x) {
+  constexpr double g1 = 0x1.b096cp-27, g2 = 0x1.f212dp-5, g3 = 0x1.92f1ap-1, g4 = 25.0, mfftnhf = -15.5,
+                   e0 = 0x1.5555555554dbdp-2, e1 = 0x1.11112e0a6b45fp-3;
+  if (((unsigned)__double2hiint(x) & 0x7ff00000u) == 0x7ff00000u) return x - x;
+  const double w = x < 0.0 ? -x : x;
+  if (w <= g1) return x;
+  if (w <= g2) {
+    const double x2 = x * x;
+    return fma(x * x2, tan_poly(x2), x);
+  }
+  if (w <= g3) {
+    const int i = (int)fma(w, 256.0, mfftnhf);
+    const double s = x < 0.0 ? -1.0 : 1.0;
+    const double z = w - kXfg[i][0], z2 = z * z;
+    const double pz = fma(z * z2, fma(z2, e1, e0), z);
+    const double fi = kXfg[i][1], gi = kXfg[i][2];
+    return (((fi + gi) * pz) / (gi - pz) + fi) * s;
+  }
+  if (!(w <= g4)) return ::tan(x);  // not restated: unreachable from the path
+  const double t = fma(x, 0x1.45f306dc9c883p-1, 0x1.8p52), xn = t - 0x1.8p52;
+  const int n = __double2loint(t) & 1;
+  const double t1 = fma(-xn, -0x1.dde973cp-27, fma(-xn, 0x1.921fb58p+0, x));
+  const double a = fma(-xn, -0x1.cb3b399d747f2p-55, t1);
+  const double da = fma(-xn, -0x1.cb3b399d747f2p-55, t1 - a);
+  double ya, yya, sy;
+  if (a < 0.0) { ya = -a; yya = -da; sy = -1.0; } else { ya = a; yya = da; sy = 1.0; }
+  if (ya <= g2) {
+    const double a2 = a * a;
+    const double t2 = fma(a * a2, tan_poly(a2), da);
+    const double b = a + t2;
+    if (!n) return b;
+    const double db = fabs(a) > fabs(t2) ? (a - b) + t2 : (t2 - b) + a;
+    const double c = 1.0 / b;
+    const double uu0 = c * b, uu1 = fma(c, b, -uu0);
+    const double cc = fma(-db, c, ((1.0 - uu0) - uu1) + 0.0) / b;
+    const double zc = c + cc, zzc = (c - zc) + cc;
+    return -(zzc + zc);
+  }
+  const int i = (int)fma(ya, 256.0, mfftnhf);
+  const double z = (ya - kXfg[i][0]) + yya, z2 = z * z;
+  const double pz = fma(z * z2, fma(z2, e1, e0), z);
+  const double fi = kXfg[i][1], gi = kXfg[i][2];
+  const double num = (fi + gi) * pz;
+  if (n) return (gi - num / (pz + fi)) * -sy;
+  return (num / (gi - pz) + fi) * sy;
+}
+
+// ---- hypot (sysdeps/ieee754/dbl-64/e_hypot.c of glibc 2.35; no fused operations in the x86-64 build) -----------
+__device__ __forceinline__ double hypot_kernel(double ax, double ay) {
+  double h = sqrt(ax * ax + ay * ay), t1, t2;
+  if (h <= 2.0 * ay) {
+    const double delta = h - ay;
+    t1 = ax * (2.0 * delta - ax);
+    t2 = (delta - 2.0 * (ax - ay)) * delta;
+  } else {
+    const double delta = h - ax;
+    t1 = 2.0 * delta * (ax - 2.0 * ay);
+    t2 = (4.0 * delta - ay) * ay + delta * delta;
+  }
+  h -= (t2 + t1) / (2.0 * h);
+  return h;
+}
+__device__ __forceinline__ double hypot(double x, double y) {
+  if (!isfinite(x) || !isfinite(y)) {
+    if (isinf(x) || isinf(y)) return INFINITY;
+    return x + y;
+  }
+  x = fabs(x);
+  y = fabs(y);
+  const double ax = x < y ? y : x, ay = x < y ? x : y;
+  if (ax > 0x1p+511) {
+    if (ay <= ax * 0x1p-54) return ax + ay;
+    return hypot_kernel(ax * 0x1p-600, ay * 0x1p-600) * 0x1p+600;
+  }
+  if (ay < 0x1p-459) {
+    if (ax >= ay * 0x1p+54) return ax + ay;
+    return hypot_kernel(ax * 0x1p+600, ay * 0x1p+600) * 0x1p-600;
+  }
+  if (ay <= ax * 0x1p-54) return ax + ay;
+  return hypot_kernel(ax, ay);
+}
+
+}  // namespace glm
+}  // namespace outfit

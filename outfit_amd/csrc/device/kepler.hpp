@@ -14,6 +14,7 @@
 #include <type_traits>
 #include "crmath.hpp"
 #include "glibcmath.hpp"
+#include "glibcmath2.hpp"
 #include "fastdiv.hpp"
 
 namespace outfit {
@@ -197,8 +198,10 @@ __device__ __forceinline__ double prelim_elliptic(const KeplerProblem& p) {
   else u0 = kPi;
   if (p.sig0 < 0.0) u0 = -u0;
   u0 = principal_angle(u0);
+  // `u0.sin()` is an ISOLATED sine in the reference (prelim_elliptic.rs:97): the standalone libm entry point, whose
+  // bits differ from sincos's in glibc (glibcmath.hpp sin1); correctly rounded otherwise
   double su0, cu0;
-  sincos_mode(p.math_mode, u0, su0, cu0);
+  if (p.math_mode == kMathGlibc) su0 = glm::sin1(u0); else crm::sincos(u0, su0, cu0);
   const double m0 = principal_angle(u0 - p.e0 * su0);
   const double m = m0 + n * p.dt;
   double u = m;
@@ -339,6 +342,9 @@ struct KeplerSolution {
   double psi;
   Stumpff s;
   bool ok;
+#ifdef OUTFIT_K2B_STATS
+  int rounds = 0;
+#endif
 };
 
 // kepler/newton_solver.rs:151-161,240-352 (SolverKind::NewtonRaphson)
@@ -352,6 +358,9 @@ __device__ __forceinline__ KeplerSolution run_newton(const KeplerProblem& p, dou
   out.s = {1.0, 0.0, 0.0, 0.0};
   for (int it = 0; it < 50; ++it) {
     KSTAT(0);
+#ifdef OUTFIT_K2B_STATS
+    out.rounds = it + 1;
+#endif
     if (!isfinite(psi)) { psi = 0.5; continue; }
     const Stumpff s = s_funct(psi, p.alpha);
     const double residual = p.r0 * s.s1 + p.sig0 * s.s2 + s.s3 - sqrt_mu * p.dt;

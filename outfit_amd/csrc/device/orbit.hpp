@@ -53,21 +53,36 @@ struct Elements {
   double e[6];
 };
 
-// Platform or correctly-rounded elementary functions, chosen per caller: the candidate RMS (K2c, 2x10^8
-// observation evaluations per step) keeps the platform functions — they move the RMS by <= 1e-9 relative, never the
-// returned elements; the differential corrector (ill-conditioned normal equations amplify a last place up to
-// 1e13 times) uses the correctly-rounded ones and is then bit-identical to the oracle.
-template <bool kCr> __device__ __forceinline__ void sincos_sel(double x, double& s, double& c, int math_mode = kMathCr) {
-  if constexpr (kCr) sincos_mode(math_mode, x, s, c); else ::sincos(x, &s, &c);
+// Which elementary functions a caller of the conversions below gets (template argument kFn):
+//   kFnPlatform  ROCm's — the candidate RMS in the correctly-rounded math mode (K2c, 2x10^8 observation evaluations
+//                per step): they move the RMS by <= 1e-6 relative, never the returned elements;
+//   kFnCr        correctly rounded (sin/cos by `math_mode`) — the returned elements (K3) in that mode, and the
+//                differential corrector in both modes (ill-conditioned normal equations amplify a last place up to
+//                1e13 times; bit-identical to the oracle);
+//   kFnGlibc     glibc 2.35's bits (glibcmath.hpp, glibcmath2.hpp) — the whole candidate -> RMS chain and the returned
+//                elements in OUTFIT_MATH_GLIBC: `rms`, the selection and the elements then follow a glibc run of the
+//                reference bit for bit. Every sin/cos pair here shares its operand, i.e. is ONE sincos call in the
+//                reference (glm::sincos); the one isolated cosine, cos(dec_obs), is K1's (glm::cos1).
+constexpr int kFnPlatform = 0, kFnCr = 1, kFnGlibc = 2;
+template <int kFn> __device__ __forceinline__ void sincos_sel(double x, double& s, double& c, int math_mode = kMathCr) {
+  if constexpr (kFn == kFnCr) sincos_mode(math_mode, x, s, c);
+  else if constexpr (kFn == kFnGlibc) glm::sincos(x, s, c);
+  else ::sincos(x, &s, &c);
 }
-template <bool kCr> __device__ __forceinline__ double atan2_sel(double y, double x) {
-  if constexpr (kCr) return crm::atan2(y, x); else return ::atan2(y, x);
+template <int kFn> __device__ __forceinline__ double atan2_sel(double y, double x) {
+  if constexpr (kFn == kFnCr) return crm::atan2(y, x);
+  else if constexpr (kFn == kFnGlibc) return glm::atan2(y, x);
+  else return ::atan2(y, x);
 }
-template <bool kCr> __device__ __forceinline__ double tan_sel(double x) {
-  if constexpr (kCr) return crm::tan(x); else return ::tan(x);
+template <int kFn> __device__ __forceinline__ double tan_sel(double x) {
+  if constexpr (kFn == kFnCr) return crm::tan(x);
+  else if constexpr (kFn == kFnGlibc) return glm::tan(x);
+  else return ::tan(x);
 }
-template <bool kCr> __device__ __forceinline__ double hypot_sel(double x, double y) {
-  if constexpr (kCr) return crm::hypot(x, y); else return ::hypot(x, y);
+template <int kFn> __device__ __forceinline__ double hypot_sel(double x, double y) {
+  if constexpr (kFn == kFnCr) return crm::hypot(x, y);
+  else if constexpr (kFn == kFnGlibc) return glm::hypot(x, y);
+  else return ::hypot(x, y);
 }
 
 // orb_elem.rs:58-226 (input already rotated to the ecliptic frame). The angles and the rotation's sines and
@@ -75,7 +90,7 @@ template <bool kCr> __device__ __forceinline__ double hypot_sel(double x, double
 // near-parabolic 1/a and ~1/e in omega and M of a near-circular orbit, and these are the returned elements.
 // kCr = false (platform functions, ~900 instructions cheaper) serves the RMS evaluation of every candidate in K2c;
 // the elements that are RETURNED are recomputed with kCr = true for the selected candidate only (K3).
-template <bool kCr = true>
+template <int kCr = kFnCr>
 __device__ __forceinline__ Elements ccek1(const Vec3& pos, const Vec3& vel, double epoch, int math_mode = kMathCr) {
   constexpr double EPS_EQ = 1e-15, EPS_PARAB = 1e-12, EPS_E = 5e-15;
   Elements out;
@@ -202,7 +217,7 @@ __device__ __forceinline__ void sincos_k(double x, const SinCosConsts& K, double
 }
 
 // equinoctial_element.rs:285-313
-template <bool kCr = false>
+template <int kCr = kFnPlatform>
 __device__ __forceinline__ Equinoctial from_kepler(double epoch, double a, double e, double inc, double node,
                                           double argp, double ma) {
   Equinoctial q;
@@ -223,7 +238,7 @@ __device__ __forceinline__ Equinoctial from_kepler(double epoch, double a, doubl
 
 // orbit_type/mod.rs:399-443 ; returns 0, 3 (InvalidConversion) or 4 (InvalidOrbit) =
 // OUTFIT_TRAJ_* of include/outfit_hip.h
-template <bool kCr = false>
+template <int kCr = kFnPlatform>
 __device__ __forceinline__ int to_equinoctial(const Elements& el, Equinoctial& eq) {
   if (el.kind == 0) {
     eq = from_kepler<kCr>(el.epoch, el.e[0], el.e[1], el.e[2], el.e[3], el.e[4], el.e[5]);
@@ -235,7 +250,7 @@ __device__ __forceinline__ int to_equinoctial(const Elements& el, Equinoctial& e
   const double a = -p / (e * e - 1.0);
   if (e <= 1.0) return 4;
   const double s = sqrt((e - 1.0) / (e + 1.0));
-  const double x = clampd(s * tan(0.5 * el.e[5]), -1.0 + 1e-15, 1.0 - 1e-15);
+  const double x = clampd(s * tan_sel<kCr>(0.5 * el.e[5]), -1.0 + 1e-15, 1.0 - 1e-15);
   const double hh = 2.0 * atanh(x);
   eq = from_kepler<kCr>(el.epoch, a, e, el.e[2], el.e[3], el.e[4], e * sinh(hh) - hh);
   return 0;
@@ -249,7 +264,7 @@ struct TwoBodyFrame {
   Vec3 f, g;
 };
 
-template <bool kCr = false>
+template <int kCr = kFnPlatform>
 __device__ __forceinline__ TwoBodyFrame twobody_frame(const Equinoctial& q) {
   TwoBodyFrame F;
   F.n = sqrt(kMu / (q.a * q.a * q.a));
@@ -273,7 +288,7 @@ __device__ __forceinline__ TwoBodyFrame twobody_frame(const Equinoctial& q) {
 // equinoctial_element.rs:326-348: roots::find_root_newton_raphson on F - k sin F + h cos F = lambda1 from
 // F0 = pi + varpi, SimpleConvergency{eps: 100*EPSILON, max_iter: 25}; also returns sin F, cos F.
 // false = Err(RootFindingError)
-template <bool kCr = false>
+template <int kCr = kFnPlatform>
 __device__ __forceinline__ bool solve_kepler_equation(const Equinoctial& q, const TwoBodyFrame& F, double lam,
                                                       double& x, double& sx, double& cx,
                                                       const SinCosConsts* K = nullptr) {
@@ -301,13 +316,14 @@ __device__ __forceinline__ bool solve_kepler_equation(const Equinoctial& q, cons
 }
 
 // equinoctial_element.rs:809-867 with t0 = 0, t1 = dt ; false = Err(RootFindingError)
+template <int kCr = kFnPlatform>
 __device__ __forceinline__ bool propagate_twobody(const Equinoctial& q, const TwoBodyFrame& F, double dt,
                                          Vec3& pos, Vec3& vel, const SinCosConsts* K = nullptr) {
   double lam = principal_angle_fast(q.lambda + F.n * (dt - 0.0));
   if (lam < F.varpi) lam += kTwoPi;
   // roots::find_root_newton_raphson, SimpleConvergency{eps: 100*EPSILON, max_iter: 25}
   double x, sx, cx;
-  if (!solve_kepler_equation(q, F, lam, x, sx, cx, K)) return false;
+  if (!solve_kepler_equation<kCr>(q, F, lam, x, sx, cx, K)) return false;
   const double xe = q.a * (F.one_bh2 * cx + F.bet * sx - q.k);
   const double ye = q.a * (F.one_bk2 * sx + F.bet * cx - q.h);
   pos = {xe * F.f.x + ye * F.g.x, xe * F.f.y + ye * F.g.y, xe * F.f.z + ye * F.g.z};
@@ -319,17 +335,18 @@ __device__ __forceinline__ bool propagate_twobody(const Equinoctial& q, const Tw
 }
 
 // observation_ephemeris.rs:369-416 for one observation; false = Err(_)
+template <int kCr = kFnPlatform>
 __device__ __forceinline__ bool ephemeris_error(const Equinoctial& q, const TwoBodyFrame& F, double mjd, double ra,
                                        double dec, double cos_dec, double sra, double sdec,
                                        const Vec3& obs_pos_equ, double& term, const SinCosConsts* K = nullptr) {
   Vec3 pe, ve;
-  if (!propagate_twobody(q, F, mjd - q.epoch, pe, ve, K)) return false;
+  if (!propagate_twobody<kCr>(q, F, mjd - q.epoch, pe, ve, K)) return false;
   const Vec3 pq = ecl_to_equ_finite(pe), vq = ecl_to_equ_finite(ve);
   const Vec3 rel = {pq.x - obs_pos_equ.x, pq.y - obs_pos_equ.y, pq.z - obs_pos_equ.z};
   const double lt = norm(rel) / kVlightAU;
   const Vec3 cor = {rel.x - lt * vq.x, rel.y - lt * vq.y, rel.z - lt * vq.z};
-  const double delta = atan2(cor.z, hypot(cor.x, cor.y));
-  double alpha = atan2(cor.y, cor.x);  // |atan2| <= pi < 2*pi: rem_euclid(TAU) only adds 2*pi when negative
+  const double delta = atan2_sel<kCr>(cor.z, hypot_sel<kCr>(cor.x, cor.y));
+  double alpha = atan2_sel<kCr>(cor.y, cor.x);  // |atan2| <= pi < 2*pi: rem_euclid(TAU) only adds 2*pi when negative
   if (alpha < 0.0) alpha += kTwoPi;
   double da = fmod_2pi(ra - alpha);  // Rust `%`: sign of the dividend is kept (quirk Q6)
   if (da > kPi) da -= kTwoPi;

@@ -128,6 +128,7 @@ struct RmsArgs {
   const double* cos_dec;
   double extf, dtmax;
   SinCosConsts sc;  // polynomial constants as kernel arguments = scalar registers (device/orbit.hpp)
+  int math_mode;    // kMathGlibc: the whole candidate -> RMS chain on glibc's bits (k_orbit_rms<.., true>)
 };
 
 struct SelectArgs {
@@ -187,6 +188,7 @@ hipError_t launch_selftest_aberth(unsigned long long n_threads, unsigned long lo
                                   unsigned long long seed, unsigned long long* d_out, hipStream_t s);
 hipError_t launch_calibration_stream(unsigned long long n, const double* in, double* out, hipStream_t s);
 hipError_t launch_prelim_kepuni(unsigned long long n, const double* prob, int math_mode, double* out, hipStream_t s);
+hipError_t launch_glibc_eval(int fn, unsigned long long n, const double* x, const double* y, double* out, hipStream_t s);
 hipError_t launch_crmath_eval(int fn, unsigned long long n, const double* x, double* out, hipStream_t s);
 hipError_t launch_selftest_crmath(unsigned long long n_threads, unsigned long long n_per_thread,
                                   unsigned long long seed, unsigned long long* d_out, hipStream_t s);

@@ -95,8 +95,9 @@ k_observer_prepass(PrepassArgs a) {
     a.unit[2 * a.n_obs + o] = sd;
   }
   if (!(a.parts & kPrepassObserver)) return;
-  // cos(dec_obs) of ephemeris_error (observation_ephemeris.rs:411) depends on the observation only
-  if (live) a.cos_dec[o] = cos(a.dec[o]);
+  // cos(dec_obs) of ephemeris_error (observation_ephemeris.rs:412) depends on the observation only. It is an ISOLATED
+  // cosine in the reference: the standalone libm entry point (glm::cos1 in the glibc-faithful mode; glibcmath.hpp)
+  if (live) a.cos_dec[o] = a.math_mode == kMathGlibc ? glm::cos1(a.dec[o]) : cos(a.dec[o]);
   if (!a.has_table) return;
   if (threadIdx.x == 0) { s_min = ~0ull; s_max = 0ull; s_bad = 0; }
   __syncthreads();
@@ -620,7 +621,7 @@ __device__ __forceinline__ void select_rms_interval(const double* mjd, unsigned 
 
 // One candidate of K2c. kSlowList = false skips the candidates marked kFlagSlow (their state is being produced
 // concurrently by the general correction kernel); true handles exactly those.
-template <bool kSlowList>
+template <bool kSlowList, int kFn>
 __device__ __forceinline__ void rms_candidate(const RmsArgs& a, unsigned long long cid) {
   const unsigned f0 = a.W.flags[cid];
   if ((f0 & kFlagEmpty) || !(f0 & kFlagOk)) return;
@@ -632,13 +633,13 @@ __device__ __forceinline__ void rms_candidate(const RmsArgs& a, unsigned long lo
   const double epoch = a.W.state[6 * n + cid];
 
   // build_result -> compute_orbit_from_state -> ccek1 (gauss.rs:906-923,1063-1076)
-  // platform functions here: these elements only feed the candidate's RMS; the selected candidate's elements are
-  // recomputed correctly rounded in K3 from the same state
-  const Elements el = ccek1<false>(equ_to_ecl(r2), equ_to_ecl(v2), epoch);
+  // kFn = kFnPlatform (correctly-rounded mode): these elements only feed the candidate's RMS, the selected candidate's
+  // are recomputed correctly rounded in K3 from the same state; kFn = kFnGlibc: glibc's bits all the way (orbit.hpp)
+  const Elements el = ccek1<kFn>(equ_to_ecl(r2), equ_to_ecl(v2), epoch);
   unsigned flags = (f0 & (kFlagOk | kFlagCorrected | kFlagSlow)) | (el.kind ? kFlagCometary : 0u);
 
   Equinoctial eq;
-  const int conv = to_equinoctial(el, eq);
+  const int conv = to_equinoctial<kFn>(el, eq);
   if (conv != 0) {  // `?` at trajectory.rs:493 aborts the trajectory: K3 replays that
     a.W.flags[cid] = flags | ((unsigned)conv << kFlagConvShift);
     return;
@@ -652,13 +653,13 @@ __device__ __forceinline__ void rms_candidate(const RmsArgs& a, unsigned long lo
   if (sqrt(eq.h * eq.h + eq.k * eq.k) >= 1.0) {
     err = true;  // check_elliptical_orbit (observation_ephemeris.rs:288-296)
   } else {
-    const TwoBodyFrame F = twobody_frame(eq);
+    const TwoBodyFrame F = twobody_frame<kFn>(eq);
     for (unsigned long long i = i_start; i <= i_end; ++i) {
       const unsigned long long o = c.base + i;
       const Vec3 op = {a.obs_pos[3 * o], a.obs_pos[3 * o + 1], a.obs_pos[3 * o + 2]};
       double term;
-      if (!ephemeris_error(eq, F, a.I.mjd[o], a.I.ra[o], a.I.dec[o], a.cos_dec[o], a.I.sra[o], a.I.sdec[o], op,
-                           term, &a.sc)) {
+      if (!ephemeris_error<kFn>(eq, F, a.I.mjd[o], a.I.ra[o], a.I.dec[o], a.cos_dec[o], a.I.sra[o], a.I.sdec[o], op,
+                                term, kFn == kFnPlatform ? &a.sc : nullptr)) {
         err = true;
         break;
       }
@@ -669,20 +670,20 @@ __device__ __forceinline__ void rms_candidate(const RmsArgs& a, unsigned long lo
   a.W.flags[cid] = flags | (err ? kFlagRmsErr : 0u);
 }
 
-// kSlowList = false: every candidate of the chunk, one lane each. true: exactly the slow list — its length lives on
-// the device, so a modest grid strides over it (a grid sized for every candidate, whose lanes beyond the list return
-// at once, cost 0.16 ms of launch and wave scheduling per step for ~6 x 10^6 useful instructions).
-template <bool kSlowList>
+// kSlowList = false: every candidate of the chunk, one lane each. true: exactly the slow list — its length lives on the
+// device, so the grid covers every candidate and the lanes beyond the list return at once (0.16 ms; a modest grid
+// striding over the list was measured in round 3: the same 0.16 ms — the floor is the 20-observation chain of a handful
+// of waves — and the loop cost 200 spilled registers). kGlibc: the glibc-faithful functions (orbit.hpp kFnGlibc).
+template <bool kSlowList, bool kGlibc = false>
 __global__ void __launch_bounds__(256, 3)
 k_orbit_rms(RmsArgs a) {
+  constexpr int kFn = kGlibc ? kFnGlibc : kFnPlatform;
   const unsigned long long lid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (!kSlowList) {
-    if (lid < a.I.n_cand) rms_candidate<false>(a, lid);
-    return;
+  if (kSlowList) {
+    if (lid < *a.W.slow_count) rms_candidate<true, kFn>(a, a.W.slow_list[lid]);
+  } else if (lid < a.I.n_cand) {
+    rms_candidate<false, kFn>(a, lid);
   }
-  const unsigned long long n_items = *a.W.slow_count;
-  for (unsigned long long i = lid; i < n_items; i += (unsigned long long)gridDim.x * blockDim.x)
-    rms_candidate<true>(a, a.W.slow_list[i]);
 }
 
 // The mapping BASELINE.json's north_star names — ONE WAVEFRONT PER CANDIDATE — for the RMS stage, as a measurement
@@ -702,7 +703,7 @@ k_orbit_rms_wave(RmsArgs a) {
   const Vec3 r2 = {a.W.state[0 * n + cid], a.W.state[1 * n + cid], a.W.state[2 * n + cid]};
   const Vec3 v2 = {a.W.state[3 * n + cid], a.W.state[4 * n + cid], a.W.state[5 * n + cid]};
   const double epoch = a.W.state[6 * n + cid];
-  const Elements el = ccek1<false>(equ_to_ecl(r2), equ_to_ecl(v2), epoch);
+  const Elements el = ccek1<kFnPlatform>(equ_to_ecl(r2), equ_to_ecl(v2), epoch);
   const unsigned flags = (f0 & (kFlagOk | kFlagCorrected | kFlagSlow)) | (el.kind ? kFlagCometary : 0u);
   Equinoctial eq;
   const int conv = to_equinoctial(el, eq);
@@ -832,7 +833,9 @@ k_select_best(SelectArgs a) {
       const Vec3 r2 = {a.W.state[0 * nc + cid], a.W.state[1 * nc + cid], a.W.state[2 * nc + cid]};
       const Vec3 v2 = {a.W.state[3 * nc + cid], a.W.state[4 * nc + cid], a.W.state[5 * nc + cid]};
       out.epoch = a.W.state[6 * nc + cid];
-      const Elements el = ccek1<true>(equ_to_ecl(r2), equ_to_ecl(v2), out.epoch, a.math_mode);
+      // correctly rounded, or glibc's bits (atan2 included) in the glibc-faithful mode
+      const Elements el = a.math_mode == kMathGlibc ? ccek1<kFnGlibc>(equ_to_ecl(r2), equ_to_ecl(v2), out.epoch)
+                                                    : ccek1<kFnCr>(equ_to_ecl(r2), equ_to_ecl(v2), out.epoch, kMathCr);
       out.kind = el.kind;
       for (int k = 0; k < 6; ++k) out.elem[k] = el.e[k];
       out.rms = best;
@@ -1076,6 +1079,22 @@ k_crmath_eval(int fn, unsigned long long n, const double* x, double* out, SinCos
   out[i] = r;
 }
 
+// outfit_hip_glibc_eval: the glibc-faithful functions of round 3 on given arguments (checked against the oracle's
+// restatement and, on glibc hosts, against the platform libm by the tests). fn: 0 sin1, 1 cos1 (the standalone
+// entry points), 2 tan, 3 atan2(x[i], y[i]), 4 hypot(x[i], y[i]).
+__global__ void __launch_bounds__(256)
+k_glibc_eval(int fn, unsigned long long n, const double* x, const double* y, double* out) {
+  const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double a = x[i], b = (fn >= 3) ? y[i] : 0.0;
+  out[i] = fn == 0 ? glm::sin1(a) : fn == 1 ? glm::cos1(a) : fn == 2 ? glm::tan(a) : fn == 3 ? glm::atan2(a, b) : glm::hypot(a, b);
+}
+hipError_t launch_glibc_eval(int fn, unsigned long long n, const double* x, const double* y, double* out, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_glibc_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fn, n, x, y, out);
+  return hipGetLastError();
+}
+
 // Calibration of the HBM byte counters for THIS library's access width: every kernel here reads and writes 8 bytes
 // per lane (SoA doubles), a width the rocprofv3 FETCH_SIZE / WRITE_SIZE derivations are not calibrated for on gfx950
 // (MI355X_MICROARCH.md, HBM section). This kernel streams n doubles in and n doubles out, 8 B per lane, coalesced;
@@ -1209,6 +1228,13 @@ hipError_t launch_gauss_correct_fast(const CorrectArgs& a, unsigned n_cu, hipStr
     for (int i = 0; i < 7; ++i)
       fprintf(stderr, "[k2b stats]   %-28s wave passes/trip %7.3f   lanes/pass %5.2f\n", names[i], (double)k[2 * i] / h[1],
               k[2 * i] ? (double)k[2 * i + 1] / k[2 * i] : 0.0);
+    for (int c = 0; c < 2; ++c) {
+      unsigned long long tot = 0;
+      for (int r = 0; r < 8; ++r) tot += k[16 + 8 * c + r];
+      fprintf(stderr, "[k2b stats]   Newton rounds per solve, %s:", c ? "first iteration (cold start)" : "later iterations (warm start)");
+      for (int r = 0; r < 8; ++r) fprintf(stderr, " %d:%.4f", r, tot ? (double)k[16 + 8 * c + r] / tot : 0.0);
+      fprintf(stderr, "  (n = %llu)\n", tot);
+    }
   }
 #endif
   return hipGetLastError();
@@ -1228,10 +1254,9 @@ hipError_t launch_gauss_correct(const CorrectArgs& a, unsigned n_cu, hipStream_t
 hipError_t launch_orbit_rms(const RmsArgs& a, bool slow_list, hipStream_t s) {
   if (a.I.n_cand == 0) return hipSuccess;
   if (slow_list) {
-    // the list length lives on the device: a grid of at most 8 workgroups per CU strides over it
-    const unsigned long long want = (a.I.n_cand + 255) / 256;
-    const unsigned grid = (unsigned)(want < 2048ull ? want : 2048ull);
-    hipLaunchKernelGGL(k_orbit_rms<true>, dim3(grid), dim3(256), 0, s, a);
+    const unsigned grid = (unsigned)((a.I.n_cand + 255) / 256);  // the list length lives on the device
+    if (a.math_mode == kMathGlibc) hipLaunchKernelGGL((k_orbit_rms<true, true>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_orbit_rms<true, false>), dim3(grid), dim3(256), 0, s, a);
   } else {
     static const bool wave_per_candidate = std::getenv("OUTFIT_RMS_WAVE") != nullptr;  // measurement aid, see k_orbit_rms_wave
     if (wave_per_candidate) {
@@ -1239,7 +1264,8 @@ hipError_t launch_orbit_rms(const RmsArgs& a, bool slow_list, hipStream_t s) {
       return hipGetLastError();
     }
     const unsigned grid = (unsigned)((a.I.n_cand + 255) / 256);
-    hipLaunchKernelGGL(k_orbit_rms<false>, dim3(grid), dim3(256), 0, s, a);
+    if (a.math_mode == kMathGlibc) hipLaunchKernelGGL((k_orbit_rms<false, true>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_orbit_rms<false, false>), dim3(grid), dim3(256), 0, s, a);
   }
   return hipGetLastError();
 }

@@ -1,0 +1,121 @@
+"""glibc 2.35's atan2 / tan / hypot and its STANDALONE sin / cos, restated (oracle/glibcmath2.c, oracle/glibcmath.c
+`orc_glibc_sin1 / cos1`; device/glibcmath2.hpp, glm::sin1 / cos1).
+
+Pins: on a glibc / x86-64 / FMA host the restatements equal the platform libm bit for bit (2 x 10^6 arguments per
+function here; tools/glibc_pin2.c ran 2 x 10^9). The finding of round 3 is asserted too: glibc's sin(x) / cos(x) and
+its sincos(x) are DIFFERENT functions at the last bit (0.07 % of arguments) — the first two are what an isolated
+`x.sin()` of the reference calls, the third what a sin/cos pair on one operand calls (LLVM's FSINCOS combine).
+On the device (-m gpu) the same functions equal the restatement bit for bit.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from test_glibcmath import host_is_glibc_x86_64
+
+dp = C.POINTER(C.c_double)
+N = 2_000_000
+
+
+@pytest.fixture(scope="module")
+def L():
+    lib = O.lib()
+    for name, nargs in (("orc_glibc_sin", 1), ("orc_glibc_cos", 1), ("orc_glibc_sin1", 1), ("orc_glibc_cos1", 1),
+                        ("orc_glibc_tan", 1), ("orc_glibc_atan2", 2), ("orc_glibc_hypot", 2)):
+        f = getattr(lib, name)
+        f.restype, f.argtypes = C.c_double, [C.c_double] * nargs
+    return lib
+
+
+def args(kind, n, seed):
+    rng = np.random.default_rng(seed)
+    if kind == "angle":
+        return np.concatenate([rng.uniform(-40, 40, n // 2), rng.uniform(-7, 7, n // 4), rng.uniform(-1e5, 1e5, n // 8),
+                               rng.uniform(-1, 1, n // 8) * 2.0 ** rng.integers(-30, 2, n // 8)])
+    if kind == "tan":
+        return np.concatenate([rng.uniform(-1.6, 1.6, n // 2), rng.uniform(-25, 25, n // 4),
+                               1.5707963267948966 + rng.uniform(-1, 1, n // 8) * 2.0 ** rng.integers(-40, -3, n // 8),
+                               rng.uniform(-1, 1, n // 8) * 2.0 ** rng.integers(-30, 0, n // 8)])
+    t = rng.uniform(-np.pi, np.pi, n)
+    r = np.exp(rng.uniform(-10, 10, n))
+    y, x = r * np.sin(t), r * np.cos(t)
+    k = n // 4
+    x[:k] = rng.uniform(-2, 2, k) * 2.0 ** rng.integers(-60, 60, k)          # every exponent gap incl. |y/x| ~ 2^+-57
+    y[:k] = x[:k] * rng.uniform(-2, 2, k) * 2.0 ** rng.integers(-62, 62, k)
+    return y, x
+
+
+def vec(f, *a):
+    return np.array([f(*(float(v) for v in row)) for row in zip(*a)])
+
+
+@pytest.mark.skipif(not host_is_glibc_x86_64(), reason="the platform libm is the reference here: needs glibc on x86-64 with FMA")
+def test_restatements_equal_the_platform_libm(L):
+    libm = C.CDLL("libm.so.6")   # the entry points themselves (numpy may route through its own SIMD kernels)
+    for name, nargs in (("sin", 1), ("cos", 1), ("tan", 1), ("atan2", 2), ("hypot", 2)):
+        f = getattr(libm, name)
+        f.restype, f.argtypes = C.c_double, [C.c_double] * nargs
+    n = N // 10
+    x = args("angle", n, 1)
+    assert np.array_equal(vec(L.orc_glibc_sin1, x), vec(libm.sin, x))
+    assert np.array_equal(vec(L.orc_glibc_cos1, x), vec(libm.cos, x))
+    t = args("tan", n, 2)
+    assert np.array_equal(vec(L.orc_glibc_tan, t), vec(libm.tan, t))
+    y, xx = args("pair", n, 3)
+    assert np.array_equal(vec(L.orc_glibc_atan2, y, xx), vec(libm.atan2, y, xx))
+    assert np.array_equal(vec(L.orc_glibc_hypot, y, xx), vec(libm.hypot, y, xx))
+
+
+@pytest.mark.skipif(not host_is_glibc_x86_64(), reason="needs glibc on x86-64 with FMA")
+def test_glibc_sin_and_sincos_are_different_functions(L):
+    """sincos(x) (one SSE2 variant) and sin(x) / cos(x) (FMA variants) of glibc 2.35 disagree in the last bit for
+    0.03 - 0.2 % of arguments; the two restatements reproduce their respective originals exactly."""
+    libm = C.CDLL("libm.so.6")
+    libm.sincos.argtypes = [C.c_double, dp, dp]
+    libm.sin.restype = libm.cos.restype = C.c_double
+    libm.sin.argtypes = libm.cos.argtypes = [C.c_double]
+    x = args("angle", 400_000, 4)
+    s, c = C.c_double(), C.c_double()
+    differ = 0
+    for v in x:
+        v = float(v)
+        libm.sincos(v, C.byref(s), C.byref(c))
+        a, b = libm.sin(v), libm.cos(v)
+        assert (s.value, c.value) == (L.orc_glibc_sin(v), L.orc_glibc_cos(v))      # the sincos-equivalent restatement
+        assert (a, b) == (L.orc_glibc_sin1(v), L.orc_glibc_cos1(v))                # the standalone restatement
+        differ += (a != s.value) + (b != c.value)
+    assert 0.0002 * 2 * len(x) < differ < 0.003 * 2 * len(x), differ
+
+
+@pytest.mark.gpu
+def test_device_functions_equal_the_restatement(L):
+    from outfit_amd import _lib
+    H = _lib.lib()
+    n = 400_000
+
+    def dev(fn, x, y=None):
+        x = np.ascontiguousarray(x)
+        out = np.empty_like(x)
+        yy = None if y is None else np.ascontiguousarray(y)
+        rc = H.outfit_hip_glibc_eval(fn, len(x), x.ctypes.data_as(dp), None if yy is None else yy.ctypes.data_as(dp),
+                                     out.ctypes.data_as(dp))
+        assert rc == 0, _lib.last_error()
+        return out
+    x = args("angle", n, 11)
+    assert np.array_equal(dev(0, x).view(np.uint64), vec(L.orc_glibc_sin1, x).view(np.uint64))
+    assert np.array_equal(dev(1, x).view(np.uint64), vec(L.orc_glibc_cos1, x).view(np.uint64))
+    t = args("tan", n, 12)
+    assert np.array_equal(dev(2, t).view(np.uint64), vec(L.orc_glibc_tan, t).view(np.uint64))
+    y, xx = args("pair", n, 13)
+    assert np.array_equal(dev(3, y, xx).view(np.uint64), vec(L.orc_glibc_atan2, y, xx).view(np.uint64))
+    assert np.array_equal(dev(4, y, xx).view(np.uint64), vec(L.orc_glibc_hypot, y, xx).view(np.uint64))
+    # special values of atan2 (e_atan2.c's prologue) and hypot
+    sp = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, -1.0, 1e-320, 1e308])
+    yy, xs = np.meshgrid(sp, sp)
+    yy, xs = yy.ravel(), xs.ravel()
+    a, b = dev(3, yy, xs), vec(L.orc_glibc_atan2, yy, xs)
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)].view(np.uint64), b[~np.isnan(b)].view(np.uint64))
+    a, b = dev(4, yy, xs), vec(L.orc_glibc_hypot, yy, xs)
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)].view(np.uint64), b[~np.isnan(b)].view(np.uint64))

@@ -70,7 +70,8 @@ def test_glibc_mode_against_the_reference_faithful_oracle(label, n, kw):
     # 1. device(glibc mode) == oracle(restated mode): every field but rms the same bytes
     ref_restated = oracle(params, batch, ephem, glibc=1)
     d0 = distance(dev_glibc, ref_restated)
-    assert d0["bit_identical"] == d0["orbits"], d0
+    assert d0["bit_identical"] == d0["orbits"] == d0["rms_identical"], d0
+    assert dev_glibc.tobytes() == ref_restated.tobytes()             # round 3: every byte of every record, `rms` included
     report = {"case": label, "device_glibc_vs_oracle_restated": d0}
     # 2. against the platform libm (= what the reference computes on this host, when it is glibc)
     if host_is_glibc_x86_64():
@@ -80,7 +81,9 @@ def test_glibc_mode_against_the_reference_faithful_oracle(label, n, kw):
         report["device_glibc_vs_oracle_libm"] = d1
         report["device_cr_vs_oracle_libm"] = d2
         assert d1["beyond_len"] == 0 and d1["beyond_ang"] == 0, d1      # the north-star tolerance, every orbit
-        assert d1["bit_identical"] >= 0.98 * d1["orbits"], d1            # the rest: glibc's atan2/acos/log last places
+        assert d1["bit_identical"] >= 0.999 * d1["orbits"], d1           # the rest: glibc's acos / log last places (not restated)
+        same = (dev_glibc["elem"] == ref_libm["elem"]).all(axis=1)
+        assert np.array_equal(dev_glibc["rms"][same], ref_libm["rms"][same])   # the selection key: the platform libm's bits
         assert d2["beyond_ang"] <= 0.03 * d2["orbits"], d2               # the default mode's measured distance
     os.makedirs(os.path.join(os.path.dirname(__file__), "..", "gpurun_out"), exist_ok=True)
     with open(os.path.join(os.path.dirname(__file__), "..", "gpurun_out", "glibc_mode_distance.jsonl"), "a") as f:

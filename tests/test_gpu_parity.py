@@ -5,7 +5,9 @@ Tolerance (BASELINE.json north_star): returned Keplerian elements within 1e-10 A
 epoch within 1e-10 d. Integer outputs (status, cause, stage, kind, attempts, n_triplets,
 best_triplet) must match exactly.
 
-The `rms` field is the one output whose functions differ between device and oracle (per-observation
+In the glibc-faithful math mode (the default) every field incl. `rms` is bit-identical (round 3: glibc's atan2, tan,
+hypot, standalone sin / cos restated on both sides). In the correctly-rounded mode the `rms` field is the one output
+whose functions differ between device and oracle (per-observation
 atan2 / hypot / sincos: ROCm's on the device, the platform libm in the oracle, as in the reference); the
 differences alpha_obs - alpha amplify a last place by ~1e6. Measured on 1.5e6 objects:
 median 6e-12 relative, 99 % below 5e-11, worst 2.8e-7 (orbits with a ~ 1000 AU). The bound asserted here
@@ -57,6 +59,10 @@ def compare(got, ref, allow_flips=0):
         assert np.array_equal(g["elem"], r["elem"]), "elements are not bit-identical"
         assert np.abs(g["epoch"] - r["epoch"]).max() <= 1e-10
         d_rms = np.abs(g["rms"] - r["rms"]) / np.maximum(1.0, r["rms"])
+        if outfit_amd.get_math_mode() == outfit_amd.MATH_GLIBC:
+            # glibc-faithful mode (round 3): the whole candidate -> RMS chain runs on restated glibc functions on both
+            # sides — the selection key itself is the same bits
+            assert np.array_equal(g["rms"], r["rms"]), f"{int((g['rms'] != r['rms']).sum())} rms values differ"
         assert d_rms.max() <= RMS_TOL, d_rms.max()
         assert (d_rms <= RMS_TOL_TYPICAL).mean() >= 0.999 or (d_rms > RMS_TOL_TYPICAL).sum() <= 1, (d_rms > RMS_TOL_TYPICAL).sum()
     return flips

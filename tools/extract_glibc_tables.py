@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Tables of glibc 2.35's table-driven atan2 and tan (IBM Accurate Mathematical Library, sysdeps/ieee754/dbl-64/
+e_atan2.c `cij`, s_tan.c `xfg`), read out of the installed libm.so.6 for the glibc-faithful restatement
+(oracle/glibcmath2.c, outfit_amd/csrc/device/glibcmath2.hpp).
+
+Unlike the sin/cos and exp tables (tools/gen_glibc_tables.py, regenerated with mpmath) these cannot be regenerated:
+their nodes x_i are "accurate table" points chosen by a search so that atan(x_i) / tan(x_i) are unusually close to
+doubles. They are mathematical constants of a third-party library (glibc, LGPL-2.1) that the reference links against
+at run time; what is taken is data (241 x 7 and 186 x 4 doubles), located by the addresses the machine code of
+__ieee754_atan2_fma / __tan_fma loads them from, in the exact build named below. The values are sanity-checked
+against math.atan / math.tan before anything is written, and the restatement built on them is pinned against the
+platform's atan2 / tan bit for bit (tests/test_glibcmath2.py).
+
+Usage: python tools/extract_glibc_tables.py [/lib/x86_64-linux-gnu/libm.so.6]
+"""
+import hashlib
+import math
+import os
+import struct
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBM = sys.argv[1] if len(sys.argv) > 1 else "/lib/x86_64-linux-gnu/libm.so.6"
+KNOWN = {  # sha256 of libm.so.6 -> (cij file offset, xfg file offset, description)
+    "e5141752c850ea45691513faadc577133fedf77bcbf19473f97e7247561254b2":
+        (0xbe0e0, 0xc15c0, "Ubuntu GLIBC 2.35-0ubuntu3.12, x86-64, Build ID df46fc5774ae8aaaf6efcb97dc7b91532056b898"),
+}
+
+
+def main():
+    data = open(LIBM, "rb").read()
+    sha = hashlib.sha256(data).hexdigest()
+    if sha not in KNOWN:
+        raise SystemExit(f"{LIBM}: unknown build (sha256 {sha}); the table offsets are known for: "
+                         + "; ".join(v[2] for v in KNOWN.values()))
+    off_cij, off_xfg, what = KNOWN[sha]
+    cij = [struct.unpack("<7d", data[off_cij + 56 * i: off_cij + 56 * i + 56]) for i in range(241)]
+    xfg = [struct.unpack("<4d", data[off_xfg + 32 * i: off_xfg + 32 * i + 32]) for i in range(186)]
+    # what the tables are: cij[i] = x_i, atan(x_i), then the Taylor coefficients of atan at x_i; x_i ~ (i + 16.25) / 256
+    for i, r in enumerate(cij):
+        assert abs(r[0] - (i + 16.25) / 256) < 2e-3 and abs(math.atan(r[0]) - r[1]) < 1e-16 and abs(r[2] - 1 / (1 + r[0] ** 2)) < 1e-15, i
+    # xfg[i] = x_i, tan(x_i), cot(x_i), low part of cot(x_i); x_i ~ (i + 16) / 256
+    for i, r in enumerate(xfg):
+        assert abs(r[0] - (i + 16) / 256) < 1e-6 and abs(math.tan(r[0]) - r[1]) < 2e-16 and abs(1 / math.tan(r[0]) - r[2]) < 4e-15, i
+    header = (f"glibc 2.35 atan2 `cij` (241 x 7) and tan `xfg` (186 x 4) tables, extracted by tools/extract_glibc_tables.py\n"
+              f"from {what} (sha256 {sha[:16]}...). Data of a third-party library (glibc, LGPL-2.1); see the tool.")
+
+    def rows(tab):
+        return ",\n".join("  {" + ", ".join(float.hex(v) for v in r) + "}" for r in tab)
+    c = ("/* " + header.replace("\n", "\n * ") + " */\n#pragma once\n"
+         f"static const double orc_glibc_cij[241][7] = {{\n{rows(cij)}\n}};\n"
+         f"static const double orc_glibc_xfg[186][4] = {{\n{rows(xfg)}\n}};\n")
+    open(os.path.join(ROOT, "oracle", "glibc_tables2.h"), "w").write(c)
+    d = ("// " + header.replace("\n", "\n// ") + "\n#pragma once\nnamespace outfit {\nnamespace glm {\n"
+         f"__device__ const double kCij[241][7] = {{\n{rows(cij)}\n}};\n"
+         f"__device__ const double kXfg[186][4] = {{\n{rows(xfg)}\n}};\n}}  // namespace glm\n}}  // namespace outfit\n")
+    open(os.path.join(ROOT, "outfit_amd", "csrc", "device", "glibc_tables2.hpp"), "w").write(d)
+    print("wrote oracle/glibc_tables2.h and outfit_amd/csrc/device/glibc_tables2.hpp from", what)
+
+
+if __name__ == "__main__":
+    main()
