@@ -237,11 +237,11 @@ struct DevBuf {
   }
 };
 
-enum KernelId { K_TRIPLETS = 0, K_PREPASS, K_ROOTS, K_CORRECT_FAST, K_CORRECT, K_RMS, K_RMS_SLOW, K_SELECT, K_DIFFCOR, K_COUNT };
+enum KernelId { K_TRIPLETS = 0, K_PREPASS, K_ROOTS, K_CORRECT_FAST, K_CORRECT, K_RMS, K_RMS_SLOW, K_SELECT, K_REFINE, K_DIFFCOR, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"k_triplet_select", "k_observer_prepass",   "k_gauss_roots",
                                            "k_gauss_correct_fast", "k_gauss_correct",
                                            "k_orbit_rms",      "k_orbit_rms_slow",     "k_select_best",
-                                           "k_diffcor"};
+                                           "k_refine_best",    "k_diffcor"};
 
 }  // namespace
 
@@ -789,7 +789,9 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
       HIP_TRY(outfit::launch_gauss_correct(cg, s->n_cu, aux));
     }
     HIP_TRY(hipEventRecord(s->ev_general, aux));
-    const outfit::RmsArgs rm{ci, w, obs_pos, s->cos_dec.p, s->params.extf, s->params.dtmax, outfit::sincos_consts(), s->math_mode};
+    static const bool exact_all_env = std::getenv("OUTFIT_RMS_EXACT_ALL") != nullptr;  // verification aid (kernels.hip, K3b)
+    const bool exact_all = exact_all_env && s->math_mode == OUTFIT_MATH_GLIBC;
+    const outfit::RmsArgs rm{ci, w, obs_pos, s->cos_dec.p, s->params.extf, s->params.dtmax, outfit::sincos_consts(), exact_all ? 1 : 0};
     HIP_TRY(hipStreamWaitEvent(st, s->ev_prepass, 0));
     {
       Stamp stamp(s, st, K_RMS);
@@ -808,6 +810,10 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
     {
       Stamp stamp(s, st, K_SELECT);
       HIP_TRY(outfit::launch_select_best(sa, st));
+    }
+    if (s->math_mode == OUTFIT_MATH_GLIBC && !exact_all) {  // K3b: the contenders, exactly (glibc's functions)
+      Stamp stamp(s, st, K_REFINE);
+      HIP_TRY(outfit::launch_refine_best(sa, rm, st));
     }
     HIP_TRY(hipEventRecord(s->ev_k3[tb], st));
     s->k3_recorded[tb] = true;

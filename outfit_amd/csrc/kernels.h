@@ -128,7 +128,8 @@ struct RmsArgs {
   const double* cos_dec;
   double extf, dtmax;
   SinCosConsts sc;  // polynomial constants as kernel arguments = scalar registers (device/orbit.hpp)
-  int math_mode;    // kMathGlibc: the whole candidate -> RMS chain on glibc's bits (k_orbit_rms<.., true>)
+  int exact_all;    // 1: every candidate with the glibc-faithful functions (k_orbit_rms<.., true>; OUTFIT_RMS_EXACT_ALL=1)
+                    // 0: platform functions; in OUTFIT_MATH_GLIBC k_refine_best then re-evaluates the contenders exactly
 };
 
 struct SelectArgs {
@@ -178,6 +179,7 @@ hipError_t launch_gauss_correct_fast(const CorrectArgs& a, unsigned n_cu, hipStr
 hipError_t launch_gauss_correct(const CorrectArgs& a, unsigned n_cu, hipStream_t s);
 hipError_t launch_orbit_rms(const RmsArgs& a, bool slow_list, hipStream_t s);
 hipError_t launch_select_best(const SelectArgs& a, hipStream_t s);
+hipError_t launch_refine_best(const SelectArgs& a, const RmsArgs& r, hipStream_t s);
 constexpr unsigned kDiffcorMaxGroup = 8;  // lanes that may share one trajectory in k_diffcor
 hipError_t launch_diffcor(const DiffCorArgs& a, unsigned group, unsigned n_cu, hipStream_t s);
 hipError_t launch_observer_geometry(const GeometryArgs& a, hipStream_t s);

@@ -848,6 +848,155 @@ k_select_best(SelectArgs a) {
 }
 
 // ------------------------------------------------------------------------------
+// K3b (glibc-faithful mode): exact re-evaluation of the contenders.
+//
+// In OUTFIT_MATH_GLIBC the selection key — the RMS of estimate_best_orbit's fold (trajectory.rs:455-544) — must be the
+// bits a glibc run of the reference computes, which takes glibc's atan2 / hypot / tan / sincos (glibcmath*.hpp): ~2.2x
+// the instructions of the platform functions in the residual loop (measured: K2c 5.7 -> 12.5 ms per 10^7 candidates).
+// Two stages instead: K2c screens every candidate with the platform functions (relative error of an RMS ~1e-11,
+// worst ever observed 2.8e-7), K3 folds those values, and this kernel re-evaluates EXACTLY — with the glibc-faithful
+// functions — every candidate whose screened RMS lies within kContenderWindow (1e-4 relative) of the screened minimum
+// (1.004 candidates per trajectory on the bench workload) and keeps the smallest (rms, index), i.e. the first minimum
+// of the reference's strict-`<` fold. The winner, its `rms` and its elements are then those of the exhaustive exact
+// evaluation as long as no contender's screening error reaches half the window (5e-5: 180 x the worst error ever
+// seen, 5 x 10^6 x the typical one); OUTFIT_RMS_EXACT_ALL=1 runs the exhaustive evaluation instead, and
+// tests/test_gpu_glibc_mode.py holds the two against each other byte for byte on 135 000 trajectories.
+// Four lanes per trajectory (a lane per trajectory was a 45 k-instruction chain on 1.5 waves per SIMD: 1.6 ms;
+// four lanes 0.6 ms, of which the contender scan is 0.04 ms).
+// ------------------------------------------------------------------------------
+constexpr unsigned kMaxContenders = 8;
+#ifndef OUTFIT_CONTENDER_WINDOW
+#define OUTFIT_CONTENDER_WINDOW 1.0e-4
+#endif
+constexpr double kContenderWindow = OUTFIT_CONTENDER_WINDOW;
+constexpr unsigned kRefineGroup = 4;                      // lanes per trajectory
+constexpr unsigned kRefineTraj = 64 / kRefineGroup;       // trajectories per wave
+
+// rms_orbit_error of one candidate with the glibc-faithful functions, evaluated by the kRefineGroup lanes of a group:
+// lane `sub` takes the observations i_start + sub, + kRefineGroup, ...; the terms are then added one after the other in
+// observation order by every lane (the reference's left fold, bit for bit). NaN = the candidate cannot be selected
+// (conversion error, e >= 1, an Err of ephemeris_error). The prologue is evaluated redundantly by the lanes.
+__device__ __forceinline__ double exact_candidate_rms(const RmsArgs& a, unsigned long long cid, unsigned sub,
+                                                      unsigned group_base) {
+  const unsigned long long n = a.I.n_cand;
+  const CandidateRef c = decode_candidate(a.I, cid);
+  const Vec3 r2 = {a.W.state[0 * n + cid], a.W.state[1 * n + cid], a.W.state[2 * n + cid]};
+  const Vec3 v2 = {a.W.state[3 * n + cid], a.W.state[4 * n + cid], a.W.state[5 * n + cid]};
+  Equinoctial eq;
+  {
+    const Elements el = ccek1<kFnGlibc>(equ_to_ecl(r2), equ_to_ecl(v2), a.W.state[6 * n + cid]);
+    if (to_equinoctial<kFnGlibc>(el, eq) != 0) return nan("");
+  }
+  unsigned long long i_start, i_end;
+  select_rms_interval(a.I.mjd + c.base, c.n_obs, c.idx[0], c.idx[2], a.extf, a.dtmax, i_start, i_end);
+  if (sqrt(eq.h * eq.h + eq.k * eq.k) >= 1.0) return nan("");
+  const TwoBodyFrame F = twobody_frame<kFnGlibc>(eq);
+  double acc = 0.0;
+  bool err = false;
+  for (unsigned long long b0 = i_start; b0 <= i_end && !err; b0 += kRefineGroup) {
+    const unsigned long long i = b0 + sub;
+    double term = 0.0;
+    int bad = 0;
+    if (i <= i_end) {
+      const unsigned long long o = c.base + i;
+      const Vec3 op = {a.obs_pos[3 * o], a.obs_pos[3 * o + 1], a.obs_pos[3 * o + 2]};
+      bad = !ephemeris_error<kFnGlibc>(eq, F, a.I.mjd[o], a.I.ra[o], a.I.dec[o], a.cos_dec[o], a.I.sra[o], a.I.sdec[o],
+                                       op, term, nullptr);
+    }
+    const unsigned cnt = (unsigned)((i_end - b0 + 1) < kRefineGroup ? (i_end - b0 + 1) : kRefineGroup);
+    for (unsigned k = 0; k < cnt; ++k) {
+      if (__shfl(bad, (int)(group_base + k))) { err = true; break; }
+      acc = acc + __shfl(term, (int)(group_base + k));
+    }
+  }
+  return err ? nan("") : sqrt(acc / (2.0 * (double)(i_end - i_start + 1)));
+}
+
+__global__ void __launch_bounds__(64, 2)
+k_refine_best(RmsArgs r, GaussResultRec* out_all, unsigned long long n_traj) {
+  __shared__ unsigned s_cont[kRefineTraj][kMaxContenders];
+  __shared__ unsigned s_count[kRefineTraj];
+  __shared__ double s_window[kRefineTraj];
+  __shared__ unsigned s_nc[kRefineTraj];
+  const unsigned tl = threadIdx.x, g = tl / kRefineGroup, sub = tl % kRefineGroup, group_base = g * kRefineGroup;
+  const unsigned long long blk0 = (unsigned long long)blockIdx.x * kRefineTraj;
+  const unsigned long long lt = blk0 + g;
+  const bool live = lt < n_traj;
+  const bool ok = live && out_all[r.I.traj0 + lt].status == 0;
+  if (sub == 0) {
+    s_count[g] = 0u;
+    s_window[g] = ok ? out_all[r.I.traj0 + lt].rms * (1.0 + kContenderWindow) : -1.0;
+    s_nc[g] = ok ? r.I.n_triplets[lt] * r.I.n_real : 0u;
+  }
+  __syncthreads();
+  // 1. the contenders of the wave's trajectories: candidates whose screened RMS is within the window of the screened
+  //    minimum. The 64 lanes sweep one trajectory's candidates at a time (coalesced); the list is unordered.
+  for (unsigned t = 0; t < kRefineTraj; ++t) {
+    const unsigned n_c = s_nc[t];
+    const double window = s_window[t];
+    const unsigned long long row = (blk0 + t) * r.I.cand_per_traj;
+    for (unsigned c = tl; c < n_c; c += 64u) {
+      const unsigned f = r.W.flags[row + c];
+      if (!(f & kFlagOk) || ((f >> kFlagConvShift) & 0x7u) || (f & kFlagRmsErr)) continue;
+      const double screened = sqrt(r.W.sum[row + c] / (2.0 * (double)r.W.n_win[row + c]));
+      if (!(screened <= window)) continue;
+      const unsigned slot = atomicAdd(&s_count[t], 1u);
+      if (slot < kMaxContenders) s_cont[t][slot] = c;
+    }
+  }
+  __syncthreads();
+#ifdef OUTFIT_REFINE_SCAN_ONLY  // measurement aid
+  return;
+#endif
+  // 2. exact evaluation: the k-th contender of every trajectory of the wave in lockstep (one call site: the function
+  //    is ~12 k instructions per lane). The winner is the smallest (rms, index): the first minimum of the fold.
+  const unsigned long long c0 = lt * r.I.cand_per_traj;
+  const unsigned n_list = ok ? (s_count[g] < kMaxContenders ? s_count[g] : kMaxContenders) : 0u;
+  const bool overflow = ok && s_count[g] > kMaxContenders;
+  double best = INFINITY;
+  long long best_c = -1;
+  unsigned scan = 0;  // overflow (more contenders than slots; not seen on any workload): the group walks ALL its candidates
+  for (unsigned k = 0;; ++k) {
+    long long c = -1;
+    if (ok && !overflow) {
+      if (k < n_list) c = (long long)s_cont[g][k];
+    } else if (overflow) {
+      for (; scan < s_nc[g] && c < 0; ++scan) {
+        const unsigned long long cid = c0 + scan;
+        const unsigned f = r.W.flags[cid];
+        if (!(f & kFlagOk) || ((f >> kFlagConvShift) & 0x7u) || (f & kFlagRmsErr)) continue;
+        if (sqrt(r.W.sum[cid] / (2.0 * (double)r.W.n_win[cid])) <= s_window[g]) c = (long long)scan;
+      }
+    }
+    if (__ballot(c >= 0) == 0ull) break;
+    if (c >= 0) {
+      const double e = exact_candidate_rms(r, c0 + (unsigned long long)c, sub, group_base);
+      if (isfinite(e) && (e < best || (e == best && c < best_c))) { best = e; best_c = c; }
+    }
+  }
+  if (!ok || best_c < 0 || sub != 0) return;  // (no finite exact value: the screened record stands)
+  // the winner's record: build_result -> compute_orbit_from_state -> ccek1 with glibc's bits (K3 filled the counters)
+  const unsigned long long cid = c0 + (unsigned long long)best_c, nc = r.I.n_cand;
+  const unsigned f = r.W.flags[cid];
+  const Vec3 r2 = {r.W.state[0 * nc + cid], r.W.state[1 * nc + cid], r.W.state[2 * nc + cid]};
+  const Vec3 v2 = {r.W.state[3 * nc + cid], r.W.state[4 * nc + cid], r.W.state[5 * nc + cid]};
+  const Elements el = ccek1<kFnGlibc>(equ_to_ecl(r2), equ_to_ecl(v2), r.W.state[6 * nc + cid]);
+  GaussResultRec* out = out_all + r.I.traj0 + lt;
+  out->stage = (f & kFlagCorrected) ? 1 : 0;
+  out->best_triplet = (unsigned)best_c / r.I.n_real;
+  out->best_realization = (unsigned)best_c % r.I.n_real;
+  out->epoch = el.epoch;
+  out->kind = el.kind;
+  for (int k = 0; k < 6; ++k) out->elem[k] = el.e[k];
+  out->rms = best;
+}
+hipError_t launch_refine_best(const SelectArgs& a, const RmsArgs& r, hipStream_t s) {
+  if (a.n_traj == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_refine_best, dim3((unsigned)((a.n_traj + kRefineTraj - 1) / kRefineTraj)), dim3(64), 0, s, r, a.out, a.n_traj);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------
 // kepler::propagate_universal, batched
 // ------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
@@ -1255,7 +1404,7 @@ hipError_t launch_orbit_rms(const RmsArgs& a, bool slow_list, hipStream_t s) {
   if (a.I.n_cand == 0) return hipSuccess;
   if (slow_list) {
     const unsigned grid = (unsigned)((a.I.n_cand + 255) / 256);  // the list length lives on the device
-    if (a.math_mode == kMathGlibc) hipLaunchKernelGGL((k_orbit_rms<true, true>), dim3(grid), dim3(256), 0, s, a);
+    if (a.exact_all) hipLaunchKernelGGL((k_orbit_rms<true, true>), dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((k_orbit_rms<true, false>), dim3(grid), dim3(256), 0, s, a);
   } else {
     static const bool wave_per_candidate = std::getenv("OUTFIT_RMS_WAVE") != nullptr;  // measurement aid, see k_orbit_rms_wave
@@ -1264,7 +1413,7 @@ hipError_t launch_orbit_rms(const RmsArgs& a, bool slow_list, hipStream_t s) {
       return hipGetLastError();
     }
     const unsigned grid = (unsigned)((a.I.n_cand + 255) / 256);
-    if (a.math_mode == kMathGlibc) hipLaunchKernelGGL((k_orbit_rms<false, true>), dim3(grid), dim3(256), 0, s, a);
+    if (a.exact_all) hipLaunchKernelGGL((k_orbit_rms<false, true>), dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((k_orbit_rms<false, false>), dim3(grid), dim3(256), 0, s, a);
   }
   return hipGetLastError();
