@@ -183,11 +183,13 @@ int  outfit_hip_iod_params_validate(const outfit_iod_params_t *p);
  * (direction cosines gauss.rs:488-502, cold starts prelim_elliptic.rs / prelim_hyperbolic.rs, the rotations of
  * orb_elem.rs:58-226). The reference calls the platform libm there, so its own results depend on that libm; the
  * loop amplifies a last-place difference to ~1e-10.
- *   OUTFIT_MATH_GLIBC (default): sin, cos, sinh, cosh return the bits of glibc 2.35 on x86-64 (restated,
- *       device/glibcmath.hpp) — what the reference computes on the platform its known answers were recorded on;
- *       acos, log, atan2 are correctly rounded (glibc's differ from that for 7e-4 / 2e-4 / 9e-4 of arguments).
- *       Measured against the reference's arithmetic on glibc: integer outputs identical, no orbit beyond
- *       1e-10 AU, 3 of 652 670 beyond 1e-12 rad (2-7e-12; tests/test_gpu_glibc_mode.py).
+ *   OUTFIT_MATH_GLIBC (default): sin, cos (the sincos pair AND the standalone entry points, which differ in glibc),
+ *       sinh, cosh, atan2, tan, hypot return the bits of glibc 2.35 on x86-64 with FMA (restated, device/glibcmath.hpp,
+ *       glibcmath2.hpp) — what the reference computes on the platform its known answers were recorded on; acos and log
+ *       (cold starts only) are correctly rounded. The RMS of every candidate is screened with the platform functions and
+ *       the contenders (within 1e-4 of the screened minimum) are re-evaluated with glibc's (kernel K3b). Measured against
+ *       the reference's arithmetic on glibc (the CPU restatement with the platform libm): 300 000 of 300 000 records
+ *       byte-identical, `rms` included (profiles/round03_parity_glibc_bench_300000.json).
  *   OUTFIT_MATH_CORRECTLY_ROUNDED: every such function correctly rounded — platform independent (what a reference
  *       built against another libm would be compared with); against a glibc run of the reference ~0.8 % of the
  *       orbits move by more than 1e-12 rad.

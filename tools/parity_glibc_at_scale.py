@@ -53,14 +53,15 @@ def distance(got, ref):
     d[:, 2:] = np.minimum(d[:, 2:], np.abs(2 * np.pi - d[:, 2:]))
     dl, da = d[:, :2].max(1), d[:, 2:].max(1)
     return {"orbits": int((ref["status"] == 0).sum()), "different_integer_outputs": int((~same).sum()),
+            "byte_identical_records": int(sum(got[i].tobytes() == ref[i].tobytes() for i in range(n))),
+            "bit_identical_rms": int((got["rms"][ok] == ref["rms"][ok]).sum()),
             "bit_identical": int((got["elem"][ok] == ref["elem"][ok]).all(1).sum()),
             "beyond_1e-10_AU": int((dl > 1e-10).sum()), "beyond_1e-12_rad": int((da > 1e-12).sum()),
             "max_len": float(dl.max()), "max_ang": float(da.max())}
 
 
-with outfit_amd.math_mode(outfit_amd.MATH_GLIBC):
-    dev_g = outfit_amd.fit_full_iod_records(batch, ephem, params, n_devices=1)
-dev_c = outfit_amd.fit_full_iod_records(batch, ephem, params, n_devices=1)
+dev_g = outfit_amd.fit_full_iod_records(batch, ephem, params, n_devices=1, math_mode=outfit_amd.MATH_GLIBC)
+dev_c = outfit_amd.fit_full_iod_records(batch, ephem, params, n_devices=1, math_mode=outfit_amd.MATH_CORRECTLY_ROUNDED)
 ref_libm = oracle(1, 0)
 ref_rest = oracle(0, 1)
 out = {"objects": n, "seed": seed, "mode": mode, "glibc": os.confstr("CS_GNU_LIBC_VERSION"),
