@@ -861,10 +861,10 @@ k_select_best(SelectArgs a) {
 // evaluation as long as no contender's screening error reaches half the window (5e-5: 180 x the worst error ever
 // seen, 5 x 10^6 x the typical one); OUTFIT_RMS_EXACT_ALL=1 runs the exhaustive evaluation instead, and
 // tests/test_gpu_glibc_mode.py holds the two against each other byte for byte on 135 000 trajectories.
-// Four lanes per trajectory (a lane per trajectory was a 45 k-instruction chain on 1.5 waves per SIMD: 1.6 ms;
-// four lanes 0.6 ms, of which the contender scan is 0.04 ms).
+// Four lanes per evaluation (a lane per trajectory was a 45 k-instruction chain on 1.5 waves per SIMD: 1.6 ms;
+// four lanes 0.6 ms, of which the contender scan is 0.04 ms), and the contenders of a wave's sixteen trajectories form
+// one work list, so a trajectory with many of them is spread over the wave.
 // ------------------------------------------------------------------------------
-constexpr unsigned kMaxContenders = 8;
 #ifndef OUTFIT_CONTENDER_WINDOW
 #define OUTFIT_CONTENDER_WINDOW 1.0e-4
 #endif
@@ -912,10 +912,15 @@ __device__ __forceinline__ double exact_candidate_rms(const RmsArgs& a, unsigned
   return err ? nan("") : sqrt(acc / (2.0 * (double)(i_end - i_start + 1)));
 }
 
+#ifdef OUTFIT_REFINE_STATS  // diagnostic build: trajectories, contenders, list flushes, largest list of one wave
+__device__ unsigned long long g_refine_stats[4];
+#endif
+constexpr unsigned kRefineList = 256;  // contenders a wave holds between two evaluation passes
 __global__ void __launch_bounds__(64, 2)
 k_refine_best(RmsArgs r, GaussResultRec* out_all, unsigned long long n_traj) {
-  __shared__ unsigned s_cont[kRefineTraj][kMaxContenders];
-  __shared__ unsigned s_count[kRefineTraj];
+  __shared__ unsigned s_item_c[kRefineList];      // candidate index within its trajectory
+  __shared__ unsigned char s_item_t[kRefineList]; // trajectory of the wave (0..kRefineTraj-1)
+  __shared__ double s_item_rms[kRefineList];      // its exact RMS (NaN: cannot be selected)
   __shared__ double s_window[kRefineTraj];
   __shared__ unsigned s_nc[kRefineTraj];
   const unsigned tl = threadIdx.x, g = tl / kRefineGroup, sub = tl % kRefineGroup, group_base = g * kRefineGroup;
@@ -924,56 +929,76 @@ k_refine_best(RmsArgs r, GaussResultRec* out_all, unsigned long long n_traj) {
   const bool live = lt < n_traj;
   const bool ok = live && out_all[r.I.traj0 + lt].status == 0;
   if (sub == 0) {
-    s_count[g] = 0u;
     s_window[g] = ok ? out_all[r.I.traj0 + lt].rms * (1.0 + kContenderWindow) : -1.0;
     s_nc[g] = ok ? r.I.n_triplets[lt] * r.I.n_real : 0u;
   }
   __syncthreads();
-  // 1. the contenders of the wave's trajectories: candidates whose screened RMS is within the window of the screened
-  //    minimum. The 64 lanes sweep one trajectory's candidates at a time (coalesced); the list is unordered.
-  for (unsigned t = 0; t < kRefineTraj; ++t) {
-    const unsigned n_c = s_nc[t];
-    const double window = s_window[t];
-    const unsigned long long row = (blk0 + t) * r.I.cand_per_traj;
-    for (unsigned c = tl; c < n_c; c += 64u) {
-      const unsigned f = r.W.flags[row + c];
-      if (!(f & kFlagOk) || ((f >> kFlagConvShift) & 0x7u) || (f & kFlagRmsErr)) continue;
-      const double screened = sqrt(r.W.sum[row + c] / (2.0 * (double)r.W.n_win[row + c]));
-      if (!(screened <= window)) continue;
-      const unsigned slot = atomicAdd(&s_count[t], 1u);
-      if (slot < kMaxContenders) s_cont[t][slot] = c;
-    }
-  }
-  __syncthreads();
-#ifdef OUTFIT_REFINE_SCAN_ONLY  // measurement aid
-  return;
-#endif
-  // 2. exact evaluation: the k-th contender of every trajectory of the wave in lockstep (one call site: the function
-  //    is ~12 k instructions per lane). The winner is the smallest (rms, index): the first minimum of the fold.
-  const unsigned long long c0 = lt * r.I.cand_per_traj;
-  const unsigned n_list = ok ? (s_count[g] < kMaxContenders ? s_count[g] : kMaxContenders) : 0u;
-  const bool overflow = ok && s_count[g] > kMaxContenders;
+  // The wave alternates two phases until its kRefineTraj trajectories are exhausted:
+  //  1. scan: the 64 lanes sweep one trajectory's candidates at a time (coalesced) and append the contenders —
+  //     screened RMS within the window of the screened minimum — to ONE list of the wave (ballot compaction, the
+  //     count is wave-uniform), until the list could overflow on the next sweep;
+  //  2. evaluate: the groups take the list's entries sixteen at a time, whichever trajectory they belong to (one call
+  //     site: the function is ~12 k instructions per lane), then each trajectory's group folds the exact values of its
+  //     entries: the smallest (rms, index) wins, i.e. the first minimum of the reference's strict-`<` fold.
+  // A trajectory with many contenders (seen: 77 of 210 noisy candidates within 1e-4) is thus shared by the whole wave
+  // instead of serialising on its own four lanes (that one trajectory used to cost 3.7 ms of a 4.3 ms launch).
   double best = INFINITY;
   long long best_c = -1;
-  unsigned scan = 0;  // overflow (more contenders than slots; not seen on any workload): the group walks ALL its candidates
-  for (unsigned k = 0;; ++k) {
-    long long c = -1;
-    if (ok && !overflow) {
-      if (k < n_list) c = (long long)s_cont[g][k];
-    } else if (overflow) {
-      for (; scan < s_nc[g] && c < 0; ++scan) {
-        const unsigned long long cid = c0 + scan;
+  unsigned count = 0, t = 0, sweep = 0;  // wave-uniform
+  for (;;) {
+    while (t < kRefineTraj) {
+      const unsigned n_c = s_nc[t];
+      if (sweep >= n_c) { ++t; sweep = 0; continue; }
+      if (count + 64u > kRefineList) break;
+      const unsigned c = sweep + tl;
+      bool is = false;
+      if (c < n_c) {
+        const unsigned long long cid = (blk0 + t) * r.I.cand_per_traj + c;
         const unsigned f = r.W.flags[cid];
-        if (!(f & kFlagOk) || ((f >> kFlagConvShift) & 0x7u) || (f & kFlagRmsErr)) continue;
-        if (sqrt(r.W.sum[cid] / (2.0 * (double)r.W.n_win[cid])) <= s_window[g]) c = (long long)scan;
+        if ((f & kFlagOk) && !((f >> kFlagConvShift) & 0x7u) && !(f & kFlagRmsErr))
+          is = sqrt(r.W.sum[cid] / (2.0 * (double)r.W.n_win[cid])) <= s_window[t];
+      }
+      const unsigned long long mask = __ballot(is);
+      if (is) {
+        const unsigned slot = count + (unsigned)__popcll(mask & ((1ull << tl) - 1ull));
+        s_item_c[slot] = c;
+        s_item_t[slot] = (unsigned char)t;
+      }
+      count += (unsigned)__popcll(mask);
+      sweep += 64u;
+    }
+    if (count == 0u) break;
+    __syncthreads();
+#ifdef OUTFIT_REFINE_STATS
+    if (tl == 0) { atomicAdd(&g_refine_stats[1], (unsigned long long)count); atomicAdd(&g_refine_stats[2], 1ull);
+                   atomicMax(&g_refine_stats[3], (unsigned long long)count); }
+#endif
+#ifndef OUTFIT_REFINE_SCAN_ONLY  // (measurement aid)
+    for (unsigned k0 = 0; k0 < count; k0 += kRefineTraj) {
+      const unsigned k = k0 + g;
+      if (k < count) {
+        const unsigned long long cid = (blk0 + s_item_t[k]) * r.I.cand_per_traj + s_item_c[k];
+        const double e = exact_candidate_rms(r, cid, sub, group_base);
+        if (sub == 0) s_item_rms[k] = e;
       }
     }
-    if (__ballot(c >= 0) == 0ull) break;
-    if (c >= 0) {
-      const double e = exact_candidate_rms(r, c0 + (unsigned long long)c, sub, group_base);
-      if (isfinite(e) && (e < best || (e == best && c < best_c))) { best = e; best_c = c; }
-    }
+    __syncthreads();
+    if (sub == 0)
+      for (unsigned k = 0; k < count; ++k) {
+        if (s_item_t[k] != g) continue;
+        const double e = s_item_rms[k];
+        const long long c = (long long)s_item_c[k];
+        if (isfinite(e) && (e < best || (e == best && c < best_c))) { best = e; best_c = c; }
+      }
+    __syncthreads();
+#endif
+    count = 0u;
+    if (t >= kRefineTraj) break;
   }
+#ifdef OUTFIT_REFINE_STATS
+  if (ok && sub == 0) atomicAdd(&g_refine_stats[0], 1ull);
+#endif
+  const unsigned long long c0 = lt * r.I.cand_per_traj;
   if (!ok || best_c < 0 || sub != 0) return;  // (no finite exact value: the screened record stands)
   // the winner's record: build_result -> compute_orbit_from_state -> ccek1 with glibc's bits (K3 filled the counters)
   const unsigned long long cid = c0 + (unsigned long long)best_c, nc = r.I.n_cand;
@@ -992,7 +1017,14 @@ k_refine_best(RmsArgs r, GaussResultRec* out_all, unsigned long long n_traj) {
 }
 hipError_t launch_refine_best(const SelectArgs& a, const RmsArgs& r, hipStream_t s) {
   if (a.n_traj == 0) return hipSuccess;
+#ifdef OUTFIT_REFINE_STATS
+  { static const unsigned long long z[4] = {}; (void)hipStreamSynchronize(s); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_refine_stats), z, sizeof z); }
+#endif
   hipLaunchKernelGGL(k_refine_best, dim3((unsigned)((a.n_traj + kRefineTraj - 1) / kRefineTraj)), dim3(64), 0, s, r, a.out, a.n_traj);
+#ifdef OUTFIT_REFINE_STATS
+  { unsigned long long h[4] = {}; (void)hipStreamSynchronize(s); (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_refine_stats), sizeof h);
+    fprintf(stderr, "[refine stats] trajectories %llu contenders %llu (%.4f each) list passes %llu largest list of a wave %llu\n", h[0], h[1], h[0] ? (double)h[1] / h[0] : 0.0, h[2], h[3]); }
+#endif
   return hipGetLastError();
 }
 
