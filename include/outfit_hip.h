@@ -262,6 +262,15 @@ int outfit_hip_session_results(outfit_hip_session_t *s, outfit_gauss_result_t *o
 int outfit_hip_session_check(outfit_hip_session_t *s);
 /* Device pointer of the session's own result buffer (n_traj records). */
 void *outfit_hip_session_device_results(outfit_hip_session_t *s);
+/* Diagnostic: the per-candidate scores K2c left for the LAST chunk of the last run (candidate c of the chunk's
+ * trajectory t at t * cand_per_traj + c): the sum of squared normalised residuals over the RMS window, the window's
+ * observation count and the candidate's flag word (0x10 = a preliminary orbit exists, 0x80 = a residual
+ * evaluation failed; see kernels.h). In
+ * OUTFIT_MATH_GLIBC these are the SCREENING values (device/screen.hpp) that k_refine_best starts from; with
+ * OUTFIT_RMS_EXACT_ALL=1 the exact ones — tests hold one against the other. Any of sum / n_win / flags may be NULL;
+ * *n_out = number of candidates of that chunk (also when capacity is too small: OUTFIT_ERR_INVALID_BATCH). */
+int outfit_hip_session_candidate_scores(outfit_hip_session_t *s, uint64_t capacity, double *sum, uint32_t *n_win,
+                                        uint32_t *flags, uint64_t *n_out);
 /* Per-kernel totals since profiling was switched on: summed duration (ms, HIP events
  * recorded on the stream each run was enqueued on) and number of launches. names[i]
  * are static strings; returns the number of kernels reported. Synchronises. */

@@ -76,6 +76,8 @@ def lib():
     L.outfit_hip_session_check.argtypes = [vp]
     L.outfit_hip_session_device_results.argtypes = [vp]
     L.outfit_hip_session_device_results.restype = vp
+    L.outfit_hip_session_candidate_scores.argtypes = [vp, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_uint32),
+                                                      C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
     L.outfit_hip_session_kernel_times.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float),
                                                   C.POINTER(C.c_int)]
     L.outfit_hip_session_set_profiling.argtypes = [vp, C.c_int]
@@ -127,7 +129,7 @@ def lib():
 EXPORTED_SYMBOLS = [
     "outfit_hip_iod_params_default", "outfit_hip_iod_params_validate", "outfit_hip_fit_full_iod",
     "outfit_hip_session_create", "outfit_hip_session_run", "outfit_hip_session_results",
-    "outfit_hip_session_device_results", "outfit_hip_session_check", "outfit_hip_session_kernel_times",
+    "outfit_hip_session_device_results", "outfit_hip_session_candidate_scores", "outfit_hip_session_check", "outfit_hip_session_kernel_times",
     "outfit_hip_session_set_profiling", "outfit_hip_session_destroy", "outfit_hip_propagate_universal",
     "outfit_hip_last_error", "outfit_hip_abi_version", "outfit_hip_device_count",
     "outfit_hip_selftest_division", "outfit_hip_selftest_crmath", "outfit_hip_crmath_eval", "outfit_hip_selftest_aberth", "outfit_hip_device_normals", "outfit_hip_observer_positions", "outfit_hip_diffcor_config_default", "outfit_hip_diffcor_config_validate",

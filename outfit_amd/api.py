@@ -464,6 +464,21 @@ class IODSession:
             _raise_rc(rc)
         return np.frombuffer(out, dtype=RESULT_DTYPE)[:self.n_traj].copy()
 
+    def candidate_scores(self):
+        """Diagnostic (outfit_hip_session_candidate_scores): (sum, n_win, flags) K2c left for the last chunk of the
+        last run, one entry per candidate slot."""
+        n = C.c_uint64(0)
+        self._L.outfit_hip_session_candidate_scores(self._h, 0, None, None, None, C.byref(n))
+        total = int(n.value)
+        total_sum, n_win, flags = np.empty(total), np.empty(total, np.uint32), np.empty(total, np.uint32)
+        if total:
+            rc = self._L.outfit_hip_session_candidate_scores(
+                self._h, total, total_sum.ctypes.data_as(C.POINTER(C.c_double)),
+                n_win.ctypes.data_as(C.POINTER(C.c_uint32)), flags.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(n))
+            if rc != 0:
+                _raise_rc(rc)
+        return total_sum, n_win, flags
+
     def check(self):
         """Synchronise and raise what `results()` would (EphemerisRange) without fetching anything."""
         rc = self._L.outfit_hip_session_check(self._h)

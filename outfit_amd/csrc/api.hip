@@ -273,7 +273,7 @@ struct outfit_hip_session {
   bool noise_device = false;
   unsigned long long noise_seed = 0, traj_key_base = 0;
   DevBuf<double> mjd, ra, dec, sra, sdec, helio, geo, obs_pos, cos_dec, unit[2], noise, coef;
-  DevBuf<double> heap_w, sum, dirS, roots, state, psi0;
+  DevBuf<double> heap_w, sum, dirS, roots, state, psi0, sel_bound;
   DevBuf<unsigned long long> heap_id, triplets[2], queue, slow_list, slow_count;
   DevBuf<unsigned> n_triplets[2], flags, n_win;
   unsigned n_cu = 256;
@@ -333,7 +333,7 @@ struct outfit_hip_session {
     traj_offset.release(); traj_key.release(); mjd.release(); ra.release(); dec.release(); sra.release(); sdec.release();
     helio.release(); geo.release(); obs_pos.release(); cos_dec.release(); unit[0].release(); unit[1].release(); noise.release(); coef.release();
     heap_w.release(); sum.release(); dirS.release(); roots.release(); state.release();
-    psi0.release(); slow_list.release(); slow_count.release();
+    psi0.release(); slow_list.release(); slow_count.release(); sel_bound.release();
     heap_id.release(); triplets[0].release(); triplets[1].release(); queue.release();
     n_triplets[0].release(); n_triplets[1].release(); flags.release();
     n_win.release(); results.release(); error_flag.release();
@@ -603,7 +603,8 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
   HIP_TRY(s->queue.alloc(16));  // [0] fast kernel, [1] general kernel, [2] k_diffcor; [8..15] diagnostic builds
   HIP_TRY(s->psi0.alloc(2 * n_cand));
   HIP_TRY(s->slow_list.alloc(n_cand));
-  HIP_TRY(s->slow_count.alloc(1));
+  HIP_TRY(s->slow_count.alloc(2));
+  HIP_TRY(s->sel_bound.alloc(2 * chunk));
   g_trace.mark("  scratch alloc");
   int n_cu = 0;
   HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, s->device));
@@ -791,7 +792,10 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
     HIP_TRY(hipEventRecord(s->ev_general, aux));
     static const bool exact_all_env = std::getenv("OUTFIT_RMS_EXACT_ALL") != nullptr;  // verification aid (kernels.hip, K3b)
     const bool exact_all = exact_all_env && s->math_mode == OUTFIT_MATH_GLIBC;
-    const outfit::RmsArgs rm{ci, w, obs_pos, s->cos_dec.p, s->params.extf, s->params.dtmax, outfit::sincos_consts(), exact_all ? 1 : 0};
+    static const bool no_screen_env = std::getenv("OUTFIT_RMS_NO_SCREEN") != nullptr;  // measurement aid: exact platform-function K2c + K3b
+    const int rms_mode = s->math_mode != OUTFIT_MATH_GLIBC ? 0 : exact_all ? 1 : no_screen_env ? 0 : 2;
+    const outfit::RmsArgs rm{ci, w, obs_pos, s->cos_dec.p, s->params.extf, s->params.dtmax, outfit::sincos_consts(),
+                             outfit::screen_consts(), rms_mode};
     HIP_TRY(hipStreamWaitEvent(st, s->ev_prepass, 0));
     {
       Stamp stamp(s, st, K_RMS);
@@ -807,11 +811,14 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
     sa.n_real = s->n_real; sa.n_triplets = s->n_triplets[tb].p; sa.W = w;
     sa.out = d_out ? d_out : s->results.p;
     sa.math_mode = s->math_mode;
+    const bool refine = s->math_mode == OUTFIT_MATH_GLIBC && !exact_all;
+    sa.bound = refine ? s->sel_bound.p : nullptr;
+    sa.traj_offset = ci.traj_offset; sa.sra = ci.sra; sa.sdec = ci.sdec;
     {
       Stamp stamp(s, st, K_SELECT);
       HIP_TRY(outfit::launch_select_best(sa, st));
     }
-    if (s->math_mode == OUTFIT_MATH_GLIBC && !exact_all) {  // K3b: the contenders, exactly (glibc's functions)
+    if (refine) {  // K3b: the contenders, exactly (glibc's functions)
       Stamp stamp(s, st, K_REFINE);
       HIP_TRY(outfit::launch_refine_best(sa, rm, st));
     }
@@ -1112,6 +1119,21 @@ int outfit_hip_session_check(outfit_hip_session_t* s) {
 }
 
 void* outfit_hip_session_device_results(outfit_hip_session_t* s) { return s ? s->results.p : nullptr; }
+
+int outfit_hip_session_candidate_scores(outfit_hip_session_t* s, uint64_t capacity, double* sum, uint32_t* n_win,
+                                        uint32_t* flags, uint64_t* n_out) {
+  if (!s || !n_out) return fail(OUTFIT_ERR_BAD_HANDLE, "session or n_out is NULL");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(wait_last_run(s));
+  const uint64_t last_chunk = s->n_traj ? (s->n_traj - 1) % s->chunk + 1 : 0;
+  const uint64_t n = last_chunk * s->cand_per_traj;
+  *n_out = n;
+  if (n > capacity) return fail(OUTFIT_ERR_INVALID_BATCH, "candidate_scores: capacity is smaller than the last chunk");
+  if (n && sum) HIP_TRY(hipMemcpy(sum, s->sum.p, n * sizeof(double), hipMemcpyDeviceToHost));
+  if (n && n_win) HIP_TRY(hipMemcpy(n_win, s->n_win.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (n && flags) HIP_TRY(hipMemcpy(flags, s->flags.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return OUTFIT_OK;
+}
 
 int outfit_hip_session_set_profiling(outfit_hip_session_t* s, int enabled) {
   if (!s) return fail(OUTFIT_ERR_BAD_HANDLE, "session is NULL");

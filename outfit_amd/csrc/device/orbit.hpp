@@ -191,7 +191,7 @@ struct SinCosConsts {
   double s1, s2, s3, s4, s5, s6;
   double c1, c2, c3, c4, c5, c6;
 };
-inline SinCosConsts sincos_consts() {
+__host__ __device__ inline SinCosConsts sincos_consts() {
   return {0.6366197723675814, 1.5707963267341256, 6.077100506303966e-11, 2.0222662487959506e-21,
           -1.66666666666666324348e-01, 8.33333333332248946124e-03, -1.98412698298579493134e-04,
           2.75573137070700676789e-06, -2.50507602534068634195e-08, 1.58969099521155010221e-10,

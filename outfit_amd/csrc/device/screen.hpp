@@ -1,0 +1,208 @@
+// screen.hpp — the SCREENING evaluation of a candidate's residuals (K2c in OUTFIT_MATH_GLIBC).
+//
+// In the glibc-faithful math mode the RMS that decides estimate_best_orbit's fold (trajectory.rs:455-544) is computed
+// twice: K2c screens all candidates, K3b (k_refine_best) re-evaluates the contenders — everything within 1e-4
+// relative of the screened minimum — with the glibc-faithful functions, and only K3b's bits reach the result. The
+// screen therefore owes nobody a last place: it has to be ACCURATE (error << the window; measured ~1e-12 relative on
+// the RMS, tests/test_gpu_glibc_mode.py holds it under 1e-8 against the exact values and the selected records byte
+// for byte against the exhaustive exact evaluation), and it has to agree with the exact evaluation on which
+// candidates fail. Within that it is free to be cheap, and the reference's per-observation work
+// (observation_ephemeris.rs:369-416, equinoctial_element.rs:326-348,809-867) is mostly spent in places where it can:
+//   * Kepler's equation: the reference restarts Newton from F0 = pi + varpi for every observation (5-7 iterations,
+//     a sin/cos each). Consecutive observations of one candidate are close in mean longitude, so the screen carries
+//     the solution forward: a first-order prediction from the previous observation, ONE sin/cos there, then Newton
+//     steps whose sin/cos come from the angle-addition formulas with a 5-term series of the (tiny) step. The first
+//     observation, a jump of more than 0.5 rad, and any step that does not shrink as expected go through the
+//     reference's own iteration (solve_kepler_equation), which is also what decides Err(RootFindingError).
+//   * atan2 (twice per observation): one division, an odd polynomial of degree 21 on |t| <= tan(pi/8) (1.4e-16
+//     relative), constants in scalar registers — 45 instructions against the platform's 105.
+//   * sqrt and the divisions: v_rsq_f64 / v_rcp_f64 with Newton refinements, no scaling for subnormals.
+//   * explicit fma() throughout (the exact paths are compiled with contraction off and spell out every rounding).
+// Result: 877 -> ~350 VALU instructions per (candidate, observation).
+#pragma once
+#include "orbit.hpp"
+
+namespace outfit {
+
+struct ScreenConsts {
+  double at[10];               // atan t = t + t z P(z), z = t^2, |t| <= tan(pi/8)
+  double s3, s5, s7, s9;       // sin d = d + d z (s3 + z (s5 + z (s7 + z s9))), |d| <= 1/16: error < 2e-21
+  double c2, c4, c6, c8;       // cos d = 1 + z (c2 + z (c4 + z (c6 + z c8))): error < 3e-19
+  double tan_pi_8, pi_4, pi_2, pi, two_pi, inv_vlight;
+};
+__host__ __device__ inline ScreenConsts screen_consts() {
+  return {{-0.3333333333333325, 0.19999999999898407, -0.14285714266096589, 0.11111109636532501, -0.09090852557115886,
+           0.07691055157306188, -0.06649613683809145, 0.057363320954987404, -0.04483334390288593, 0.022750523818742745},
+          -1.0 / 6.0, 1.0 / 120.0, -1.0 / 5040.0, 1.0 / 362880.0,
+          -0.5, 1.0 / 24.0, -1.0 / 720.0, 1.0 / 40320.0,
+          0.41421356237309503, 0.7853981633974483, 1.5707963267948966, 3.141592653589793, 6.283185307179586,
+          1.0 / kVlightAU};
+}
+
+// 1/d to ~2^-28 (one Newton step on v_rcp_f64) and to the last place or two (two steps)
+__device__ __forceinline__ double rcp_nr1(double d) {
+  const double r = __builtin_amdgcn_rcp(d);
+  return fma(fma(-d, r, 1.0), r, r);
+}
+__device__ __forceinline__ double rcp_nr2(double d) {
+  const double r = rcp_nr1(d);
+  return fma(fma(-d, r, 1.0), r, r);
+}
+// sqrt(x) and 1/sqrt(x) for a positive, normal x (coupled Newton on v_rsq_f64, two rounds); x <= 0 gives 0, 0
+__device__ __forceinline__ void sqrt_rsqrt(double x, double& root, double& inv_root) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  const bool ok = x > 0.0;
+  root = ok ? g : 0.0;
+  inv_root = ok ? 2.0 * h : 0.0;
+}
+
+// atan2(y, x) to ~2e-16 absolute; (0, 0) -> 0
+__device__ __forceinline__ double atan2_screen(double y, double x, const ScreenConsts& C) {
+  const double ax = fabs(x), ay = fabs(y);
+  const double mx = fmax(ax, ay), mn = fmin(ax, ay);
+  const bool big = mn > C.tan_pi_8 * mx;           // atan t = pi/4 + atan((t - 1) / (t + 1))
+  const double num = big ? mn - mx : mn, den = big ? mn + mx : mx;
+  const double rd = rcp_nr2(den);
+  double t = num * rd;
+  t = fma(fma(-den, t, num), rd, t);
+  t = (mx > 0.0) ? t : 0.0;
+  const double z = t * t;
+  double p = C.at[9];
+#pragma unroll
+  for (int j = 8; j >= 0; --j) p = fma(p, z, C.at[j]);
+  double r = fma(t * z, p, t);
+  r = big ? r + C.pi_4 : r;
+  r = (ay > ax) ? C.pi_2 - r : r;
+  r = (x < 0.0) ? C.pi - r : r;
+  return copysign(r, y);
+}
+
+// (sin, cos)(x) -> (sin, cos)(x + d), |d| <= 1/16
+__device__ __forceinline__ void rotate_small(double& sx, double& cx, double d, const ScreenConsts& C) {
+  const double z = d * d;
+  const double sd = fma(d * z, fma(z, fma(z, fma(z, C.s9, C.s7), C.s5), C.s3), d);
+  const double cd = fma(z, fma(z, fma(z, fma(z, C.c8, C.c6), C.c4), C.c2), 1.0);
+  const double ns = fma(sx, cd, cx * sd), nc = fma(cx, cd, -(sx * sd));
+  sx = ns;
+  cx = nc;
+}
+
+// The solution of F - k sin F + h cos F = lam carried from one observation of a candidate to the next.
+struct ScreenKepler {
+  bool warm;
+  double x, sx, cx;  // F and its sine / cosine at the previous observation
+  double lam;        // the right-hand side it solved
+  double off;        // lam - (lambda + n dt): the multiple of 2 pi the reference's principal_angle removed
+  double dmin;       // smallest dlam/dF = 1 - k cos F - h sin F met so far (-> screen_level)
+};
+// The reference's Newton iteration stops as soon as |f| < 100 eps = 2.2e-14 (equinoctial_element.rs:339), i.e. with an
+// error of up to 2.2e-14 / (dlam/dF) in F — part of its result, reproduced by the exact evaluation only because that
+// follows the same iterates. Any other solver, however accurate, differs from it by that much, and dlam/dF =
+// 1 - e cos E gets arbitrarily small for a near-parabolic candidate at perihelion (measured: the RMS of 3 in 10^7
+// candidates off by 0.1 - 1.4 %, of 3 in 10^4 by more than 1e-8). The screen therefore reports, with its sum, how
+// small dlam/dF got: `level` = -exponent(dmin) clamped to 0..31, i.e. dmin >= 2^-(level+1), in five bits of the
+// candidate's flag word, and k_refine_best widens that candidate's window by the matching bound (screen_slack_rad).
+constexpr unsigned kFlagLevelShift = 23, kFlagLevelMask = 0x1Fu << kFlagLevelShift;
+__device__ __forceinline__ unsigned screen_level(double dmin) {
+  if (!(dmin > 0.0)) return 31u;
+  const int e = __builtin_amdgcn_frexp_exp(dmin);  // dmin = m 2^e, 0.5 <= m < 1
+  return (unsigned)(e >= 0 ? 0 : (e <= -31 ? 31 : -e));
+}
+// Bound, in radians on the sky, of what the stopping rule can move a candidate of that level: 2.2e-14 * 2^(level+1) in F,
+// times 227 for semi-major axis over topocentric distance and the observations adding up (= 1.6e-10 rad at level <= 4,
+// where the measured maximum is 5.5e-11); level 31 = unbounded.
+__device__ __forceinline__ double screen_slack_rad(unsigned level) {
+  if (level >= 31u) return INFINITY;
+  return ldexp(5.0e-12, (int)(level < 4u ? 4u : level) + 1);
+}
+
+// false = Err(RootFindingError), decided by the reference's own iteration
+__device__ __forceinline__ bool screen_kepler(const Equinoctial& q, const TwoBodyFrame& F, double dt, ScreenKepler& S,
+                                              const SinCosConsts& K, const ScreenConsts& C) {
+  const double lamu = fma(F.n, dt, q.lambda);
+  bool full = !S.warm;
+  if (S.warm) {
+    const double lam = lamu + S.off;
+    const double d0 = fma(-q.h, S.sx, fma(-q.k, S.cx, 1.0));  // dlam/dF at the previous solution
+    double x = fma(lam - S.lam, rcp_nr1(d0), S.x);
+    if (!(fabs(x - S.x) < 0.5)) {
+      full = true;
+    } else {
+      double sx, cx;
+      sincos_k(x, K, sx, cx);
+      bool ok = false;
+      for (int it = 0; it < 6; ++it) {
+        const double f = fma(q.h, cx, fma(-q.k, sx, x - lam));
+        const double d = fma(-q.h, sx, fma(-q.k, cx, 1.0));
+        S.dmin = fmin(S.dmin, d);
+        const double dl = -f * rcp_nr1(d);
+        if (!(fabs(dl) < 0.0625)) break;
+        x += dl;
+        rotate_small(sx, cx, dl, C);
+        if (fabs(dl) < 1e-9) { ok = true; break; }  // quadratic: the step after this one is below 1e-17
+      }
+      if (ok) { S.x = x; S.sx = sx; S.cx = cx; S.lam = lam; }
+      else full = true;
+    }
+  }
+  if (full) {
+    double lam = principal_angle_fast(lamu);
+    if (lam < F.varpi) lam += kTwoPi;
+    if (!solve_kepler_equation<kFnPlatform>(q, F, lam, S.x, S.sx, S.cx, &K)) return false;
+    S.dmin = fmin(S.dmin, fma(-q.h, S.sx, fma(-q.k, S.cx, 1.0)));
+    S.lam = lam;
+    S.off = lam - lamu;
+    S.warm = true;
+  }
+  return true;
+}
+
+// Candidate-constant part of the screen's residual: the orbital-plane axes in the equatorial frame.
+struct ScreenFrame {
+  Vec3 f, g;
+  double na2;
+};
+__device__ __forceinline__ ScreenFrame screen_frame(const Equinoctial& q, const TwoBodyFrame& F) {
+  return {ecl_to_equ_finite(F.f), ecl_to_equ_finite(F.g), F.n * (q.a * q.a)};
+}
+
+// The squared normalised residual of one observation from (sin F, cos F): equinoctial_element.rs:850-867,
+// observation_ephemeris.rs:222-275,388-416 (incl. the sign-keeping `%` of quirk Q6), in the screen's arithmetic.
+__device__ __forceinline__ double screen_term(const Equinoctial& q, const TwoBodyFrame& F, const ScreenFrame& G,
+                                              double sx, double cx, double ra, double dec, double cos_dec, double sra,
+                                              double sdec, const Vec3& obs_pos_equ, const ScreenConsts& C) {
+  const double xe = q.a * fma(F.one_bh2, cx, fma(F.bet, sx, -q.k));
+  const double ye = q.a * fma(F.one_bk2, sx, fma(F.bet, cx, -q.h));
+  double r, inv_r;
+  sqrt_rsqrt(fma(xe, xe, ye * ye), r, inv_r);
+  const double vc = G.na2 * inv_r;
+  const double vxe = vc * fma(F.bet, cx, -(F.one_bh2 * sx));
+  const double vye = vc * fma(F.one_bk2, cx, -(F.bet * sx));
+  const Vec3 rel = {fma(xe, G.f.x, fma(ye, G.g.x, -obs_pos_equ.x)), fma(xe, G.f.y, fma(ye, G.g.y, -obs_pos_equ.y)),
+                    fma(xe, G.f.z, fma(ye, G.g.z, -obs_pos_equ.z))};
+  const Vec3 vq = {fma(vxe, G.f.x, vye * G.g.x), fma(vxe, G.f.y, vye * G.g.y), fma(vxe, G.f.z, vye * G.g.z)};
+  double dist, inv_dist;
+  sqrt_rsqrt(fma(rel.x, rel.x, fma(rel.y, rel.y, rel.z * rel.z)), dist, inv_dist);
+  const double lt = dist * C.inv_vlight;
+  const Vec3 cor = {fma(-lt, vq.x, rel.x), fma(-lt, vq.y, rel.y), fma(-lt, vq.z, rel.z)};
+  double rho, inv_rho;
+  sqrt_rsqrt(fma(cor.x, cor.x, cor.y * cor.y), rho, inv_rho);
+  const double delta = atan2_screen(cor.z, rho, C);
+  double alpha = atan2_screen(cor.y, cor.x, C);
+  if (alpha < 0.0) alpha += C.two_pi;
+  double da = ra - alpha;
+  if (!(fabs(da) < C.two_pi)) da = fmod_2pi(da);
+  if (da > C.pi) da -= C.two_pi;
+  const double t1 = cos_dec * (da * rcp_nr2(sra));
+  const double t2 = (dec - delta) * rcp_nr2(sdec);
+  return fma(t1, t1, t2 * t2);
+}
+
+}  // namespace outfit

@@ -7,6 +7,7 @@
 #include "device/triplets.hpp"
 #include "device/diffcor.hpp"
 #include "device/noise.hpp"
+#include "device/screen.hpp"
 
 namespace outfit {
 
@@ -28,6 +29,8 @@ constexpr unsigned kFlagFirstShift = 16;      // 4 bits: slot of the first accep
 constexpr unsigned kFlagSlow = 0x100000u;     // irregular candidate: handled by the general kernel
 constexpr unsigned kFlagFirstNone = 0x200000u;  // the fast kernel ran the first accepted root's loop to its None:
                                                 // the general kernel pushes that PrelimOrbit and goes on with the next root
+
+// bits 23-27: K2c screen, how far its RMS may be from the exact one (device/screen.hpp, kFlagLevelShift)
 
 // same 96-byte layout as outfit_gauss_result_t (include/outfit_hip.h)
 struct GaussResultRec {
@@ -100,8 +103,9 @@ struct CandidateScratch {
   double* S;         // [9][n_cand]   direction matrix, m[r][c] at (3r+c)
   double* roots;     // [kRootSlots][n_cand] filtered roots in solver order
   double* psi0;      // [2][n_cand] cold-start values of the two universal-Kepler solves
-  unsigned long long* slow_list;   // [n_cand] candidates for the general kernel
-  unsigned long long* slow_count;  // [1]
+  unsigned long long* slow_list;   // [n_cand] candidates for the general kernel from the front; from the back, the
+                                   // candidates the K2c screen hands to the exact evaluation (redo list)
+  unsigned long long* slow_count;  // [2] lengths of the two
   double* state;     // [7][n_cand]   r2[3], v2[3], epoch (equatorial J2000)
   double* sum;       // [n_cand]
   unsigned* n_win;   // [n_cand]
@@ -128,8 +132,10 @@ struct RmsArgs {
   const double* cos_dec;
   double extf, dtmax;
   SinCosConsts sc;  // polynomial constants as kernel arguments = scalar registers (device/orbit.hpp)
-  int exact_all;    // 1: every candidate with the glibc-faithful functions (k_orbit_rms<.., true>; OUTFIT_RMS_EXACT_ALL=1)
-                    // 0: platform functions; in OUTFIT_MATH_GLIBC k_refine_best then re-evaluates the contenders exactly
+  ScreenConsts scr; // the same for the screening arithmetic (device/screen.hpp)
+  int rms_mode;     // 0 exact with the platform functions (correctly-rounded mode) | 1 every candidate with the
+                    // glibc-faithful functions (OUTFIT_RMS_EXACT_ALL=1) | 2 screening arithmetic, after which
+                    // k_refine_best re-evaluates the contenders exactly (the glibc-faithful mode's default)
 };
 
 struct SelectArgs {
@@ -139,6 +145,12 @@ struct SelectArgs {
   CandidateScratch W;
   GaussResultRec* out;  // indexed by absolute trajectory
   int math_mode;        // kMathCr / kMathGlibc for the returned elements
+  // set when k_refine_best follows (glibc-faithful mode): K3 leaves the winner's elements to it and stores, per
+  // trajectory of the chunk, the two numbers of its contender rule: bound[2 lt] = min_c (screened_c + slack_c),
+  // bound[2 lt + 1] = 1 / sigma_min (kernels.hip, K3b)
+  double* bound;
+  const unsigned long long* traj_offset;
+  const double *sra, *sdec;
 };
 
 // same layouts as outfit_lsq_result_t (480 B) / outfit_obs_fit_t (32 B)

@@ -621,7 +621,9 @@ __device__ __forceinline__ void select_rms_interval(const double* mjd, unsigned 
 
 // One candidate of K2c. kSlowList = false skips the candidates marked kFlagSlow (their state is being produced
 // concurrently by the general correction kernel); true handles exactly those.
-template <bool kSlowList, int kFn>
+// kScreen: the residual loop in the screening arithmetic of device/screen.hpp (glibc-faithful mode: K3b re-evaluates
+// the contenders exactly); the prologue and the failure conditions stay those of the exact evaluation.
+template <bool kSlowList, int kFn, bool kScreen = false>
 __device__ __forceinline__ void rms_candidate(const RmsArgs& a, unsigned long long cid) {
   const unsigned f0 = a.W.flags[cid];
   if ((f0 & kFlagEmpty) || !(f0 & kFlagOk)) return;
@@ -654,16 +656,49 @@ __device__ __forceinline__ void rms_candidate(const RmsArgs& a, unsigned long lo
     err = true;  // check_elliptical_orbit (observation_ephemeris.rs:288-296)
   } else {
     const TwoBodyFrame F = twobody_frame<kFn>(eq);
-    for (unsigned long long i = i_start; i <= i_end; ++i) {
-      const unsigned long long o = c.base + i;
-      const Vec3 op = {a.obs_pos[3 * o], a.obs_pos[3 * o + 1], a.obs_pos[3 * o + 2]};
-      double term;
-      if (!ephemeris_error<kFn>(eq, F, a.I.mjd[o], a.I.ra[o], a.I.dec[o], a.cos_dec[o], a.I.sra[o], a.I.sdec[o], op,
-                                term, kFn == kFnPlatform ? &a.sc : nullptr)) {
-        err = true;
-        break;
+    bool exact = !kScreen;
+    if (kScreen) {
+      const ScreenFrame G = screen_frame(eq, F);
+      const ScreenConsts SCR = screen_consts();
+      ScreenKepler S;
+      S.warm = false;
+      S.dmin = 1.0;
+      for (unsigned long long i = i_start; i <= i_end; ++i) {
+        const unsigned long long o = c.base + i;
+        if (!screen_kepler(eq, F, a.I.mjd[o] - eq.epoch, S, a.sc, SCR)) {
+          err = true;
+          break;
+        }
+        const Vec3 op = {a.obs_pos[3 * o], a.obs_pos[3 * o + 1], a.obs_pos[3 * o + 2]};
+        acc += screen_term(eq, F, G, S.sx, S.cx, a.I.ra[o], a.I.dec[o], a.cos_dec[o], a.I.sra[o], a.I.sdec[o], op, SCR);
       }
-      acc = acc + term;
+      // anything the screen's shortcuts were not made for (non-finite or absurd inputs: overflow, 0 / 0, a zero
+      // uncertainty) shows up as a non-finite sum: such a candidate takes the reference's expressions instead — here
+      // in the slow-list pass; the main pass hands it to that pass through the redo list (the tail of slow_list: a
+      // candidate is on one list at most), which keeps the second loop out of the main pass's register budget
+      flags |= screen_level(S.dmin) << kFlagLevelShift;
+      if (!err && !(fabs(acc) < 1e300)) {
+        if (!kSlowList) {
+          const unsigned long long at = atomicAdd(a.W.slow_count + 1, 1ull);
+          a.W.slow_list[n - 1 - at] = cid;
+          return;
+        }
+        exact = true;
+        acc = 0.0;
+      }
+    }
+    if (exact) {
+      for (unsigned long long i = i_start; i <= i_end; ++i) {
+        const unsigned long long o = c.base + i;
+        const Vec3 op = {a.obs_pos[3 * o], a.obs_pos[3 * o + 1], a.obs_pos[3 * o + 2]};
+        double term;
+        if (!ephemeris_error<kFn>(eq, F, a.I.mjd[o], a.I.ra[o], a.I.dec[o], a.cos_dec[o], a.I.sra[o], a.I.sdec[o], op,
+                                  term, kFn == kFnPlatform ? &a.sc : nullptr)) {
+          err = true;
+          break;
+        }
+        acc = acc + term;
+      }
     }
   }
   a.W.sum[cid] = acc;
@@ -673,16 +708,26 @@ __device__ __forceinline__ void rms_candidate(const RmsArgs& a, unsigned long lo
 // kSlowList = false: every candidate of the chunk, one lane each. true: exactly the slow list — its length lives on the
 // device, so the grid covers every candidate and the lanes beyond the list return at once (0.16 ms; a modest grid
 // striding over the list was measured in round 3: the same 0.16 ms — the floor is the 20-observation chain of a handful
-// of waves — and the loop cost 200 spilled registers). kGlibc: the glibc-faithful functions (orbit.hpp kFnGlibc).
-template <bool kSlowList, bool kGlibc = false>
-__global__ void __launch_bounds__(256, 3)
+// of waves — and the loop cost 200 spilled registers).
+// kMode: kRmsExact — platform functions, every rounding of the reference's expressions (correctly-rounded mode);
+//        kRmsGlibc — the glibc-faithful functions (orbit.hpp kFnGlibc; OUTFIT_RMS_EXACT_ALL=1);
+//        kRmsScreen — the screening arithmetic (glibc-faithful mode, followed by K3b).
+constexpr int kRmsExact = 0, kRmsGlibc = 1, kRmsScreen = 2;
+#ifndef OUTFIT_RMS_WAVES
+#define OUTFIT_RMS_WAVES 3
+#endif
+template <bool kSlowList, int kMode = kRmsExact>
+__global__ void __launch_bounds__(256, OUTFIT_RMS_WAVES)
 k_orbit_rms(RmsArgs a) {
-  constexpr int kFn = kGlibc ? kFnGlibc : kFnPlatform;
+  constexpr int kFn = kMode == kRmsGlibc ? kFnGlibc : kFnPlatform;
   const unsigned long long lid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (kSlowList) {
-    if (lid < *a.W.slow_count) rms_candidate<true, kFn>(a, a.W.slow_list[lid]);
+    const unsigned long long n_slow = a.W.slow_count[0];
+    if (lid < n_slow) rms_candidate<true, kFn, kMode == kRmsScreen>(a, a.W.slow_list[lid]);
+    else if (kMode == kRmsScreen && lid - n_slow < a.W.slow_count[1])  // the main pass's redo list
+      rms_candidate<false, kFn, false>(a, a.W.slow_list[a.I.n_cand - 1 - (lid - n_slow)]);
   } else if (lid < a.I.n_cand) {
-    rms_candidate<false, kFn>(a, lid);
+    rms_candidate<false, kFn, kMode == kRmsScreen>(a, lid);
   }
 }
 
@@ -774,6 +819,14 @@ k_select_best(SelectArgs a) {
   bool aborted = false;
   const unsigned long long c0 = lt * a.cand_per_traj;
   const unsigned n_c = nt * a.n_real;
+  // for K3b: the upper bound of the exact minimum, min_c (screened_c + slack_c), slack_c = screen_slack_rad / sigma_min
+  double inv_sigma = 0.0, bound = INFINITY;
+  if (a.bound && live) {
+    double sig = INFINITY;
+    for (unsigned long long o = a.traj_offset[a.traj0 + lt]; o < a.traj_offset[a.traj0 + lt + 1]; ++o)
+      sig = fmin(sig, fmin(fabs(a.sra[o]), fabs(a.sdec[o])));
+    inv_sigma = 1.0 / sig;
+  }
   for (unsigned cb = 0; cb < a.cand_per_traj; cb += kSelTile) {
     // does any trajectory of this wave still need candidates from this tile on?
     const bool want = live && !aborted && cb < n_c;
@@ -807,12 +860,18 @@ k_select_best(SelectArgs a) {
           rms = (sm >= cutoff) ? best : sqrt(sm / denom);
         }
         if (!isfinite(rms)) { last_error = 4; continue; }  // NonFiniteScore
+        if (a.bound && !(f & kFlagRmsErr))
+          bound = fmin(bound, sqrt(s_sum[tl][cc] / denom) + screen_slack_rad((f & kFlagLevelMask) >> kFlagLevelShift) * inv_sigma);
         if (rms < best) { best = rms; best_c = (long long)c; }
       }
     }
     __syncthreads();
   }
   if (!live) return;
+  if (a.bound) {
+    a.bound[2 * lt] = bound;
+    a.bound[2 * lt + 1] = inv_sigma;
+  }
   if (nt == 0) {
     out.status = 1;  // NoFeasibleTriplets (trajectory.rs:439-451)
     a.out[a.traj0 + lt] = out;
@@ -833,12 +892,14 @@ k_select_best(SelectArgs a) {
       const Vec3 r2 = {a.W.state[0 * nc + cid], a.W.state[1 * nc + cid], a.W.state[2 * nc + cid]};
       const Vec3 v2 = {a.W.state[3 * nc + cid], a.W.state[4 * nc + cid], a.W.state[5 * nc + cid]};
       out.epoch = a.W.state[6 * nc + cid];
-      // correctly rounded, or glibc's bits (atan2 included) in the glibc-faithful mode
-      const Elements el = a.math_mode == kMathGlibc ? ccek1<kFnGlibc>(equ_to_ecl(r2), equ_to_ecl(v2), out.epoch)
-                                                    : ccek1<kFnCr>(equ_to_ecl(r2), equ_to_ecl(v2), out.epoch, kMathCr);
-      out.kind = el.kind;
-      for (int k = 0; k < 6; ++k) out.elem[k] = el.e[k];
       out.rms = best;
+      if (!a.bound) {  // (with K3b behind it the winner and its elements are K3b's to write)
+        // correctly rounded, or glibc's bits (atan2 included) in the glibc-faithful mode
+        const Elements el = a.math_mode == kMathGlibc ? ccek1<kFnGlibc>(equ_to_ecl(r2), equ_to_ecl(v2), out.epoch)
+                                                      : ccek1<kFnCr>(equ_to_ecl(r2), equ_to_ecl(v2), out.epoch, kMathCr);
+        out.kind = el.kind;
+        for (int k = 0; k < 6; ++k) out.elem[k] = el.e[k];
+      }
     } else {
       out.status = 2;  // NoViableOrbit{cause, attempts}
       out.cause = last_error;
@@ -917,20 +978,28 @@ __device__ unsigned long long g_refine_stats[4];
 #endif
 constexpr unsigned kRefineList = 256;  // contenders a wave holds between two evaluation passes
 __global__ void __launch_bounds__(64, 2)
-k_refine_best(RmsArgs r, GaussResultRec* out_all, unsigned long long n_traj) {
+k_refine_best(RmsArgs r, GaussResultRec* out_all, const double* bound, unsigned long long n_traj) {
   __shared__ unsigned s_item_c[kRefineList];      // candidate index within its trajectory
   __shared__ unsigned char s_item_t[kRefineList]; // trajectory of the wave (0..kRefineTraj-1)
   __shared__ double s_item_rms[kRefineList];      // its exact RMS (NaN: cannot be selected)
-  __shared__ double s_window[kRefineTraj];
+  __shared__ double s_window[kRefineTraj], s_inv_sigma[kRefineTraj];
   __shared__ unsigned s_nc[kRefineTraj];
   const unsigned tl = threadIdx.x, g = tl / kRefineGroup, sub = tl % kRefineGroup, group_base = g * kRefineGroup;
   const unsigned long long blk0 = (unsigned long long)blockIdx.x * kRefineTraj;
   const unsigned long long lt = blk0 + g;
   const bool live = lt < n_traj;
   const bool ok = live && out_all[r.I.traj0 + lt].status == 0;
+  if (sub == 0) s_nc[g] = ok ? r.I.n_triplets[lt] * r.I.n_real : 0u;
+  __syncthreads();
+  // The contender rule. The screen's error is an error in the computed ANGLES (screen_slack_rad of the candidate's
+  // level), so in the normalised RMS it has an absolute part — that angle over the smallest uncertainty of the
+  // trajectory — beside the relative one (roundings: kContenderWindow). With slack_c = screen_slack_rad(level_c) /
+  // sigma_min the exact RMS of candidate c lies in screened_c (1 -+ w) -+ slack_c, so the exact minimum is at most
+  //   m = min_c (screened_c + slack_c)                          (folded by K3: bound[])
+  // and c can be that minimum only if   screened_c <= m (1 + kContenderWindow) + slack_c:   the contenders.
   if (sub == 0) {
-    s_window[g] = ok ? out_all[r.I.traj0 + lt].rms * (1.0 + kContenderWindow) : -1.0;
-    s_nc[g] = ok ? r.I.n_triplets[lt] * r.I.n_real : 0u;
+    s_window[g] = ok ? bound[2 * lt] * (1.0 + kContenderWindow) : -1.0;
+    s_inv_sigma[g] = ok ? bound[2 * lt + 1] : 0.0;
   }
   __syncthreads();
   // The wave alternates two phases until its kRefineTraj trajectories are exhausted:
@@ -942,8 +1011,11 @@ k_refine_best(RmsArgs r, GaussResultRec* out_all, unsigned long long n_traj) {
   //     entries: the smallest (rms, index) wins, i.e. the first minimum of the reference's strict-`<` fold.
   // A trajectory with many contenders (seen: 77 of 210 noisy candidates within 1e-4) is thus shared by the whole wave
   // instead of serialising on its own four lanes (that one trajectory used to cost 3.7 ms of a 4.3 ms launch).
+  // A second round of the two phases, with an unbounded window, serves the trajectories none of whose contenders has
+  // a finite exact RMS (the exact evaluation fails where the screen did not): all their candidates are then evaluated.
   double best = INFINITY;
   long long best_c = -1;
+  for (int round = 0; round < 2; ++round) {
   unsigned count = 0, t = 0, sweep = 0;  // wave-uniform
   for (;;) {
     while (t < kRefineTraj) {
@@ -956,7 +1028,8 @@ k_refine_best(RmsArgs r, GaussResultRec* out_all, unsigned long long n_traj) {
         const unsigned long long cid = (blk0 + t) * r.I.cand_per_traj + c;
         const unsigned f = r.W.flags[cid];
         if ((f & kFlagOk) && !((f >> kFlagConvShift) & 0x7u) && !(f & kFlagRmsErr))
-          is = sqrt(r.W.sum[cid] / (2.0 * (double)r.W.n_win[cid])) <= s_window[t];
+          is = sqrt(r.W.sum[cid] / (2.0 * (double)r.W.n_win[cid])) <=
+               s_window[t] + screen_slack_rad((f & kFlagLevelMask) >> kFlagLevelShift) * s_inv_sigma[t];
       }
       const unsigned long long mask = __ballot(is);
       if (is) {
@@ -995,11 +1068,24 @@ k_refine_best(RmsArgs r, GaussResultRec* out_all, unsigned long long n_traj) {
     count = 0u;
     if (t >= kRefineTraj) break;
   }
+  const bool again = ok && best_c < 0 && sub == 0;
+  if (round == 1 || __ballot(again) == 0ull) break;
+  __syncthreads();
+  if (sub == 0) {
+    s_window[g] = again ? INFINITY : -1.0;
+    if (!again) s_nc[g] = 0u;
+  }
+  __syncthreads();
+  }
 #ifdef OUTFIT_REFINE_STATS
   if (ok && sub == 0) atomicAdd(&g_refine_stats[0], 1ull);
 #endif
   const unsigned long long c0 = lt * r.I.cand_per_traj;
-  if (!ok || best_c < 0 || sub != 0) return;  // (no finite exact value: the screened record stands)
+  if (!ok || sub != 0) return;
+  if (best_c < 0) {  // no finite exact value: K3's choice stands, with its screened RMS
+    best_c = (long long)(out_all[r.I.traj0 + lt].best_triplet * r.I.n_real + out_all[r.I.traj0 + lt].best_realization);
+    best = out_all[r.I.traj0 + lt].rms;
+  }
   // the winner's record: build_result -> compute_orbit_from_state -> ccek1 with glibc's bits (K3 filled the counters)
   const unsigned long long cid = c0 + (unsigned long long)best_c, nc = r.I.n_cand;
   const unsigned f = r.W.flags[cid];
@@ -1020,7 +1106,7 @@ hipError_t launch_refine_best(const SelectArgs& a, const RmsArgs& r, hipStream_t
 #ifdef OUTFIT_REFINE_STATS
   { static const unsigned long long z[4] = {}; (void)hipStreamSynchronize(s); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_refine_stats), z, sizeof z); }
 #endif
-  hipLaunchKernelGGL(k_refine_best, dim3((unsigned)((a.n_traj + kRefineTraj - 1) / kRefineTraj)), dim3(64), 0, s, r, a.out, a.n_traj);
+  hipLaunchKernelGGL(k_refine_best, dim3((unsigned)((a.n_traj + kRefineTraj - 1) / kRefineTraj)), dim3(64), 0, s, r, a.out, a.bound, a.n_traj);
 #ifdef OUTFIT_REFINE_STATS
   { unsigned long long h[4] = {}; (void)hipStreamSynchronize(s); (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_refine_stats), sizeof h);
     fprintf(stderr, "[refine stats] trajectories %llu contenders %llu (%.4f each) list passes %llu largest list of a wave %llu\n", h[0], h[1], h[0] ? (double)h[1] / h[0] : 0.0, h[2], h[3]); }
@@ -1373,7 +1459,7 @@ hipError_t launch_gauss_roots(const RootsArgs& a, hipStream_t s) {
 }
 // the slow list is filled by K2a (fused cold start): reset it before the first K2a slice of a chunk
 hipError_t reset_slow_list(const CandidateScratch& w, hipStream_t s) {
-  return hipMemsetAsync(w.slow_count, 0, sizeof(unsigned long long), s);
+  return hipMemsetAsync(w.slow_count, 0, 2 * sizeof(unsigned long long), s);  // slow list, redo list (K2c screen)
 }
 hipError_t launch_gauss_correct_fast(const CorrectArgs& a, unsigned n_cu, hipStream_t s) {
   if (a.I.n_cand == 0) return hipSuccess;
@@ -1436,8 +1522,9 @@ hipError_t launch_orbit_rms(const RmsArgs& a, bool slow_list, hipStream_t s) {
   if (a.I.n_cand == 0) return hipSuccess;
   if (slow_list) {
     const unsigned grid = (unsigned)((a.I.n_cand + 255) / 256);  // the list length lives on the device
-    if (a.exact_all) hipLaunchKernelGGL((k_orbit_rms<true, true>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_orbit_rms<true, false>), dim3(grid), dim3(256), 0, s, a);
+    if (a.rms_mode == kRmsGlibc) hipLaunchKernelGGL((k_orbit_rms<true, kRmsGlibc>), dim3(grid), dim3(256), 0, s, a);
+    else if (a.rms_mode == kRmsScreen) hipLaunchKernelGGL((k_orbit_rms<true, kRmsScreen>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_orbit_rms<true, kRmsExact>), dim3(grid), dim3(256), 0, s, a);
   } else {
     static const bool wave_per_candidate = std::getenv("OUTFIT_RMS_WAVE") != nullptr;  // measurement aid, see k_orbit_rms_wave
     if (wave_per_candidate) {
@@ -1445,8 +1532,9 @@ hipError_t launch_orbit_rms(const RmsArgs& a, bool slow_list, hipStream_t s) {
       return hipGetLastError();
     }
     const unsigned grid = (unsigned)((a.I.n_cand + 255) / 256);
-    if (a.exact_all) hipLaunchKernelGGL((k_orbit_rms<false, true>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_orbit_rms<false, false>), dim3(grid), dim3(256), 0, s, a);
+    if (a.rms_mode == kRmsGlibc) hipLaunchKernelGGL((k_orbit_rms<false, kRmsGlibc>), dim3(grid), dim3(256), 0, s, a);
+    else if (a.rms_mode == kRmsScreen) hipLaunchKernelGGL((k_orbit_rms<false, kRmsScreen>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_orbit_rms<false, kRmsExact>), dim3(grid), dim3(256), 0, s, a);
   }
   return hipGetLastError();
 }

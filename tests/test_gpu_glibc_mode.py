@@ -140,8 +140,12 @@ def test_noisy_realisations_and_the_corrector_in_glibc_mode():
     assert (lref["status"] == 0).sum() > 100
 
 
-def _digests(env):
-    """sha1 of the records of three workloads in a child process (the switch is read once per process)"""
+LEVEL_SHIFT, LEVEL_MASK = 23, 0x1F << 23   # device/screen.hpp: kFlagLevelShift, kFlagLevelMask
+
+
+def _digests(env, scores_to=None):
+    """sha1 of the records of three workloads in a child process (the switch is read once per process); with
+    `scores_to`, K2c's per-candidate scores of each workload go to <scores_to><i>.npz as well"""
     import subprocess
     import sys
     code = r"""
@@ -153,29 +157,73 @@ from outfit_amd import synth
 eph_d = synth.make_ephemeris()
 ephem = outfit_amd.Ephemeris.from_dict(eph_d)
 out = []
-for n, seed, kw, params in ((100000, 20263003, {}, synth.bench_params(outfit_amd.IODParams())),
-                            (20000, 20263004, {"topocentric": True}, synth.bench_params(outfit_amd.IODParams())),
-                            (15000, 20263005, {}, outfit_amd.IODParams())):
+for i, (n, seed, kw, params) in enumerate(((100000, 20263003, {}, synth.bench_params(outfit_amd.IODParams())),
+                                           (20000, 20263004, {"topocentric": True}, synth.bench_params(outfit_amd.IODParams())),
+                                           (15000, 20263005, {}, outfit_amd.IODParams()))):
     ds = synth.make_dataset(n, seed=seed, ephem=eph_d, **kw)
     nz = n * params.max_triplets * params.n_noise_realizations * 6
     if nz:
         ds["noise_z"] = np.random.default_rng(seed).standard_normal(nz)
-    rec = outfit_amd.fit_full_iod_records(outfit_amd.ObsBatch.from_dict(ds), ephem, params, 1, math_mode=outfit_amd.MATH_GLIBC)
+    sess = outfit_amd.IODSession(outfit_amd.ObsBatch.from_dict(ds), ephem, params, math_mode=outfit_amd.MATH_GLIBC)
+    sess.run()
+    rec = sess.results()
+    if len(sys.argv) > 2:
+        total, n_win, flags = sess.candidate_scores()
+        np.savez(sys.argv[2] + "%d.npz" % i, sum=total, n_win=n_win, flags=flags)
+    sess.close()
     out.append(hashlib.sha1(rec.tobytes()).hexdigest() + ":%d" % int((rec["status"] == 0).sum()))
 print(" ".join(out))
 """
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, "-c", code, root], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    argv = [sys.executable, "-c", code, root] + ([scores_to] if scores_to else [])
+    p = subprocess.run(argv, env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     return p.stdout.strip().splitlines()[-1].split()
 
 
-def test_contender_refinement_equals_the_exhaustive_exact_evaluation():
-    """K3b (kernels.hip): in the glibc-faithful mode K2c screens with the platform functions and only the candidates
-    within 1e-3 of the screened minimum are re-evaluated with glibc's atan2 / hypot / tan / sincos. OUTFIT_RMS_EXACT_ALL=1
-    evaluates EVERY candidate with them instead (2.2x the K2c time). On 135 000 trajectories (1.5 x 10^7 candidates; bench
-    workload, topocentric, IODParams::default() noise) the two give the same bytes in every record."""
-    refined = _digests({})
-    exhaustive = _digests({"OUTFIT_RMS_EXACT_ALL": "1"})
+def test_contender_refinement_equals_the_exhaustive_exact_evaluation(tmp_path):
+    """K2c + K3b (kernels.hip, device/screen.hpp): in the glibc-faithful mode K2c SCREENS the candidates in its own cheap
+    arithmetic and only those within 1e-4 of the screened minimum are re-evaluated with glibc's atan2 / hypot / tan /
+    sincos. OUTFIT_RMS_EXACT_ALL=1 evaluates EVERY candidate with them instead (3.5x the K2c time). On 135 000
+    trajectories (1.5 x 10^7 candidates; bench workload, topocentric, IODParams::default() noise)
+      * the two give the same bytes in every record, and
+      * the screen is what it claims to be: same window length and same failure flag as the exact evaluation for every
+        candidate, and its RMS within 1e-8 relative of the exact one (the contender window is 1e-4) — the figures go
+        to gpurun_out/screen_accuracy.json."""
+    import json
+    refined = _digests({}, str(tmp_path / "screen"))
+    exhaustive = _digests({"OUTFIT_RMS_EXACT_ALL": "1"}, str(tmp_path / "exact"))
     assert refined == exhaustive, (refined, exhaustive)
     assert all(int(d.split(":")[1]) > 14000 for d in refined)
+    report = []
+    for i in range(3):
+        a, b = np.load(tmp_path / ("screen%d.npz" % i)), np.load(tmp_path / ("exact%d.npz" % i))
+        level = (a["flags"] & LEVEL_MASK) >> LEVEL_SHIFT   # set by the screen only: dlam/dF got as small as 2^-(level+1)
+        fragile = level > 4
+        assert np.array_equal(a["flags"] & ~np.uint32(LEVEL_MASK), b["flags"])
+        fl = a["flags"]  # kernels.h: 0x10 a preliminary orbit exists, 0x80 an ephemeris_error failed, bits 8-10 conversion error
+        scored = ((fl & 0x10) != 0) & ((fl >> 8 & 0x7) == 0) & ((fl & 0x80) == 0) & ((fl & 0x80000000) == 0)
+        assert scored.sum() > 0.5 * scored.size
+        assert np.array_equal(a["n_win"][scored], b["n_win"][scored])
+        ra, rb = np.sqrt(a["sum"][scored] / (2.0 * a["n_win"][scored])), np.sqrt(b["sum"][scored] / (2.0 * b["n_win"][scored]))
+        assert np.array_equal(np.isfinite(ra), np.isfinite(rb))
+        idx = np.nonzero(scored)[0][np.isfinite(rb)]
+        ra, rb = ra[np.isfinite(rb)], rb[np.isfinite(rb)]
+        frag = fragile[idx]
+        dev = np.abs(ra - rb)
+        # K3b's bound for a candidate of that level (screen_slack_rad / sigma_min, sigma >= 0.3" = 1.45e-6 rad here)
+        bound = 5.0e-12 * 2.0 ** (np.maximum(level[idx], 4) + 1.0) / 1.45e-6 + 1e-4 * rb
+        assert (dev < 0.25 * bound).all(), (i, float((dev / bound).max()))
+        rel = dev / rb
+        worst = np.argsort(np.where(frag, 0.0, dev))[-5:][::-1]
+        report.append({"workload": i, "candidates": int(scored.sum()), "fragile": int(frag.sum()),
+                       "robust_max_abs": float(dev[~frag].max()), "robust_max_rel": float(rel[~frag].max()),
+                       "robust_p999_abs": float(np.quantile(dev[~frag], 0.999)), "robust_median_abs": float(np.median(dev[~frag])),
+                       "fragile_max_rel": float(rel[frag].max()) if frag.any() else 0.0,
+                       "worst_robust": [{"candidate": int(idx[w]), "screen": float(ra[w]), "exact": float(rb[w])} for w in worst]})
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/screen_accuracy.json", "w") as f:
+        json.dump(report, f, indent=1)
+    # (every candidate stays a factor 4 inside the bound K3b's contender rule gives it: asserted above)
+    for r in report:
+        assert r["fragile"] < 0.01 * r["candidates"], r
