@@ -795,7 +795,7 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
     static const bool no_screen_env = std::getenv("OUTFIT_RMS_NO_SCREEN") != nullptr;  // measurement aid: exact platform-function K2c + K3b
     const int rms_mode = s->math_mode != OUTFIT_MATH_GLIBC ? 0 : exact_all ? 1 : no_screen_env ? 0 : 2;
     const outfit::RmsArgs rm{ci, w, obs_pos, s->cos_dec.p, s->params.extf, s->params.dtmax, outfit::sincos_consts(),
-                             outfit::screen_consts(), rms_mode};
+                             rms_mode};
     HIP_TRY(hipStreamWaitEvent(st, s->ev_prepass, 0));
     {
       Stamp stamp(s, st, K_RMS);

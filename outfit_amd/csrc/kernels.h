@@ -132,7 +132,6 @@ struct RmsArgs {
   const double* cos_dec;
   double extf, dtmax;
   SinCosConsts sc;  // polynomial constants as kernel arguments = scalar registers (device/orbit.hpp)
-  ScreenConsts scr; // the same for the screening arithmetic (device/screen.hpp)
   int rms_mode;     // 0 exact with the platform functions (correctly-rounded mode) | 1 every candidate with the
                     // glibc-faithful functions (OUTFIT_RMS_EXACT_ALL=1) | 2 screening arithmetic, after which
                     // k_refine_best re-evaluates the contenders exactly (the glibc-faithful mode's default)

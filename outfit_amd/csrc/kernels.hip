@@ -659,7 +659,7 @@ __device__ __forceinline__ void rms_candidate(const RmsArgs& a, unsigned long lo
     bool exact = !kScreen;
     if (kScreen) {
       const ScreenFrame G = screen_frame(eq, F);
-      const ScreenConsts SCR = screen_consts();
+      const ScreenConsts SCR = screen_consts();  // compile-time literals (screen.hpp: why not kernel arguments)
       ScreenKepler S;
       S.warm = false;
       S.dmin = 1.0;
@@ -914,17 +914,17 @@ k_select_best(SelectArgs a) {
 // In OUTFIT_MATH_GLIBC the selection key — the RMS of estimate_best_orbit's fold (trajectory.rs:455-544) — must be the
 // bits a glibc run of the reference computes, which takes glibc's atan2 / hypot / tan / sincos (glibcmath*.hpp): ~2.2x
 // the instructions of the platform functions in the residual loop (measured: K2c 5.7 -> 12.5 ms per 10^7 candidates).
-// Two stages instead: K2c screens every candidate with the platform functions (relative error of an RMS ~1e-11,
-// worst ever observed 2.8e-7), K3 folds those values, and this kernel re-evaluates EXACTLY — with the glibc-faithful
-// functions — every candidate whose screened RMS lies within kContenderWindow (1e-4 relative) of the screened minimum
-// (1.004 candidates per trajectory on the bench workload) and keeps the smallest (rms, index), i.e. the first minimum
-// of the reference's strict-`<` fold. The winner, its `rms` and its elements are then those of the exhaustive exact
-// evaluation as long as no contender's screening error reaches half the window (5e-5: 180 x the worst error ever
-// seen, 5 x 10^6 x the typical one); OUTFIT_RMS_EXACT_ALL=1 runs the exhaustive evaluation instead, and
-// tests/test_gpu_glibc_mode.py holds the two against each other byte for byte on 135 000 trajectories.
+// Two stages instead: K2c screens every candidate (device/screen.hpp: its own cheap arithmetic, with a per-candidate error
+// level), K3 folds those values and the bound m = min_c (screened_c + slack_c), and this kernel re-evaluates EXACTLY — with
+// the glibc-faithful functions — every candidate that can still be the exact minimum (screened_c <= m (1 + 1e-4) +
+// slack_c: 1.014 candidates per trajectory on the bench workload) and keeps the smallest (rms, index), i.e. the first
+// minimum of the reference's strict-`<` fold. The winner, its `rms` and its elements are then those of the exhaustive
+// exact evaluation as long as every candidate's screening error stays inside its bound (tests/test_gpu_glibc_mode.py:
+// all of 1.5 x 10^7 candidates within a quarter of it); OUTFIT_RMS_EXACT_ALL=1 runs the exhaustive evaluation instead, and
+// the same test holds the two against each other byte for byte on 135 000 trajectories.
 // Four lanes per evaluation (a lane per trajectory was a 45 k-instruction chain on 1.5 waves per SIMD: 1.6 ms;
-// four lanes 0.6 ms, of which the contender scan is 0.04 ms), and the contenders of a wave's sixteen trajectories form
-// one work list, so a trajectory with many of them is spread over the wave.
+// four lanes 0.6 ms), and the contenders of a wave's sixteen trajectories form one work list, so a trajectory with many
+// of them is spread over the wave.
 // ------------------------------------------------------------------------------
 #ifndef OUTFIT_CONTENDER_WINDOW
 #define OUTFIT_CONTENDER_WINDOW 1.0e-4
