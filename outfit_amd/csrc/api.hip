@@ -793,7 +793,12 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
     static const bool exact_all_env = std::getenv("OUTFIT_RMS_EXACT_ALL") != nullptr;  // verification aid (kernels.hip, K3b)
     const bool exact_all = exact_all_env && s->math_mode == OUTFIT_MATH_GLIBC;
     static const bool no_screen_env = std::getenv("OUTFIT_RMS_NO_SCREEN") != nullptr;  // measurement aid: exact platform-function K2c + K3b
-    const int rms_mode = s->math_mode != OUTFIT_MATH_GLIBC ? 0 : exact_all ? 1 : no_screen_env ? 0 : 2;
+    // K2c: 0 exact with the platform functions | 1 exact with the glibc-faithful ones | 2 screen. `refine`: K3b follows
+    // and re-evaluates the contenders exactly — glibc-faithful mode: glibc's functions (always, unless K2c already did);
+    // correctly-rounded mode: the platform functions, i.e. the bits of its exact K2c, after a screening K2c.
+    const bool glibc_mode = s->math_mode == OUTFIT_MATH_GLIBC;
+    const int rms_mode = exact_all ? 1 : (no_screen_env || (!glibc_mode && exact_all_env)) ? 0 : 2;
+    const bool refine = glibc_mode ? !exact_all : rms_mode == 2;
     const outfit::RmsArgs rm{ci, w, obs_pos, s->cos_dec.p, s->params.extf, s->params.dtmax, outfit::sincos_consts(),
                              rms_mode};
     HIP_TRY(hipStreamWaitEvent(st, s->ev_prepass, 0));
@@ -811,14 +816,13 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
     sa.n_real = s->n_real; sa.n_triplets = s->n_triplets[tb].p; sa.W = w;
     sa.out = d_out ? d_out : s->results.p;
     sa.math_mode = s->math_mode;
-    const bool refine = s->math_mode == OUTFIT_MATH_GLIBC && !exact_all;
     sa.bound = refine ? s->sel_bound.p : nullptr;
     sa.traj_offset = ci.traj_offset; sa.sra = ci.sra; sa.sdec = ci.sdec;
     {
       Stamp stamp(s, st, K_SELECT);
       HIP_TRY(outfit::launch_select_best(sa, st));
     }
-    if (refine) {  // K3b: the contenders, exactly (glibc's functions)
+    if (refine) {  // K3b: the contenders, exactly
       Stamp stamp(s, st, K_REFINE);
       HIP_TRY(outfit::launch_refine_best(sa, rm, st));
     }

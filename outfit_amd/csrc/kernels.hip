@@ -937,6 +937,7 @@ constexpr unsigned kRefineTraj = 64 / kRefineGroup;       // trajectories per wa
 // lane `sub` takes the observations i_start + sub, + kRefineGroup, ...; the terms are then added one after the other in
 // observation order by every lane (the reference's left fold, bit for bit). NaN = the candidate cannot be selected
 // (conversion error, e >= 1, an Err of ephemeris_error). The prologue is evaluated redundantly by the lanes.
+template <int kFn>
 __device__ __forceinline__ double exact_candidate_rms(const RmsArgs& a, unsigned long long cid, unsigned sub,
                                                       unsigned group_base) {
   const unsigned long long n = a.I.n_cand;
@@ -945,13 +946,13 @@ __device__ __forceinline__ double exact_candidate_rms(const RmsArgs& a, unsigned
   const Vec3 v2 = {a.W.state[3 * n + cid], a.W.state[4 * n + cid], a.W.state[5 * n + cid]};
   Equinoctial eq;
   {
-    const Elements el = ccek1<kFnGlibc>(equ_to_ecl(r2), equ_to_ecl(v2), a.W.state[6 * n + cid]);
-    if (to_equinoctial<kFnGlibc>(el, eq) != 0) return nan("");
+    const Elements el = ccek1<kFn>(equ_to_ecl(r2), equ_to_ecl(v2), a.W.state[6 * n + cid]);
+    if (to_equinoctial<kFn>(el, eq) != 0) return nan("");
   }
   unsigned long long i_start, i_end;
   select_rms_interval(a.I.mjd + c.base, c.n_obs, c.idx[0], c.idx[2], a.extf, a.dtmax, i_start, i_end);
   if (sqrt(eq.h * eq.h + eq.k * eq.k) >= 1.0) return nan("");
-  const TwoBodyFrame F = twobody_frame<kFnGlibc>(eq);
+  const TwoBodyFrame F = twobody_frame<kFn>(eq);
   double acc = 0.0;
   bool err = false;
   for (unsigned long long b0 = i_start; b0 <= i_end && !err; b0 += kRefineGroup) {
@@ -961,8 +962,8 @@ __device__ __forceinline__ double exact_candidate_rms(const RmsArgs& a, unsigned
     if (i <= i_end) {
       const unsigned long long o = c.base + i;
       const Vec3 op = {a.obs_pos[3 * o], a.obs_pos[3 * o + 1], a.obs_pos[3 * o + 2]};
-      bad = !ephemeris_error<kFnGlibc>(eq, F, a.I.mjd[o], a.I.ra[o], a.I.dec[o], a.cos_dec[o], a.I.sra[o], a.I.sdec[o],
-                                       op, term, nullptr);
+      bad = !ephemeris_error<kFn>(eq, F, a.I.mjd[o], a.I.ra[o], a.I.dec[o], a.cos_dec[o], a.I.sra[o], a.I.sdec[o], op, term,
+                                  kFn == kFnPlatform ? &a.sc : nullptr);
     }
     const unsigned cnt = (unsigned)((i_end - b0 + 1) < kRefineGroup ? (i_end - b0 + 1) : kRefineGroup);
     for (unsigned k = 0; k < cnt; ++k) {
@@ -977,6 +978,7 @@ __device__ __forceinline__ double exact_candidate_rms(const RmsArgs& a, unsigned
 __device__ unsigned long long g_refine_stats[4];
 #endif
 constexpr unsigned kRefineList = 256;  // contenders a wave holds between two evaluation passes
+template <int kFn>  // kFnGlibc: the glibc-faithful mode; kFnPlatform: the correctly-rounded mode's RMS (platform functions)
 __global__ void __launch_bounds__(64, 2)
 k_refine_best(RmsArgs r, GaussResultRec* out_all, const double* bound, unsigned long long n_traj) {
   __shared__ unsigned s_item_c[kRefineList];      // candidate index within its trajectory
@@ -1051,7 +1053,7 @@ k_refine_best(RmsArgs r, GaussResultRec* out_all, const double* bound, unsigned 
       const unsigned k = k0 + g;
       if (k < count) {
         const unsigned long long cid = (blk0 + s_item_t[k]) * r.I.cand_per_traj + s_item_c[k];
-        const double e = exact_candidate_rms(r, cid, sub, group_base);
+        const double e = exact_candidate_rms<kFn>(r, cid, sub, group_base);
         if (sub == 0) s_item_rms[k] = e;
       }
     }
@@ -1091,7 +1093,8 @@ k_refine_best(RmsArgs r, GaussResultRec* out_all, const double* bound, unsigned 
   const unsigned f = r.W.flags[cid];
   const Vec3 r2 = {r.W.state[0 * nc + cid], r.W.state[1 * nc + cid], r.W.state[2 * nc + cid]};
   const Vec3 v2 = {r.W.state[3 * nc + cid], r.W.state[4 * nc + cid], r.W.state[5 * nc + cid]};
-  const Elements el = ccek1<kFnGlibc>(equ_to_ecl(r2), equ_to_ecl(v2), r.W.state[6 * nc + cid]);
+  const Elements el = kFn == kFnGlibc ? ccek1<kFnGlibc>(equ_to_ecl(r2), equ_to_ecl(v2), r.W.state[6 * nc + cid])
+                                      : ccek1<kFnCr>(equ_to_ecl(r2), equ_to_ecl(v2), r.W.state[6 * nc + cid], kMathCr);
   GaussResultRec* out = out_all + r.I.traj0 + lt;
   out->stage = (f & kFlagCorrected) ? 1 : 0;
   out->best_triplet = (unsigned)best_c / r.I.n_real;
@@ -1106,7 +1109,9 @@ hipError_t launch_refine_best(const SelectArgs& a, const RmsArgs& r, hipStream_t
 #ifdef OUTFIT_REFINE_STATS
   { static const unsigned long long z[4] = {}; (void)hipStreamSynchronize(s); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_refine_stats), z, sizeof z); }
 #endif
-  hipLaunchKernelGGL(k_refine_best, dim3((unsigned)((a.n_traj + kRefineTraj - 1) / kRefineTraj)), dim3(64), 0, s, r, a.out, a.bound, a.n_traj);
+  const dim3 grid((unsigned)((a.n_traj + kRefineTraj - 1) / kRefineTraj));
+  if (a.math_mode == kMathGlibc) hipLaunchKernelGGL(k_refine_best<kFnGlibc>, grid, dim3(64), 0, s, r, a.out, a.bound, a.n_traj);
+  else hipLaunchKernelGGL(k_refine_best<kFnPlatform>, grid, dim3(64), 0, s, r, a.out, a.bound, a.n_traj);
 #ifdef OUTFIT_REFINE_STATS
   { unsigned long long h[4] = {}; (void)hipStreamSynchronize(s); (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_refine_stats), sizeof h);
     fprintf(stderr, "[refine stats] trajectories %llu contenders %llu (%.4f each) list passes %llu largest list of a wave %llu\n", h[0], h[1], h[0] ? (double)h[1] / h[0] : 0.0, h[2], h[3]); }

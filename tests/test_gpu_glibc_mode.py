@@ -143,7 +143,7 @@ def test_noisy_realisations_and_the_corrector_in_glibc_mode():
 LEVEL_SHIFT, LEVEL_MASK = 23, 0x1F << 23   # device/screen.hpp: kFlagLevelShift, kFlagLevelMask
 
 
-def _digests(env, scores_to=None):
+def _digests(env, scores_to=None, mode="glibc"):
     """sha1 of the records of three workloads in a child process (the switch is read once per process); with
     `scores_to`, K2c's per-candidate scores of each workload go to <scores_to><i>.npz as well"""
     import subprocess
@@ -164,24 +164,26 @@ for i, (n, seed, kw, params) in enumerate(((100000, 20263003, {}, synth.bench_pa
     nz = n * params.max_triplets * params.n_noise_realizations * 6
     if nz:
         ds["noise_z"] = np.random.default_rng(seed).standard_normal(nz)
-    sess = outfit_amd.IODSession(outfit_amd.ObsBatch.from_dict(ds), ephem, params, math_mode=outfit_amd.MATH_GLIBC)
+    mode = outfit_amd.MATH_GLIBC if sys.argv[2] == "glibc" else outfit_amd.MATH_CORRECTLY_ROUNDED
+    sess = outfit_amd.IODSession(outfit_amd.ObsBatch.from_dict(ds), ephem, params, math_mode=mode)
     sess.run()
     rec = sess.results()
-    if len(sys.argv) > 2:
+    if len(sys.argv) > 3:
         total, n_win, flags = sess.candidate_scores()
-        np.savez(sys.argv[2] + "%d.npz" % i, sum=total, n_win=n_win, flags=flags)
+        np.savez(sys.argv[3] + "%d.npz" % i, sum=total, n_win=n_win, flags=flags)
     sess.close()
     out.append(hashlib.sha1(rec.tobytes()).hexdigest() + ":%d" % int((rec["status"] == 0).sum()))
 print(" ".join(out))
 """
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    argv = [sys.executable, "-c", code, root] + ([scores_to] if scores_to else [])
+    argv = [sys.executable, "-c", code, root, mode] + ([scores_to] if scores_to else [])
     p = subprocess.run(argv, env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     return p.stdout.strip().splitlines()[-1].split()
 
 
-def test_contender_refinement_equals_the_exhaustive_exact_evaluation(tmp_path):
+@pytest.mark.parametrize("mode", ["glibc", "cr"])
+def test_contender_refinement_equals_the_exhaustive_exact_evaluation(tmp_path, mode):
     """K2c + K3b (kernels.hip, device/screen.hpp): in the glibc-faithful mode K2c SCREENS the candidates in its own cheap
     arithmetic and only those within 1e-4 of the screened minimum are re-evaluated with glibc's atan2 / hypot / tan /
     sincos. OUTFIT_RMS_EXACT_ALL=1 evaluates EVERY candidate with them instead (3.5x the K2c time). On 135 000
@@ -189,10 +191,12 @@ def test_contender_refinement_equals_the_exhaustive_exact_evaluation(tmp_path):
       * the two give the same bytes in every record, and
       * the screen is what it claims to be: same window length and same failure flag as the exact evaluation for every
         candidate, and its RMS within 1e-8 relative of the exact one (the contender window is 1e-4) — the figures go
-        to gpurun_out/screen_accuracy.json."""
+        to gpurun_out/screen_accuracy_<mode>.json.
+    The correctly-rounded mode works the same way with the platform functions as its exact evaluation (its `rms` is
+    defined by them): screen, then K3b<kFnPlatform>; OUTFIT_RMS_EXACT_ALL=1 there is the exact K2c without K3b."""
     import json
-    refined = _digests({}, str(tmp_path / "screen"))
-    exhaustive = _digests({"OUTFIT_RMS_EXACT_ALL": "1"}, str(tmp_path / "exact"))
+    refined = _digests({}, str(tmp_path / "screen"), mode)
+    exhaustive = _digests({"OUTFIT_RMS_EXACT_ALL": "1"}, str(tmp_path / "exact"), mode)
     assert refined == exhaustive, (refined, exhaustive)
     assert all(int(d.split(":")[1]) > 14000 for d in refined)
     report = []
@@ -222,7 +226,7 @@ def test_contender_refinement_equals_the_exhaustive_exact_evaluation(tmp_path):
                        "fragile_max_rel": float(rel[frag].max()) if frag.any() else 0.0,
                        "worst_robust": [{"candidate": int(idx[w]), "screen": float(ra[w]), "exact": float(rb[w])} for w in worst]})
     os.makedirs("gpurun_out", exist_ok=True)
-    with open("gpurun_out/screen_accuracy.json", "w") as f:
+    with open("gpurun_out/screen_accuracy_%s.json" % mode, "w") as f:
         json.dump(report, f, indent=1)
     # (every candidate stays a factor 4 inside the bound K3b's contender rule gives it: asserted above)
     for r in report:
