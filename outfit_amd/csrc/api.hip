@@ -133,6 +133,8 @@ struct DeviceCache {
       if (!sets[dev].empty()) { *out = sets[dev].back(); sets[dev].pop_back(); return hipSuccess; }
     }
     StreamSet ss;
+    // (stream priorities were measured for the side streams — general kernel beside K2c, K0 / K1 ahead — and change
+    // nothing on this runtime: what lets the general kernel in beside K2c is its register footprint, kernels.hip)
     for (auto& st : ss.stream) {
       hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
       if (e != hipSuccess) { destroy_streams(ss); return e; }
@@ -782,14 +784,16 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
       TRY_RC(launch_observer());
       s->deferred.clear();
     }
-    HIP_TRY(hipStreamWaitEvent(aux, s->ev_fast, 0));
+    static const bool general_serial = std::getenv("OUTFIT_GENERAL_SERIAL") != nullptr;  // measurement aid: no overlap with K2c
+    hipStream_t gs = general_serial ? st : aux;
+    HIP_TRY(hipStreamWaitEvent(gs, s->ev_fast, 0));
     {
       outfit::CorrectArgs cg = ca;
       cg.queue = s->queue.p + 1;  // its own queue head
-      Stamp stamp(s, aux, K_CORRECT);
-      HIP_TRY(outfit::launch_gauss_correct(cg, s->n_cu, aux));
+      Stamp stamp(s, gs, K_CORRECT);
+      HIP_TRY(outfit::launch_gauss_correct(cg, s->n_cu, gs));
     }
-    HIP_TRY(hipEventRecord(s->ev_general, aux));
+    HIP_TRY(hipEventRecord(s->ev_general, gs));
     static const bool exact_all_env = std::getenv("OUTFIT_RMS_EXACT_ALL") != nullptr;  // verification aid (kernels.hip, K3b)
     const bool exact_all = exact_all_env && s->math_mode == OUTFIT_MATH_GLIBC;
     static const bool no_screen_env = std::getenv("OUTFIT_RMS_NO_SCREEN") != nullptr;  // measurement aid: exact platform-function K2c + K3b

@@ -12,7 +12,10 @@
 namespace outfit {
 
 constexpr unsigned kRootSlots = 8;       // a degree-8 polynomial has at most 8 roots
-constexpr unsigned kCorrectBlock = 256;  // lanes per workgroup of the correction kernel
+#ifndef OUTFIT_GENERAL_BLOCK
+#define OUTFIT_GENERAL_BLOCK 256
+#endif
+constexpr unsigned kCorrectBlock = OUTFIT_GENERAL_BLOCK;  // lanes per workgroup of the correction kernel
 constexpr unsigned kCorrectLdsDoubles = 34;  // per lane: S, S^-1, observer matrix (27) + prelim state (7)
 constexpr unsigned kFastBlock = 64;          // lanes per workgroup of the fast correction kernel
 constexpr unsigned kFastWavesPerSimd = 3;    // residency the fast kernel is compiled and launched for

@@ -463,7 +463,12 @@ k_gauss_correct_fast(CorrectArgs a) {
 // wins (prelim_orbit, gauss.rs:1238-1247), a root whose loop returns None contributes a
 // PrelimOrbit, the walk stops after max_tested_solutions pushes. Persistent lanes as above.
 // ------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kCorrectBlock, 2)
+// kWaves (waves per SIMD the kernel is compiled for): 2 = 256 VGPRs, the shortest chain — small batches, where this kernel
+// is the floor of the run; 3 = 168 VGPRs (+120 spilled): beside K2c, whose waves hold 3 x 154 of a SIMD's 512 registers, a
+// 256-register wave practically never finds room (measured: 3.4 ms beside a 3.0 ms K2c for 0.45 ms of work, i.e. K3 waited
+// for it), a 168-register one does as soon as one K2c wave retires (0.5 ms, hidden).
+template <int kWaves>
+__global__ void __launch_bounds__(kCorrectBlock, kWaves)
 k_gauss_correct(CorrectArgs a) {
   extern __shared__ double lds[];  // [kCorrectLdsDoubles][kCorrectBlock]
   const unsigned tid = threadIdx.x;
@@ -1516,11 +1521,13 @@ hipError_t launch_gauss_correct(const CorrectArgs& a, unsigned n_cu, hipStream_t
   // general kernel over the slow list (its length is only known on the device): a modest
   // persistent grid, two 256-lane workgroups per CU at most
   const unsigned long long want = (a.I.n_cand + kCorrectBlock - 1) / kCorrectBlock;
-  const unsigned grid = (unsigned)(want < 2ull * n_cu ? want : 2ull * n_cu);
+  const unsigned long long cap = 2ull * n_cu * (256u / kCorrectBlock);  // as many waves as two 256-lane workgroups per CU
+  const unsigned grid = (unsigned)(want < cap ? want : cap);
   const size_t lds = (size_t)kCorrectLdsDoubles * kCorrectBlock * sizeof(double);
   hipError_t e = hipMemsetAsync(a.queue, 0, sizeof(unsigned long long), s);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_gauss_correct, dim3(grid), dim3(kCorrectBlock), lds, s, a);
+  if (a.I.n_cand >= (1ull << 20)) hipLaunchKernelGGL(k_gauss_correct<3>, dim3(grid), dim3(kCorrectBlock), lds, s, a);
+  else hipLaunchKernelGGL(k_gauss_correct<2>, dim3(grid), dim3(kCorrectBlock), lds, s, a);
   return hipGetLastError();
 }
 hipError_t launch_orbit_rms(const RmsArgs& a, bool slow_list, hipStream_t s) {
