@@ -983,8 +983,12 @@ __device__ __forceinline__ double exact_candidate_rms(const RmsArgs& a, unsigned
 __device__ unsigned long long g_refine_stats[4];
 #endif
 constexpr unsigned kRefineList = 256;  // contenders a wave holds between two evaluation passes
+// Compiled for 3 waves per SIMD (168 VGPRs + 220 spilled): 0.60 ms against 0.65 ms at 2 waves without spills — the kernel is
+// latency bound (dependent double-double chains, table look-ups), a third wave hides more than the spills cost.
+// Measured and dropped (round 3): the fold and this kernel run slice by slice on the side stream under the next slice's
+// K2c — same step time (18.05 ms): each of its long-lived waves displaces a K2c wave (registers), K2c 3.05 -> 3.65 ms.
 template <int kFn>  // kFnGlibc: the glibc-faithful mode; kFnPlatform: the correctly-rounded mode's RMS (platform functions)
-__global__ void __launch_bounds__(64, 2)
+__global__ void __launch_bounds__(64, 3)
 k_refine_best(RmsArgs r, GaussResultRec* out_all, const double* bound, unsigned long long n_traj) {
   __shared__ unsigned s_item_c[kRefineList];      // candidate index within its trajectory
   __shared__ unsigned char s_item_t[kRefineList]; // trajectory of the wave (0..kRefineTraj-1)

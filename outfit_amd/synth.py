@@ -195,24 +195,25 @@ def _propagate_kepler_ecl(a, e, inc, node, argp, m0, dt):
 
 
 def make_dataset(n_obj, seed=DEFAULT_SEED, ephem=None, topocentric=False, n_nights=5, n_exp=4,
-                 start_spread=300.0, sigma_arcsec=0.3):
+                 start_spread=300.0, sigma_arcsec=0.3, night_scale=1.0, a_min=1.8, a_span=1.8, e_max=0.35):
     """Synthetic batch in the SoA layout of outfit_obs_batch_t.
 
     Returns dict(traj_offset, mjd_tt, ra, dec, sigma_ra, sigma_dec, obs_helio_equ,
     obs_geo_ecl, truth) — all float64/uint64 numpy arrays, observations time-sorted
-    per trajectory."""
+    per trajectory. `night_scale` stretches the spacing of the nights (long arcs), `a_min / a_span / e_max` move
+    the population of truth orbits (fast movers, eccentric orbits); the defaults are the bench population."""
     if ephem is None:
         ephem = make_ephemeris()
     rng = SplitMix64(seed)
-    a = 1.8 + 1.8 * rng.uniform(n_obj)
-    e = 0.35 * rng.uniform(n_obj)
+    a = a_min + a_span * rng.uniform(n_obj)
+    e = e_max * rng.uniform(n_obj)
     inc = np.minimum(np.deg2rad(8.0) * np.sqrt(-2.0 * np.log(1.0 - rng.uniform(n_obj))), np.deg2rad(40.0))
     node = 2 * np.pi * rng.uniform(n_obj)
     argp = 2 * np.pi * rng.uniform(n_obj)
     m0 = 2 * np.pi * rng.uniform(n_obj)
     start = 60000.0 + start_spread * rng.uniform(n_obj)
-    night_off = np.array([0.0, 3.0, 7.0, 12.0, 20.0, 27.0, 35.0, 44.0])[:n_nights]
-    jitter = 0.2 * rng.uniform(n_obj * n_nights).reshape(n_obj, n_nights)
+    night_off = night_scale * np.array([0.0, 3.0, 7.0, 12.0, 20.0, 27.0, 35.0, 44.0])[:n_nights]
+    jitter = (0.2 * night_scale) * rng.uniform(n_obj * n_nights).reshape(n_obj, n_nights)
     nights = start[:, None] + night_off[None, :] + jitter
     mjd = (nights[:, :, None] + 0.02 * np.arange(n_exp)[None, None, :]).reshape(n_obj, n_nights * n_exp)
     n_obs = n_nights * n_exp

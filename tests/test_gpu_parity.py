@@ -204,6 +204,29 @@ def test_default_params_with_noise_12000_objects(ephem_dict):
         s.close()
 
 
+@pytest.mark.parametrize("kw", [
+    dict(night_scale=12.0, n_nights=8),                          # 1.4-year arcs: 30 - 110 d between nights, the mean longitude jumps by 0.1 - 1 rad
+    dict(a_min=0.75, a_span=0.9, e_max=0.9),                     # fast, eccentric movers, close approaches
+    dict(night_scale=4.0, a_min=0.9, a_span=2.0, e_max=0.97, n_nights=6, n_exp=3),
+], ids=["long_arcs", "fast_eccentric", "mixed"])
+def test_populations_that_stress_the_residual_screen(kw):
+    """device/screen.hpp carries the Kepler solution from one observation of a candidate to the next and falls back to
+    the reference's own iteration after a jump of more than 0.5 rad or when its steps do not shrink; candidates that come
+    close to parabolic get a wide contender window (level bits). The bench population (20-day arcs, e < 0.35) hardly
+    goes there: these three do — long arcs, fast eccentric movers, both — with the RMS window open to every observation
+    (`IODParams` default `extf = -1`). Same bytes as the oracle in the glibc-faithful mode, its tolerances in the other."""
+    eph = synth.make_ephemeris(mjd_start=59984.0, n_blocks=40)
+    ds = synth.make_dataset(700, seed=20263300 + len(kw), ephem=eph, **kw)
+    batch, ephem = outfit_amd.ObsBatch.from_dict(ds), outfit_amd.Ephemeris.from_dict(eph)
+    params = synth.bench_params(outfit_amd.IODParams())
+    got = outfit_amd.fit_full_iod_records(batch, ephem, params, 1)
+    ref = oracle(params, batch, ephem)
+    assert (ref["status"] == 0).sum() > 300
+    compare(got, ref)
+    if outfit_amd.get_math_mode() == outfit_amd.MATH_GLIBC:
+        assert got.tobytes() == ref.tobytes()
+
+
 def test_ragged_and_degenerate_trajectories(ephem_dict):
     """Ragged lengths, < 3 observations, empty trajectory, no feasible triplet, > max_obs_for_triplets."""
     ds = synth.make_dataset(40, seed=5, ephem=ephem_dict, n_nights=8, n_exp=4)  # 32 obs each
