@@ -134,12 +134,17 @@ __device__ __forceinline__ bool screen_kepler(const Equinoctial& q, const TwoBod
   if (S.warm) {
     const double lam = lamu + S.off;
     const double d0 = fma(-q.h, S.sx, fma(-q.k, S.cx, 1.0));  // dlam/dF at the previous solution
-    double x = fma(lam - S.lam, rcp_nr1(d0), S.x);
-    if (!(fabs(x - S.x) < 0.5)) {
+    const double dx = (lam - S.lam) * rcp_nr1(d0);
+    double x = S.x + dx;
+    if (!(fabs(dx) < 0.5)) {
       full = true;
     } else {
-      double sx, cx;
-      sincos_k(x, K, sx, cx);
+      // sin / cos at the prediction: by angle addition from the previous solution for a small step (most observations:
+      // 0.02 d within a night is 1e-4 rad, a few days 1e-2), a fresh evaluation otherwise. Chained rotations drift by a
+      // random walk of ~1e-16 rad each (tens per candidate: 1e-15, against a slack of 1.6e-10).
+      double sx = S.sx, cx = S.cx;
+      if (fabs(dx) < 0.0625) rotate_small(sx, cx, dx, C);
+      else sincos_k(x, K, sx, cx);
       bool ok = false;
       for (int it = 0; it < 6; ++it) {
         const double f = fma(q.h, cx, fma(-q.k, sx, x - lam));
