@@ -227,8 +227,10 @@ double orc_sin(double x) { double s, c; orc_sincos(x, &s, &c); return s; }
 double orc_cos(double x) { double s, c; orc_sincos(x, &s, &c); return c; }
 
 /* acos by one Newton step in double-double from the libm seed: y1 = y0 + (cos y0 - x)/sin y0 */
+static int scoped_cr(void);
 double orc_acos(double x) {
   if (LIBM(2) || !(fabs(x) <= 1.0)) return acos(x);
+  if (orc_math_glibc && !scoped_cr()) return orc_glibc_acos(x);  /* glibc 2.35's acos, restated (glibcmath3.c) */
   if (x == 1.0) return 0.0;
   if (x == -1.0) return CRM_PI_HI;
   double y0 = acos(x);

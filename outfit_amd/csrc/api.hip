@@ -1424,15 +1424,16 @@ int outfit_hip_crmath_eval(int fn, uint64_t n, const double* x, double* out) {
 }
 
 int outfit_hip_glibc_eval(int fn, uint64_t n, const double* x, const double* y, double* out) {
-  if (fn < 0 || fn > 4) return fail(OUTFIT_ERR_INVALID_PARAM, "fn: 0 sin1, 1 cos1, 2 tan, 3 atan2(x, y), 4 hypot(x, y)");
-  if (n && (!x || !out || (fn >= 3 && !y))) return fail(OUTFIT_ERR_INVALID_BATCH, "NULL argument");
+  if (fn < 0 || fn > 5) return fail(OUTFIT_ERR_INVALID_PARAM, "fn: 0 sin1, 1 cos1, 2 tan, 3 atan2(x, y), 4 hypot(x, y), 5 acos");
+  const bool two = fn == 3 || fn == 4;
+  if (n && (!x || !out || (two && !y))) return fail(OUTFIT_ERR_INVALID_BATCH, "NULL argument");
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
     return fail(OUTFIT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
   if (n == 0) return OUTFIT_OK;
   DevBuf<double> dx, dy, dz;
   TRY_RC(upload(dx, x, (size_t)n));
-  if (fn >= 3) TRY_RC(upload(dy, y, (size_t)n));
+  if (two) TRY_RC(upload(dy, y, (size_t)n));
   HIP_TRY(dz.alloc((size_t)n));
   hipError_t e = outfit::launch_glibc_eval(fn, n, dx.p, dy.p, dz.p, nullptr);
   if (e == hipSuccess) e = hipDeviceSynchronize();

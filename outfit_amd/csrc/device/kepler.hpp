@@ -15,6 +15,7 @@
 #include "crmath.hpp"
 #include "glibcmath.hpp"
 #include "glibcmath2.hpp"
+#include "glibcmath3.hpp"
 #include "fastdiv.hpp"
 
 namespace outfit {
@@ -193,7 +194,7 @@ __device__ __forceinline__ double prelim_elliptic(const KeplerProblem& p) {
   if (p.e0 < contr) return n * p.dt / sqrt(-p.alpha);
   const double c = (1.0 - p.r0 / a0) / p.e0;
   double u0;
-  if (fabs(c) <= 1.0) u0 = crm::acos(c);  // correctly rounded: see crmath.hpp
+  if (fabs(c) <= 1.0) u0 = p.math_mode == kMathGlibc ? glm::acos(c) : crm::acos(c);  // glibc's bits, or correctly rounded (crmath.hpp)
   else if (c >= 1.0) u0 = 0.0;
   else u0 = kPi;
   if (p.sig0 < 0.0) u0 = -u0;

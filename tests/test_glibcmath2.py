@@ -1,8 +1,8 @@
-"""glibc 2.35's atan2 / tan / hypot and its STANDALONE sin / cos, restated (oracle/glibcmath2.c, oracle/glibcmath.c
-`orc_glibc_sin1 / cos1`; device/glibcmath2.hpp, glm::sin1 / cos1).
+"""glibc 2.35's atan2 / tan / hypot / acos and its STANDALONE sin / cos, restated (oracle/glibcmath2.c, glibcmath3.c,
+oracle/glibcmath.c `orc_glibc_sin1 / cos1`; device/glibcmath2.hpp, glibcmath3.hpp, glm::sin1 / cos1).
 
 Pins: on a glibc / x86-64 / FMA host the restatements equal the platform libm bit for bit (2 x 10^6 arguments per
-function here; tools/glibc_pin2.c ran 2 x 10^9). The finding of round 3 is asserted too: glibc's sin(x) / cos(x) and
+function here; tools/glibc_pin2.c and glibc_pin3.c ran 2 x 10^9). The finding of round 3 is asserted too: glibc's sin(x) / cos(x) and
 its sincos(x) are DIFFERENT functions at the last bit (0.07 % of arguments) — the first two are what an isolated
 `x.sin()` of the reference calls, the third what a sin/cos pair on one operand calls (LLVM's FSINCOS combine).
 On the device (-m gpu) the same functions equal the restatement bit for bit.
@@ -23,7 +23,7 @@ N = 2_000_000
 def L():
     lib = O.lib()
     for name, nargs in (("orc_glibc_sin", 1), ("orc_glibc_cos", 1), ("orc_glibc_sin1", 1), ("orc_glibc_cos1", 1),
-                        ("orc_glibc_tan", 1), ("orc_glibc_atan2", 2), ("orc_glibc_hypot", 2)):
+                        ("orc_glibc_tan", 1), ("orc_glibc_atan2", 2), ("orc_glibc_hypot", 2), ("orc_glibc_acos", 1)):
         f = getattr(lib, name)
         f.restype, f.argtypes = C.c_double, [C.c_double] * nargs
     return lib
@@ -34,6 +34,15 @@ def args(kind, n, seed):
     if kind == "angle":
         return np.concatenate([rng.uniform(-40, 40, n // 2), rng.uniform(-7, 7, n // 4), rng.uniform(-1e5, 1e5, n // 8),
                                rng.uniform(-1, 1, n // 8) * 2.0 ** rng.integers(-30, 2, n // 8)])
+    if kind == "acos":   # the whole domain, dense near +-1 and around every interval boundary of e_asin.c, tiny, out of range
+        edges = np.array([0.125, 0.25, 0.5, 0.75, 0.921875, 0.953125, 0.96875, 1.0])
+        near = np.nextafter(np.repeat(edges, 41), np.inf) * 0 + (np.repeat(edges, 41).view(np.int64) + np.tile(np.arange(-20, 21), 8)).view(np.float64)
+        parts = [rng.uniform(-1, 1, n // 2), 1.0 - rng.uniform(0, 1, n // 4) * 2.0 ** -rng.integers(0, 54, n // 4).astype(float),
+                 rng.uniform(-1, 1, n // 8) * 2.0 ** rng.integers(-70, 0, n // 8), near, -near,
+                 np.array([0.0, -0.0, 1.0, -1.0, 1.5, -1.5, np.inf, -np.inf, np.nan])]
+        x = np.concatenate(parts)
+        x[n // 2: n // 2 + n // 8] *= -1.0
+        return x
     if kind == "tan":
         return np.concatenate([rng.uniform(-1.6, 1.6, n // 2), rng.uniform(-25, 25, n // 4),
                                1.5707963267948966 + rng.uniform(-1, 1, n // 8) * 2.0 ** rng.integers(-40, -3, n // 8),
@@ -54,7 +63,7 @@ def vec(f, *a):
 @pytest.mark.skipif(not host_is_glibc_x86_64(), reason="the platform libm is the reference here: needs glibc on x86-64 with FMA")
 def test_restatements_equal_the_platform_libm(L):
     libm = C.CDLL("libm.so.6")   # the entry points themselves (numpy may route through its own SIMD kernels)
-    for name, nargs in (("sin", 1), ("cos", 1), ("tan", 1), ("atan2", 2), ("hypot", 2)):
+    for name, nargs in (("sin", 1), ("cos", 1), ("tan", 1), ("atan2", 2), ("hypot", 2), ("acos", 1)):
         f = getattr(libm, name)
         f.restype, f.argtypes = C.c_double, [C.c_double] * nargs
     n = N // 10
@@ -66,6 +75,10 @@ def test_restatements_equal_the_platform_libm(L):
     y, xx = args("pair", n, 3)
     assert np.array_equal(vec(L.orc_glibc_atan2, y, xx), vec(libm.atan2, y, xx))
     assert np.array_equal(vec(L.orc_glibc_hypot, y, xx), vec(libm.hypot, y, xx))
+    a = args("acos", n, 5)
+    got, want = vec(L.orc_glibc_acos, a), vec(libm.acos, a)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.array_equal(got[~np.isnan(got)].view(np.uint64), want[~np.isnan(want)].view(np.uint64))
 
 
 @pytest.mark.skipif(not host_is_glibc_x86_64(), reason="needs glibc on x86-64 with FMA")
@@ -111,6 +124,10 @@ def test_device_functions_equal_the_restatement(L):
     y, xx = args("pair", n, 13)
     assert np.array_equal(dev(3, y, xx).view(np.uint64), vec(L.orc_glibc_atan2, y, xx).view(np.uint64))
     assert np.array_equal(dev(4, y, xx).view(np.uint64), vec(L.orc_glibc_hypot, y, xx).view(np.uint64))
+    a = args("acos", n, 14)
+    got, want = dev(5, a), vec(L.orc_glibc_acos, a)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.array_equal(got[~np.isnan(got)].view(np.uint64), want[~np.isnan(want)].view(np.uint64))
     # special values of atan2 (e_atan2.c's prologue) and hypot
     sp = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, -1.0, 1e-320, 1e308])
     yy, xs = np.meshgrid(sp, sp)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Tables of glibc 2.35's table-driven atan2 and tan (IBM Accurate Mathematical Library, sysdeps/ieee754/dbl-64/
-e_atan2.c `cij`, s_tan.c `xfg`), read out of the installed libm.so.6 for the glibc-faithful restatement
-(oracle/glibcmath2.c, outfit_amd/csrc/device/glibcmath2.hpp).
+"""Tables of glibc 2.35's table-driven atan2, tan and acos (IBM Accurate Mathematical Library, sysdeps/ieee754/dbl-64/
+e_atan2.c `cij`, s_tan.c `xfg`, asincos.tbl `asncs`, root.tbl `inroot`, powtwo.tbl `powtwo`), read out of the installed
+libm.so.6 for the glibc-faithful restatement (oracle/glibcmath2.c, glibcmath3.c, outfit_amd/csrc/device/glibcmath2.hpp, glibcmath3.hpp).
 
 Unlike the sin/cos and exp tables (tools/gen_glibc_tables.py, regenerated with mpmath) these cannot be regenerated:
 their nodes x_i are "accurate table" points chosen by a search so that atan(x_i) / tan(x_i) are unusually close to
@@ -24,6 +24,9 @@ LIBM = sys.argv[1] if len(sys.argv) > 1 else "/lib/x86_64-linux-gnu/libm.so.6"
 KNOWN = {  # sha256 of libm.so.6 -> (cij file offset, xfg file offset, description)
     "e5141752c850ea45691513faadc577133fedf77bcbf19473f97e7247561254b2":
         (0xbe0e0, 0xc15c0, "Ubuntu GLIBC 2.35-0ubuntu3.12, x86-64, Build ID df46fc5774ae8aaaf6efcb97dc7b91532056b898"),
+}
+KNOWN3 = {  # sha256 -> (asncs, inroot, powtwo): the addresses __ieee754_acos_fma (0x77960 in that build) loads them from
+    "e5141752c850ea45691513faadc577133fedf77bcbf19473f97e7247561254b2": (0xb90a0, 0xb8ca0, 0xb8bc0),
 }
 
 
@@ -56,6 +59,36 @@ def main():
          f"__device__ const double kXfg[186][4] = {{\n{rows(xfg)}\n}};\n}}  // namespace glm\n}}  // namespace outfit\n")
     open(os.path.join(ROOT, "outfit_amd", "csrc", "device", "glibc_tables2.hpp"), "w").write(d)
     print("wrote oracle/glibc_tables2.h and outfit_amd/csrc/device/glibc_tables2.hpp from", what)
+
+    # ---- acos: asncs (2568 doubles: per node x_i, the Taylor coefficients of asin at x_i and asin(x_i) in two parts),
+    # inroot (128: 1/sqrt seeds), powtwo (28: powers of two)
+    off_a, off_r, off_p = KNOWN3[sha]
+    asncs = struct.unpack("<2568d", data[off_a: off_a + 8 * 2568])
+    inroot = struct.unpack("<128d", data[off_r: off_r + 8 * 128])
+    powtwo = struct.unpack("<28d", data[off_p: off_p + 8 * 28])
+    assert all(powtwo[i] == 2.0 ** i for i in range(28))
+    assert abs(inroot[0] - 1.4087) < 1e-3 and abs(inroot[127] - 0.7085) < 1e-3 and all(inroot[i] > inroot[i + 1] for i in range(127))
+    for i in range(32):       # 0.125 <= x < 0.25: entries of 11, node, c1, .., asin(node) low / high at +7 / +8
+        n = 11 * i
+        assert abs(asncs[n + 8] + asncs[n + 7] - math.asin(asncs[n])) < 1e-16 and 0.125 <= asncs[n] < 0.25, i
+    for i in range(116, 120):  # 0.953125 <= x < 0.96875: entries of 15, asin(node) at +12
+        n = 15 * i + 768
+        assert abs(asncs[n + 12] + asncs[n + 11] - math.asin(asncs[n])) < 1e-15 and 0.953 <= asncs[n] < 0.969, i
+    header3 = (f"glibc 2.35 acos tables `asncs` (2568), `inroot` (128), `powtwo` (28), extracted by tools/extract_glibc_tables.py\n"
+               f"from {what} (sha256 {sha[:16]}...). Data of a third-party library (glibc, LGPL-2.1); see the tool.")
+
+    def flat(tab, per=4):
+        return ",\n".join("  " + ", ".join(float.hex(v) for v in tab[i:i + per]) for i in range(0, len(tab), per))
+    c3 = ("/* " + header3.replace("\n", "\n * ") + " */\n#pragma once\n"
+          f"static const double orc_glibc_asncs[2568] = {{\n{flat(asncs)}\n}};\n"
+          f"static const double orc_glibc_inroot[128] = {{\n{flat(inroot)}\n}};\n"
+          f"static const double orc_glibc_powtwo[28] = {{\n{flat(powtwo)}\n}};\n")
+    open(os.path.join(ROOT, "oracle", "glibc_tables3.h"), "w").write(c3)
+    d3 = ("// " + header3.replace("\n", "\n// ") + "\n#pragma once\nnamespace outfit {\nnamespace glm {\n"
+          f"__device__ const double kAsncs[2568] = {{\n{flat(asncs)}\n}};\n"
+          f"__device__ const double kInroot[128] = {{\n{flat(inroot)}\n}};\n}}  // namespace glm\n}}  // namespace outfit\n")
+    open(os.path.join(ROOT, "outfit_amd", "csrc", "device", "glibc_tables3.hpp"), "w").write(d3)
+    print("wrote oracle/glibc_tables3.h and outfit_amd/csrc/device/glibc_tables3.hpp")
 
 
 if __name__ == "__main__":
