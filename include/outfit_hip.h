@@ -504,7 +504,7 @@ int outfit_hip_crmath_eval(int fn, uint64_t n, const double *x, double *out);
 /* The device's glibc-faithful functions of round 3 on caller-given arguments (host arrays of n doubles): fn 0 / 1 = sin /
  * cos as glibc's STANDALONE entry points return them (the FMA variants; they differ from sincos's bits for 0.07 % of
  * arguments — device/glibcmath.hpp), 2 = tan, 3 = atan2(x[i], y[i]), 4 = hypot(x[i], y[i]) (device/glibcmath2.hpp),
- * 5 = acos (device/glibcmath3.hpp). */
+ * 5 = acos, 6 = log (device/glibcmath3.hpp). */
 int outfit_hip_glibc_eval(int fn, uint64_t n, const double *x, const double *y /* fn 3, 4 */, double *out);
 /* Profiling aid: streams n_doubles doubles in and out (8 bytes per lane, coalesced) `repeats` times. Run under
  * rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE it calibrates those counters for the 8-byte access width of this

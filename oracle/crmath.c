@@ -252,7 +252,7 @@ double orc_acos(double x) {
 #include <quadmath.h>
 double orc_sinh(double x) { return LIBM(4) ? sinh(x) : orc_math_glibc ? orc_glibc_sinh(x) : (double)sinhq((__float128)x); }
 double orc_cosh(double x) { return LIBM(4) ? cosh(x) : orc_math_glibc ? orc_glibc_cosh(x) : (double)coshq((__float128)x); }
-double orc_log(double x) { return LIBM(8) ? log(x) : (double)logq((__float128)x); }
+double orc_log(double x) { return LIBM(8) ? log(x) : (orc_math_glibc && !scoped_cr()) ? orc_glibc_log(x) : (double)logq((__float128)x); }
 /* atan2 of the state -> elements conversion (orb_elem.rs:58-226): a last-place difference of i or Omega is
  * amplified ~a/r in a near-parabolic 1/a and ~1/e in omega, M of a near-circular orbit. */
 double orc_atan2(double y, double x) {

@@ -85,3 +85,43 @@ double orc_glibc_acos(double x) {
   if (k > 0x7ff00000 || (k == 0x7ff00000 && (uint32_t)u != 0)) return x + x;
   return (x - x) / (x - x);
 }
+
+/* ---- log: glibc 2.35's `__log_fma` (sysdeps/ieee754/dbl-64/e_log.c, from ARM's optimized routines; the build with a fast
+ * fma computes r = fma(z, invc, -1) and never touches tab2). The reference calls f64::ln in the hyperbolic cold start
+ * (prelim_hyperbolic.rs:45-141). Zero, negative, subnormal and non-finite arguments go to the platform function (the path
+ * never produces them: the argument is c + sqrt(c^2 - 1) with c > 1). */
+double orc_glibc_log(double x) {
+  const double *D = orc_glibc_logdata, *A = D + 2, *B = D + 7, *T = D + 18;
+  uint64_t ix;
+  memcpy(&ix, &x, 8);
+  const uint32_t top = (uint32_t)(ix >> 48);
+  if (ix - 0x3fee000000000000ull <= 0x308ffffffffffull) {   /* 1 - 0x1p-4 <= x < 1 + 0x1.09p-4 */
+    if (ix == 0x3ff0000000000000ull) return 0.0;
+    const double r = x - 1.0, r2 = r * r, r3 = r * r2;
+    double y = fma(r2, B[9], fma(r, B[8], B[7]));
+    y = fma(r3, B[10], y);
+    y = fma(y, r3, fma(r2, B[6], fma(r, B[5], B[4])));
+    y = fma(y, r3, fma(r2, B[3], fma(r, B[2], B[1])));
+    const double rhi = fma(-0x1p27, r, fma(r, 0x1p27, r));
+    const double rlo = r - rhi;
+    const double sq = rhi * rhi;
+    const double hi = fma(sq, B[0], r);
+    const double lo = fma(B[0] * rlo, r + rhi, fma(sq, B[0], r - hi));
+    return fma(y, r3, lo) + hi;
+  }
+  if (top - 0x0010u >= 0x7ff0u - 0x0010u) return log(x);
+  const uint64_t tmp = ix - 0x3fe6000000000000ull;
+  const int i = (int)((tmp >> 45) & 127);
+  const int64_t k = (int64_t)tmp >> 52;
+  const uint64_t iz = ix - (tmp & 0xfff0000000000000ull);
+  double z;
+  memcpy(&z, &iz, 8);
+  const double invc = T[2 * i], logc = T[2 * i + 1], kd = (double)k;
+  const double r = fma(z, invc, -1.0);
+  const double w = fma(kd, D[0], logc);
+  const double hi = w + r;
+  const double lo = fma(kd, D[1], (w - hi) + r);
+  const double r2 = r * r;
+  const double p = fma(fma(r, A[4], A[3]), r2, fma(r, A[2], A[1]));
+  return fma(r * r2, p, fma(r2, A[0], lo)) + hi;
+}

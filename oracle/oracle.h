@@ -61,7 +61,8 @@ double orc_glibc_cos1(double x);
 double orc_sin1(double x);         /* crmath.c: an ISOLATED sin / cos of the reference (no partner on the same operand) */
 double orc_cos1(double x);
 double orc_cos1_s(double x);
-double orc_glibc_acos(double x);              /* glibcmath3.c: glibc 2.35's acos, restated */
+double orc_glibc_acos(double x);              /* glibcmath3.c: glibc 2.35's acos and log, restated */
+double orc_glibc_log(double x);
 double orc_glibc_atan2(double y, double x);   /* glibcmath2.c: glibc 2.35's atan2 / tan / hypot, restated */
 double orc_glibc_tan(double x);
 double orc_glibc_hypot(double x, double y);

@@ -1424,7 +1424,7 @@ int outfit_hip_crmath_eval(int fn, uint64_t n, const double* x, double* out) {
 }
 
 int outfit_hip_glibc_eval(int fn, uint64_t n, const double* x, const double* y, double* out) {
-  if (fn < 0 || fn > 5) return fail(OUTFIT_ERR_INVALID_PARAM, "fn: 0 sin1, 1 cos1, 2 tan, 3 atan2(x, y), 4 hypot(x, y), 5 acos");
+  if (fn < 0 || fn > 6) return fail(OUTFIT_ERR_INVALID_PARAM, "fn: 0 sin1, 1 cos1, 2 tan, 3 atan2(x, y), 4 hypot(x, y), 5 acos, 6 log");
   const bool two = fn == 3 || fn == 4;
   if (n && (!x || !out || (two && !y))) return fail(OUTFIT_ERR_INVALID_BATCH, "NULL argument");
   int n_dev = 0;

@@ -1,4 +1,4 @@
-// glibcmath3.hpp — acos with the bits glibc 2.35 (x86-64, FMA-capable CPU) returns. Companion of glibcmath.hpp (sin, cos,
+// glibcmath3.hpp — acos and log with the bits glibc 2.35 (x86-64, FMA-capable CPU) returns. Companion of glibcmath.hpp (sin, cos,
 // sinh, cosh) and glibcmath2.hpp (atan2, tan, hypot).
 //
 // Why: the elliptic cold start of the universal Kepler solver (prelim_elliptic.rs:9-31) calls f64::acos, i.e. the platform
@@ -71,6 +71,41 @@ __device__ __forceinline__ double acos(double x) {
   if (k == 0x3ff00000 && __double2loint(x) == 0) return m > 0 ? 0.0 : 0x1.921fb54442d18p+1;
   if (k > 0x7ff00000 || (k == 0x7ff00000 && __double2loint(x) != 0)) return x + x;
   return (x - x) / (x - x);
+}
+
+// ---- log: glibc 2.35's `__log_fma` (e_log.c; oracle/glibcmath3.c `orc_glibc_log`). Zero, negative, subnormal and non-finite
+// arguments go to the platform function; the path's call site (hyperbolic cold start, prelim_hyperbolic.rs) passes > 1.
+__device__ __forceinline__ double log(double x) {
+  const double *D = kLogData, *A = D + 2, *B = D + 7, *T = D + 18;
+  const unsigned long long ix = (unsigned long long)__double_as_longlong(x);
+  const unsigned top = (unsigned)(ix >> 48);
+  if (ix - 0x3fee000000000000ull <= 0x308ffffffffffull) {
+    if (ix == 0x3ff0000000000000ull) return 0.0;
+    const double r = x - 1.0, r2 = r * r, r3 = r * r2;
+    double y = fma(r2, B[9], fma(r, B[8], B[7]));
+    y = fma(r3, B[10], y);
+    y = fma(y, r3, fma(r2, B[6], fma(r, B[5], B[4])));
+    y = fma(y, r3, fma(r2, B[3], fma(r, B[2], B[1])));
+    const double rhi = fma(-0x1p27, r, fma(r, 0x1p27, r));
+    const double rlo = r - rhi;
+    const double sq = rhi * rhi;
+    const double hi = fma(sq, B[0], r);
+    const double lo = fma(B[0] * rlo, r + rhi, fma(sq, B[0], r - hi));
+    return fma(y, r3, lo) + hi;
+  }
+  if (top - 0x0010u >= 0x7ff0u - 0x0010u) return ::log(x);
+  const unsigned long long tmp = ix - 0x3fe6000000000000ull;
+  const int i = (int)((tmp >> 45) & 127);
+  const long long k = (long long)tmp >> 52;
+  const double z = __longlong_as_double((long long)(ix - (tmp & 0xfff0000000000000ull)));
+  const double invc = T[2 * i], logc = T[2 * i + 1], kd = (double)k;
+  const double r = fma(z, invc, -1.0);
+  const double w = fma(kd, D[0], logc);
+  const double hi = w + r;
+  const double lo = fma(kd, D[1], (w - hi) + r);
+  const double r2 = r * r;
+  const double p = fma(fma(r, A[4], A[3]), r2, fma(r, A[2], A[1]));
+  return fma(r * r2, p, fma(r2, A[0], lo)) + hi;
 }
 
 }  // namespace glm

@@ -226,8 +226,8 @@ __device__ __forceinline__ double prelim_hyperbolic(const KeplerProblem& p) {
   const double a0 = -1.0 / p.alpha;
   const double n = sqrt(kMu) * sqrt(p.alpha * p.alpha * p.alpha);
   const double c = (1.0 - p.r0 / a0) / p.e0;
-  // log / sinh / cosh correctly rounded (crmath.hpp): this value seeds the chaotically sensitive loop
-  double f0 = (c > 1.0) ? crm::log(c + sqrt(c * c - 1.0)) : 0.0;
+  // log / sinh / cosh correctly rounded (crmath.hpp) or glibc's bits (glibcmath*.hpp): this value seeds the chaotically sensitive loop
+  double f0 = (c > 1.0) ? (p.math_mode == kMathGlibc ? glm::log(c + sqrt(c * c - 1.0)) : crm::log(c + sqrt(c * c - 1.0))) : 0.0;
   if (p.sig0 < 0.0) f0 = -f0;
   double sh, ch;
   sinhcosh_mode(p.math_mode, f0, sh, ch);

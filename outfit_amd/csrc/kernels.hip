@@ -1362,13 +1362,13 @@ k_crmath_eval(int fn, unsigned long long n, const double* x, double* out, SinCos
 
 // outfit_hip_glibc_eval: the glibc-faithful functions of round 3 on given arguments (checked against the oracle's
 // restatement and, on glibc hosts, against the platform libm by the tests). fn: 0 sin1, 1 cos1 (the standalone
-// entry points), 2 tan, 3 atan2(x[i], y[i]), 4 hypot(x[i], y[i]), 5 acos.
+// entry points), 2 tan, 3 atan2(x[i], y[i]), 4 hypot(x[i], y[i]), 5 acos, 6 log.
 __global__ void __launch_bounds__(256)
 k_glibc_eval(int fn, unsigned long long n, const double* x, const double* y, double* out) {
   const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double a = x[i], b = (fn == 3 || fn == 4) ? y[i] : 0.0;
-  out[i] = fn == 0 ? glm::sin1(a) : fn == 1 ? glm::cos1(a) : fn == 2 ? glm::tan(a) : fn == 3 ? glm::atan2(a, b) : fn == 4 ? glm::hypot(a, b) : glm::acos(a);
+  out[i] = fn == 0 ? glm::sin1(a) : fn == 1 ? glm::cos1(a) : fn == 2 ? glm::tan(a) : fn == 3 ? glm::atan2(a, b) : fn == 4 ? glm::hypot(a, b) : fn == 5 ? glm::acos(a) : glm::log(a);
 }
 hipError_t launch_glibc_eval(int fn, unsigned long long n, const double* x, const double* y, double* out, hipStream_t s) {
   if (n == 0) return hipSuccess;

@@ -1,4 +1,4 @@
-"""glibc 2.35's atan2 / tan / hypot / acos and its STANDALONE sin / cos, restated (oracle/glibcmath2.c, glibcmath3.c,
+"""glibc 2.35's atan2 / tan / hypot / acos / log and its STANDALONE sin / cos, restated (oracle/glibcmath2.c, glibcmath3.c,
 oracle/glibcmath.c `orc_glibc_sin1 / cos1`; device/glibcmath2.hpp, glibcmath3.hpp, glm::sin1 / cos1).
 
 Pins: on a glibc / x86-64 / FMA host the restatements equal the platform libm bit for bit (2 x 10^6 arguments per
@@ -23,7 +23,7 @@ N = 2_000_000
 def L():
     lib = O.lib()
     for name, nargs in (("orc_glibc_sin", 1), ("orc_glibc_cos", 1), ("orc_glibc_sin1", 1), ("orc_glibc_cos1", 1),
-                        ("orc_glibc_tan", 1), ("orc_glibc_atan2", 2), ("orc_glibc_hypot", 2), ("orc_glibc_acos", 1)):
+                        ("orc_glibc_tan", 1), ("orc_glibc_atan2", 2), ("orc_glibc_hypot", 2), ("orc_glibc_acos", 1), ("orc_glibc_log", 1)):
         f = getattr(lib, name)
         f.restype, f.argtypes = C.c_double, [C.c_double] * nargs
     return lib
@@ -43,6 +43,10 @@ def args(kind, n, seed):
         x = np.concatenate(parts)
         x[n // 2: n // 2 + n // 8] *= -1.0
         return x
+    if kind == "log":    # the hyperbolic cold start passes c + sqrt(c^2 - 1) > 1; the polynomial branch around 1; every exponent
+        return np.concatenate([1.0 + rng.uniform(0, 30, n // 2), np.exp(rng.uniform(-700, 700, n // 4)),
+                               1.0 + rng.uniform(-0.07, 0.07, n // 8), 1.0 + rng.uniform(-1, 1, n // 8) * 2.0 ** -rng.integers(4, 53, n // 8).astype(float),
+                               np.array([1.0, 0.9375, 1.064697265625, np.nextafter(0.9375, 0), np.nextafter(1.064697265625, 2), 5e-324, 1e-310, np.inf])])
     if kind == "tan":
         return np.concatenate([rng.uniform(-1.6, 1.6, n // 2), rng.uniform(-25, 25, n // 4),
                                1.5707963267948966 + rng.uniform(-1, 1, n // 8) * 2.0 ** rng.integers(-40, -3, n // 8),
@@ -63,7 +67,7 @@ def vec(f, *a):
 @pytest.mark.skipif(not host_is_glibc_x86_64(), reason="the platform libm is the reference here: needs glibc on x86-64 with FMA")
 def test_restatements_equal_the_platform_libm(L):
     libm = C.CDLL("libm.so.6")   # the entry points themselves (numpy may route through its own SIMD kernels)
-    for name, nargs in (("sin", 1), ("cos", 1), ("tan", 1), ("atan2", 2), ("hypot", 2), ("acos", 1)):
+    for name, nargs in (("sin", 1), ("cos", 1), ("tan", 1), ("atan2", 2), ("hypot", 2), ("acos", 1), ("log", 1)):
         f = getattr(libm, name)
         f.restype, f.argtypes = C.c_double, [C.c_double] * nargs
     n = N // 10
@@ -79,6 +83,8 @@ def test_restatements_equal_the_platform_libm(L):
     got, want = vec(L.orc_glibc_acos, a), vec(libm.acos, a)
     assert np.array_equal(np.isnan(got), np.isnan(want))
     assert np.array_equal(got[~np.isnan(got)].view(np.uint64), want[~np.isnan(want)].view(np.uint64))
+    v = args("log", n, 6)
+    assert np.array_equal(vec(L.orc_glibc_log, v).view(np.uint64), vec(libm.log, v).view(np.uint64))
 
 
 @pytest.mark.skipif(not host_is_glibc_x86_64(), reason="needs glibc on x86-64 with FMA")
@@ -128,6 +134,8 @@ def test_device_functions_equal_the_restatement(L):
     got, want = dev(5, a), vec(L.orc_glibc_acos, a)
     assert np.array_equal(np.isnan(got), np.isnan(want))
     assert np.array_equal(got[~np.isnan(got)].view(np.uint64), want[~np.isnan(want)].view(np.uint64))
+    v = args("log", n, 15)
+    assert np.array_equal(dev(6, v).view(np.uint64), vec(L.orc_glibc_log, v).view(np.uint64))
     # special values of atan2 (e_atan2.c's prologue) and hypot
     sp = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, -1.0, 1e-320, 1e308])
     yy, xs = np.meshgrid(sp, sp)

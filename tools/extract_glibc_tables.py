@@ -25,8 +25,9 @@ KNOWN = {  # sha256 of libm.so.6 -> (cij file offset, xfg file offset, descripti
     "e5141752c850ea45691513faadc577133fedf77bcbf19473f97e7247561254b2":
         (0xbe0e0, 0xc15c0, "Ubuntu GLIBC 2.35-0ubuntu3.12, x86-64, Build ID df46fc5774ae8aaaf6efcb97dc7b91532056b898"),
 }
-KNOWN3 = {  # sha256 -> (asncs, inroot, powtwo): the addresses __ieee754_acos_fma (0x77960 in that build) loads them from
-    "e5141752c850ea45691513faadc577133fedf77bcbf19473f97e7247561254b2": (0xb90a0, 0xb8ca0, 0xb8bc0),
+KNOWN3 = {  # sha256 -> (asncs, inroot, powtwo): the addresses __ieee754_acos_fma (0x77960 in that build) loads them from;
+    # then __log_data (e_log_data.c: ln2hi, ln2lo, poly[5], poly1[11], tab[128] = {invc, logc}), read by __log_fma (0x76660)
+    "e5141752c850ea45691513faadc577133fedf77bcbf19473f97e7247561254b2": (0xb90a0, 0xb8ca0, 0xb8bc0, 0xb01e0),
 }
 
 
@@ -62,7 +63,7 @@ def main():
 
     # ---- acos: asncs (2568 doubles: per node x_i, the Taylor coefficients of asin at x_i and asin(x_i) in two parts),
     # inroot (128: 1/sqrt seeds), powtwo (28: powers of two)
-    off_a, off_r, off_p = KNOWN3[sha]
+    off_a, off_r, off_p, off_l = KNOWN3[sha]
     asncs = struct.unpack("<2568d", data[off_a: off_a + 8 * 2568])
     inroot = struct.unpack("<128d", data[off_r: off_r + 8 * 128])
     powtwo = struct.unpack("<28d", data[off_p: off_p + 8 * 28])
@@ -74,7 +75,11 @@ def main():
     for i in range(116, 120):  # 0.953125 <= x < 0.96875: entries of 15, asin(node) at +12
         n = 15 * i + 768
         assert abs(asncs[n + 12] + asncs[n + 11] - math.asin(asncs[n])) < 1e-15 and 0.953 <= asncs[n] < 0.969, i
-    header3 = (f"glibc 2.35 acos tables `asncs` (2568), `inroot` (128), `powtwo` (28), extracted by tools/extract_glibc_tables.py\n"
+    logd = struct.unpack("<274d", data[off_l: off_l + 8 * 274])   # 2 + 5 + 11 + 256
+    assert logd[0] + logd[1] == math.log(2) and abs(logd[2] + 0.5) < 1e-15 and logd[7] == -0.5
+    for i in range(128):
+        assert abs(logd[18 + 2 * i + 1] + math.log(logd[18 + 2 * i])) < 1e-15, i      # logc = log(1 / invc)
+    header3 = (f"glibc 2.35 acos tables `asncs` (2568), `inroot` (128), `powtwo` (28) and `__log_data` (274), extracted by tools/extract_glibc_tables.py\n"
                f"from {what} (sha256 {sha[:16]}...). Data of a third-party library (glibc, LGPL-2.1); see the tool.")
 
     def flat(tab, per=4):
@@ -82,11 +87,15 @@ def main():
     c3 = ("/* " + header3.replace("\n", "\n * ") + " */\n#pragma once\n"
           f"static const double orc_glibc_asncs[2568] = {{\n{flat(asncs)}\n}};\n"
           f"static const double orc_glibc_inroot[128] = {{\n{flat(inroot)}\n}};\n"
-          f"static const double orc_glibc_powtwo[28] = {{\n{flat(powtwo)}\n}};\n")
+          f"static const double orc_glibc_powtwo[28] = {{\n{flat(powtwo)}\n}};\n"
+          f"/* ln2hi, ln2lo, A[5], B[11], then 128 x (invc, logc) */\n"
+          f"static const double orc_glibc_logdata[274] = {{\n{flat(logd)}\n}};\n")
     open(os.path.join(ROOT, "oracle", "glibc_tables3.h"), "w").write(c3)
     d3 = ("// " + header3.replace("\n", "\n// ") + "\n#pragma once\nnamespace outfit {\nnamespace glm {\n"
           f"__device__ const double kAsncs[2568] = {{\n{flat(asncs)}\n}};\n"
-          f"__device__ const double kInroot[128] = {{\n{flat(inroot)}\n}};\n}}  // namespace glm\n}}  // namespace outfit\n")
+          f"__device__ const double kInroot[128] = {{\n{flat(inroot)}\n}};\n"
+          f"// ln2hi, ln2lo, A[5], B[11], then 128 x (invc, logc)\n"
+          f"__device__ const double kLogData[274] = {{\n{flat(logd)}\n}};\n}}  // namespace glm\n}}  // namespace outfit\n")
     open(os.path.join(ROOT, "outfit_amd", "csrc", "device", "glibc_tables3.hpp"), "w").write(d3)
     print("wrote oracle/glibc_tables3.h and outfit_amd/csrc/device/glibc_tables3.hpp")
 
