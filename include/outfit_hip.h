@@ -184,12 +184,13 @@ int  outfit_hip_iod_params_validate(const outfit_iod_params_t *p);
  * orb_elem.rs:58-226). The reference calls the platform libm there, so its own results depend on that libm; the
  * loop amplifies a last-place difference to ~1e-10.
  *   OUTFIT_MATH_GLIBC (default): sin, cos (the sincos pair AND the standalone entry points, which differ in glibc),
- *       sinh, cosh, atan2, tan, hypot return the bits of glibc 2.35 on x86-64 with FMA (restated, device/glibcmath.hpp,
- *       glibcmath2.hpp) — what the reference computes on the platform its known answers were recorded on; acos and log
- *       (cold starts only) are correctly rounded. The RMS of every candidate is screened with the platform functions and
- *       the contenders (within 1e-4 of the screened minimum) are re-evaluated with glibc's (kernel K3b). Measured against
- *       the reference's arithmetic on glibc (the CPU restatement with the platform libm): 300 000 of 300 000 records
- *       byte-identical, `rms` included (profiles/round03_parity_glibc_bench_300000.json).
+ *       sinh, cosh, atan2, tan, hypot, acos, log return the bits of glibc 2.35 on x86-64 with FMA (restated,
+ *       device/glibcmath.hpp, glibcmath2.hpp, glibcmath3.hpp) — what the reference computes on the platform its known
+ *       answers were recorded on. The RMS of every candidate is screened in a cheap arithmetic with an error bound and
+ *       the contenders (those that can still be the minimum) are re-evaluated with glibc's functions (kernel K3b).
+ *       Measured against the reference's arithmetic on glibc (the CPU restatement with the platform libm): 300 000 of
+ *       300 000 (bench workload) and 200 000 of 200 000 (topocentric) records byte-identical, `rms` included
+ *       (profiles/round03b_parity_glibc_bench_300000_screen.json, round03e_parity_glibc_topo_200000.json).
  *   OUTFIT_MATH_CORRECTLY_ROUNDED: every such function correctly rounded — platform independent (what a reference
  *       built against another libm would be compared with); against a glibc run of the reference ~0.8 % of the
  *       orbits move by more than 1e-12 rad.
