@@ -571,9 +571,14 @@ void orc_differential_correction(const outfit_iod_params_t *ip, const outfit_dif
   el.epoch = out->iod.epoch;
   memcpy(el.e, out->iod.elem, sizeof el.e);
   orc_equinoctial eq;
-  orc_cr_scope += 1; /* from here on every elementary function is correctly rounded (crmath.c) */
+  /* Correctly-rounded mode: from here on every elementary function is correctly rounded (crmath.c) — the corrector's
+   * ill-conditioned normal equations amplify a last place, so that mode pins every function. Glibc-faithful mode
+   * (orc_math_glibc): no scope — the corrector runs on glibc's bits like the rest of the path, i.e. as the reference does
+   * on a glibc host (round 3: every function it calls is restated). */
+  const int scope = orc_math_glibc ? 0 : 1;
+  orc_cr_scope += scope;
   int ec = orc_to_equinoctial(&el, &eq);
-  orc_cr_scope -= 1;
+  orc_cr_scope -= scope;
   if (ec) { out->status = OUTFIT_LSQ_CONVERSION_ERROR; out->conv_error = ec; return; }
 
   orc_obs_fit *fit = (orc_obs_fit *)calloc(n ? n : 1, sizeof *fit);
@@ -592,10 +597,10 @@ void orc_differential_correction(const outfit_iod_params_t *ip, const outfit_dif
   }
   orc_diffcor_output dc;
   memset(&dc, 0, sizeof dc);
-  orc_cr_scope += 1;
+  orc_cr_scope += scope;
   int rc = orc_run_differential_correction(&eq, b->mjd_tt + base, b->ra + base, b->dec + base, obs_pos,
                                            n, fit, cfg, &dc);
-  orc_cr_scope -= 1;
+  orc_cr_scope -= scope;
   out->total_newton_iterations = dc.total_newton_iterations;
   out->outer_passes = dc.outer_passes;
   out->epoch = eq.epoch;

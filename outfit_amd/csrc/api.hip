@@ -913,6 +913,7 @@ int session_run_lsq(outfit_hip_session* s, const outfit_diffcor_config_t* cfg,
   a.cfg = make_diffcor_config(cfg);
   a.res = s->dc_res.p; a.sel = s->dc_sel.p; a.cov = s->dc_cov.p; a.qr_work = s->dc_qr.p;
   a.out = s->dc_out.p; a.obs_fit = s->dc_fit.p; a.queue = s->queue.p + 2;
+  a.math_mode = s->math_mode;
   {
     Stamp stamp(s, st, K_DIFFCOR);
     // lanes per trajectory: enough to split the observation loop, not more than the mean arc length pays for

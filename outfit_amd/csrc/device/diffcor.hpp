@@ -43,9 +43,14 @@ struct PartialsFrame {
   bool elliptic;
 };
 
+// kFn (orbit.hpp): kFnCr — correctly-rounded functions throughout the corrector (the correctly-rounded math mode: its
+// ill-conditioned normal equations amplify a last place, so that mode pins every function); kFnGlibc — glibc's bits
+// throughout, i.e. what the reference computes on a glibc host (round 3: the CPU restatement in that mode equals its own
+// platform-libm run on every byte of 3 000 + 3 000 corrector records; the correctly-rounded one on 80 % of them).
+template <int kFn>
 __device__ __forceinline__ PartialsFrame partials_frame(const Equinoctial& q) {
   PartialsFrame P;
-  P.F = twobody_frame<true>(q);  // correctly-rounded functions throughout the corrector (orbit.hpp)
+  P.F = twobody_frame<kFn>(q);
   P.elliptic = !(sqrt(P.F.e2) >= 1.0);  // check_elliptical_orbit (observation_ephemeris.rs:288-296)
   const double u = 1.0 + q.p * q.p + q.q * q.q;
   P.inv_u = 1.0 / u;
@@ -67,6 +72,7 @@ struct ObsPartials {
 };
 
 // compute_obs_and_partials_2body for one observation; false = Err (the observation is skipped)
+template <int kFn>
 __device__ __forceinline__ bool obs_and_partials(const Equinoctial& q, const PartialsFrame& P, double mjd,
                                                  const Vec3& obs_pos, ObsPartials& o) {
   if (!P.elliptic) return false;
@@ -75,7 +81,7 @@ __device__ __forceinline__ bool obs_and_partials(const Equinoctial& q, const Par
   double lam = principal_angle_fast(q.lambda + F.n * (dt - 0.0));
   if (lam < F.varpi) lam += kTwoPi;
   double x, sx, cx;
-  if (!solve_kepler_equation<true>(q, F, lam, x, sx, cx)) return false;
+  if (!solve_kepler_equation<kFn>(q, F, lam, x, sx, cx)) return false;
   const double a = q.a;
   const double xe = a * (F.one_bh2 * cx + F.bet * sx - q.k);
   const double ye = a * (F.one_bk2 * sx + F.bet * cx - q.h);
@@ -115,10 +121,10 @@ __device__ __forceinline__ bool obs_and_partials(const Equinoctial& q, const Par
   const double lt = rel_norm / kVlightAU;
   const Vec3 cor = {rel.x - lt * vq.x, rel.y - lt * vq.y, rel.z - lt * vq.z};
   const double rho = norm(cor);
-  const double rho_xy = crm::hypot(cor.x, cor.y);
+  const double rho_xy = hypot_sel<kFn>(cor.x, cor.y);
   const double rho_xy_sq = rho_xy * rho_xy;
-  o.dec = crm::atan2(cor.z, rho_xy);
-  double alpha = crm::atan2(cor.y, cor.x);
+  o.dec = atan2_sel<kFn>(cor.z, rho_xy);
+  double alpha = atan2_sel<kFn>(cor.y, cor.x);
   if (alpha < 0.0) alpha += kTwoPi;  // rem_euclid(TAU) of a value in [-pi, pi]
   o.ra = alpha;
   const double rho_sq = rho * rho;

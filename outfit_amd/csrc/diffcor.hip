@@ -55,7 +55,7 @@ __device__ __forceinline__ unsigned group_sum(unsigned v) {
 // One wave per SIMD: with the correctly-rounded functions inlined the kernel wants ~480 registers (256 VGPR +
 // AGPRs). Measured at (64, 2), 111 spilled VGPRs with the three big helpers out of line: the same 1.99 ms per
 // 100 k objects as one wave — the kernel is bound by fp64 issue, not by latency, so occupancy buys nothing.
-template <unsigned kG>
+template <unsigned kG, int kFn>  // kFn: kFnCr (correctly-rounded math mode) | kFnGlibc (glibc-faithful mode), diffcor.hpp
 __global__ void __launch_bounds__(64, 1)
 k_diffcor(DiffCorArgs A) {
   // normal matrix (36), right-hand side (6) and weighted square sum (1) accumulate in LDS, [entry][slot]
@@ -185,7 +185,7 @@ k_diffcor(DiffCorArgs A) {
         el.epoch = seed.epoch;
 #pragma unroll
         for (int k = 0; k < 6; ++k) el.e[k] = seed.elem[k];
-        conv_error = to_equinoctial<true>(el, q);
+        conv_error = to_equinoctial<kFn>(el, q);
         if (conv_error) status = 3;  // OUTFIT_LSQ_CONVERSION_ERROR
       }
       if (status == 0) {
@@ -203,7 +203,7 @@ k_diffcor(DiffCorArgs A) {
     if (phase == kIterate) {
       total_iters += 1;
       // ---- single_iteration (single_iteration.rs:158-328) ----------------------------------------------
-      const PartialsFrame P = partials_frame(q);
+      const PartialsFrame P = partials_frame<kFn>(q);
 #pragma unroll
       for (int i = 0; i < 43; ++i) sN[i][lane] = 0.0;
       unsigned active = 0;
@@ -220,7 +220,7 @@ k_diffcor(DiffCorArgs A) {
           const unsigned char s = sel_written ? A.sel[o] : (unsigned char)0;
           if (s == 0) {
             const Vec3 op = {A.obs_pos[3 * o], A.obs_pos[3 * o + 1], A.obs_pos[3 * o + 2]};
-            if (obs_and_partials(q, P, A.mjd[o], op, ob)) {
+            if (obs_and_partials<kFn>(q, P, A.mjd[o], op, ob)) {
               eq_active = true;
               const double sra = A.sra[o], sdec = A.sdec[o];
               rra = angular_diff(A.ra[o] - 0.0, ob.ra);
@@ -346,7 +346,7 @@ k_diffcor(DiffCorArgs A) {
 #pragma unroll
       for (int i = 0; i < 36; ++i) cov[i] = A.cov[((unsigned long long)(cur ^ 1u) * 36ull + i) * A.n_traj + t];
       const double* ra_ = A.res + (unsigned long long)(cur ^ 1u) * RB;
-      const PartialsFrame Pin = partials_frame(q_in);
+      const PartialsFrame Pin = partials_frame<kFn>(q_in);
       unsigned changes = 0;
 #pragma unroll 1
       for (unsigned i = sub; i < n; i += kG) {
@@ -360,7 +360,7 @@ k_diffcor(DiffCorArgs A) {
         ObsPartials ob;
         if (s == 0) {
           const Vec3 op = {A.obs_pos[3 * o], A.obs_pos[3 * o + 1], A.obs_pos[3 * o + 2]};
-          eq_active = obs_and_partials(q_in, Pin, A.mjd[o], op, ob);
+          eq_active = obs_and_partials<kFn>(q_in, Pin, A.mjd[o], op, ob);
         }
         double ga[6], gd[6];
 #pragma unroll
@@ -406,11 +406,16 @@ hipError_t launch_diffcor(const DiffCorArgs& a, unsigned group, unsigned n_cu, h
   const unsigned grid = (unsigned)std::min<unsigned long long>(need, 4ull * (n_cu ? n_cu : 256u));
   hipError_t e = hipMemsetAsync(a.queue, 0, sizeof(unsigned long long), s);
   if (e != hipSuccess) return e;
+  const bool glibc = a.math_mode == kMathGlibc;
   switch (group) {
-    case 1: hipLaunchKernelGGL(k_diffcor<1>, dim3(grid), dim3(64), 0, s, a); break;
-    case 2: hipLaunchKernelGGL(k_diffcor<2>, dim3(grid), dim3(64), 0, s, a); break;
-    case 4: hipLaunchKernelGGL(k_diffcor<4>, dim3(grid), dim3(64), 0, s, a); break;
-    case 8: hipLaunchKernelGGL(k_diffcor<8>, dim3(grid), dim3(64), 0, s, a); break;
+    case 1: if (glibc) hipLaunchKernelGGL((k_diffcor<1, kFnGlibc>), dim3(grid), dim3(64), 0, s, a);
+            else hipLaunchKernelGGL((k_diffcor<1, kFnCr>), dim3(grid), dim3(64), 0, s, a); break;
+    case 2: if (glibc) hipLaunchKernelGGL((k_diffcor<2, kFnGlibc>), dim3(grid), dim3(64), 0, s, a);
+            else hipLaunchKernelGGL((k_diffcor<2, kFnCr>), dim3(grid), dim3(64), 0, s, a); break;
+    case 4: if (glibc) hipLaunchKernelGGL((k_diffcor<4, kFnGlibc>), dim3(grid), dim3(64), 0, s, a);
+            else hipLaunchKernelGGL((k_diffcor<4, kFnCr>), dim3(grid), dim3(64), 0, s, a); break;
+    case 8: if (glibc) hipLaunchKernelGGL((k_diffcor<8, kFnGlibc>), dim3(grid), dim3(64), 0, s, a);
+            else hipLaunchKernelGGL((k_diffcor<8, kFnCr>), dim3(grid), dim3(64), 0, s, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

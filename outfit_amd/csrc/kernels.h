@@ -183,6 +183,7 @@ struct DiffCorArgs {
   LsqResultRec* out;               // [n_traj]
   ObsFitRec* obs_fit;              // nullable [n_obs]
   unsigned long long* queue;       // work-queue head (zeroed before every launch)
+  int math_mode;                   // kMathCr: correctly-rounded functions throughout | kMathGlibc: glibc's bits throughout
 };
 
 hipError_t launch_triplet_select(const TripletArgs& a, bool lds_heap, hipStream_t s);

@@ -231,3 +231,25 @@ def test_contender_refinement_equals_the_exhaustive_exact_evaluation(tmp_path, m
     # (every candidate stays a factor 4 inside the bound K3b's contender rule gives it: asserted above)
     for r in report:
         assert r["fragile"] < 0.01 * r["candidates"], r
+
+
+@pytest.mark.skipif(not host_is_glibc_x86_64(), reason="the platform libm is the reference here: needs glibc on x86-64 with FMA")
+def test_corrector_equals_the_platform_libm_oracle():
+    """Row n1 in the glibc-faithful mode (round 3): IOD -> differential correction on the device against the oracle with
+    the PLATFORM libm (no restated function, no correctly-rounded scope: the reference's arithmetic on this host) —
+    every LSQ record and every per-observation fit row the same bytes, heliocentric and topocentric, 3 000 objects each.
+    (The correctly-rounded corrector of rounds 1-2 matches that oracle on 80 % of the records only: the normal equations
+    amplify the last place of sin / cos / atan2.)"""
+    ed = synth.make_ephemeris()
+    ephem = outfit_amd.Ephemeris.from_dict(ed)
+    params = synth.bench_params(outfit_amd.IODParams())
+    cfg = outfit_amd.DifferentialCorrectionConfig()
+    for kw in ({}, {"topocentric": True}):
+        ds = synth.make_dataset(3000, seed=20263400, ephem=ed, **kw)
+        batch = outfit_amd.ObsBatch.from_dict(ds)
+        got, got_obs = outfit_amd.fit_lsq_records(batch, ephem, params, cfg, None, n_devices=1, math_mode=outfit_amd.MATH_GLIBC)
+        with O.math_flags(libm=1, glibc=0):
+            rc, ref, ref_obs = O.fit_lsq(params.as_c(), cfg.as_c(), batch.as_c(), ephem.as_c(), None, n_threads=8)
+        assert rc == 0 and (ref["status"] == 0).sum() > 800
+        assert got.tobytes() == ref.tobytes(), int(sum(got[i].tobytes() != ref[i].tobytes() for i in range(len(ref))))
+        assert got_obs.tobytes() == ref_obs.tobytes()

@@ -2,10 +2,13 @@
 CPU oracle (oracle/diffcor.c) — needs an MI355X. SURVEY §8f row n1: FitLSQ::fit_lsq
 (differential_orbit_correction/obs_dataset_api.rs:57-130).
 
-The bar is BIT-EXACT records and per-observation fit data: every elementary function of the corrector is evaluated
-correctly rounded on both sides (device/crmath.hpp, oracle/crmath.c) and the linear algebra follows nalgebra's
-operation order. (Before that, the normal equations — condition numbers up to 7e12 — amplified the last-place
-differences between glibc and ROCm sin/cos/atan2 to 1e-8 sigma and flipped an iteration count on 2 objects in 10^4.)
+The bar is BIT-EXACT records and per-observation fit data in both math modes (every test runs once per mode): the
+corrector evaluates every elementary function either correctly rounded on both sides (device/crmath.hpp,
+oracle/crmath.c) or with glibc 2.35's bits on both sides (device/glibcmath*.hpp, oracle/glibcmath*.c — the default mode
+since round 3, in which the oracle equals its own platform-libm run, tests/test_gpu_glibc_mode.py), and the linear algebra
+follows nalgebra's operation order. (Before that, the normal equations — condition numbers up to 7e12 — amplified the
+last-place differences between glibc and ROCm sin/cos/atan2 to 1e-8 sigma and flipped an iteration count on 2 objects in
+10^4.)
 """
 import numpy as np
 import pytest
@@ -14,7 +17,7 @@ import oracle_lib as O
 import outfit_amd
 from outfit_amd import _abi, synth
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("device_math_mode")]
 
 INT_FIELDS = ("status", "dc_error", "conv_error", "total_newton_iterations", "num_measurements",
               "n_rejected", "outer_passes")
@@ -45,8 +48,8 @@ def oracle_lsq(params, cfg, batch, ephem, initial):
 
 
 def compare_lsq(got, got_obs, ref, ref_obs, batch, ignore=()):
-    """Bit-exact: the corrector evaluates every elementary function correctly rounded on both sides and follows the
-    same operation order, so records and per-observation fit data must be the same BYTES (`ignore`: trajectories
+    """Bit-exact: the corrector evaluates every elementary function with the same bits on both sides (correctly rounded, or
+    glibc's, by math mode) and follows the same operation order, so records and per-observation fit data must be the same BYTES (`ignore`: trajectories
     left out, e.g. degenerate arcs whose records hold NaN payloads)."""
     assert got.shape == ref.shape and got_obs.shape == ref_obs.shape
     keep = np.ones(len(ref), dtype=bool)
