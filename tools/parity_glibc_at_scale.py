@@ -1,7 +1,8 @@
 """GPU box: the device in OUTFIT_MATH_GLIBC mode against the oracle in platform-libm mode (= the reference's
 arithmetic on this host's glibc) on a LARGE batch — statistics for DESIGN.md §4.0. Also the default mode against the
 same, and the glibc mode against the oracle's restated mode (must be bit-identical).
-usage: parity_glibc_at_scale.py [n_objects] [seed] [bench|topo]  -> gpurun_out/parity_glibc_<mode>_<n>.json"""
+usage: parity_glibc_at_scale.py [n_objects] [seed] [bench|topo|noise]  -> gpurun_out/parity_glibc_<mode>_<n>.json
+(noise: IODParams::default() — 10 triplets x 21 realisations, host-drawn normals, SURVEY 8(d)'s second point)"""
 import ctypes as C
 import json
 import os
@@ -23,7 +24,10 @@ threads = len(os.sched_getaffinity(0))
 ed = synth.make_ephemeris()
 ds = synth.make_dataset(n, seed=seed, ephem=ed, topocentric=(mode == "topo"))
 batch, ephem = outfit_amd.ObsBatch.from_dict(ds), outfit_amd.Ephemeris.from_dict(ed)
-params = synth.bench_params(outfit_amd.IODParams())
+params = outfit_amd.IODParams() if mode == "noise" else synth.bench_params(outfit_amd.IODParams())
+per_traj = params.max_triplets * params.n_noise_realizations * 6
+if mode == "noise":
+    batch.noise_z = np.random.default_rng(seed).standard_normal(n * per_traj)
 L = O.lib()
 
 
@@ -35,7 +39,10 @@ def oracle(libm, glibc):
     try:
         for i in range(0, n, 10000):
             j = min(n, i + 10000)
-            rc, ref[i:j] = O.fit_full_iod(params.as_c(), batch.slice(i, j).as_c(), ephem.as_c(), n_threads=threads, hoist=1)
+            sub = batch.slice(i, j)
+            if mode == "noise":
+                sub.noise_z = batch.noise_z[i * per_traj: j * per_traj]
+            rc, ref[i:j] = O.fit_full_iod(params.as_c(), sub.as_c(), ephem.as_c(), n_threads=threads, hoist=1)
             assert rc == 0
             print(f"oracle(libm={libm}, glibc={glibc}) {j}/{n} ({time.perf_counter() - t:.0f} s)", flush=True)
     finally:
