@@ -11,6 +11,7 @@
 // (aberration.rs:139-145).
 #pragma once
 #include "kepler.hpp"
+#include "screen_math.hpp"
 
 namespace outfit {
 
@@ -53,25 +54,69 @@ struct Elements {
   double e[6];
 };
 
+// ---- sin and cos for the residual loop of K2c -------------------------------------------------------------
+// The platform sincos costs ~100 VALU instructions per call here, ~40 of them v_mov: its polynomial constants are
+// 64-bit literals, which this ISA can only feed to a VALU instruction from a register, and the compiler
+// materialises them in VGPRs inside the loop. Constants that arrive as KERNEL ARGUMENTS sit in SGPRs and are read
+// as operands directly (one scalar operand per instruction is all a Horner step needs): same ~1 ulp accuracy in ~40
+// instructions. Cody-Waite by pi/2 in three parts (k * P1 and k * P2 exact for |k| < 2^20), fdlibm's minimax
+// polynomials (k_sin.c / k_cos.c, degree 13 / 14 on [-pi/4, pi/4]). Only where a last place does not reach the
+// returned elements: the RMS of a candidate (it moves by <= 1e-9 relative against the platform functions).
+struct SinCosConsts {
+  double two_over_pi, p1, p2, p3;
+  double s1, s2, s3, s4, s5, s6;
+  double c1, c2, c3, c4, c5, c6;
+};
+__host__ __device__ inline SinCosConsts sincos_consts() {
+  return {0.6366197723675814, 1.5707963267341256, 6.077100506303966e-11, 2.0222662487959506e-21,
+          -1.66666666666666324348e-01, 8.33333333332248946124e-03, -1.98412698298579493134e-04,
+          2.75573137070700676789e-06, -2.50507602534068634195e-08, 1.58969099521155010221e-10,
+          4.16666666666666019037e-02, -1.38888888888741095749e-03, 2.48015872894767294178e-05,
+          -2.75573143513906633035e-07, 2.08757232129817482790e-09, -1.13596475577881948265e-11};
+}
+__device__ __forceinline__ void sincos_k(double x, const SinCosConsts& K, double& s, double& c) {
+  if (!(fabs(x) < 1048576.0)) { ::sincos(x, &s, &c); return; }
+  const double k = rint(x * K.two_over_pi);
+  double r = fma(-k, K.p1, x);
+  r = fma(-k, K.p2, r);
+  r = fma(-k, K.p3, r);
+  const int q = (int)k;
+  const double z = r * r;
+  const double ps = K.s2 + z * (K.s3 + z * (K.s4 + z * (K.s5 + z * K.s6)));
+  const double sr = r + (z * r) * (K.s1 + z * ps);
+  const double pc = z * (K.c1 + z * (K.c2 + z * (K.c3 + z * (K.c4 + z * (K.c5 + z * K.c6)))));
+  const double hz = 0.5 * z, w = 1.0 - hz;
+  const double cr = w + (((1.0 - w) - hz) + z * pc);
+  const double a = (q & 1) ? cr : sr, b = (q & 1) ? sr : cr;
+  s = (q & 2) ? -a : a;
+  c = ((q + 1) & 2) ? -b : b;
+}
+
+
 // Which elementary functions a caller of the conversions below gets (template argument kFn):
 //   kFnPlatform  ROCm's — the candidate RMS in the correctly-rounded math mode (K2c, 2x10^8 observation evaluations
 //                per step): they move the RMS by <= 1e-6 relative, never the returned elements;
 //   kFnCr        correctly rounded (sin/cos by `math_mode`) — the returned elements (K3) in that mode, and the
 //                differential corrector in both modes (ill-conditioned normal equations amplify a last place up to
 //                1e13 times; bit-identical to the oracle);
+//   kFnScreen    the screening arithmetic (screen_math.hpp: own atan2, sincos_k with literal constants; tan and hypot the
+//                platform's) — the candidate -> equinoctial conversion in front of K2c's screening loop: ~1e-16 from the
+//                platform functions, no decision of the conversion depends on the angles it changes;
 //   kFnGlibc     glibc 2.35's bits (glibcmath.hpp, glibcmath2.hpp) — the whole candidate -> RMS chain and the returned
 //                elements in OUTFIT_MATH_GLIBC: `rms`, the selection and the elements then follow a glibc run of the
 //                reference bit for bit. Every sin/cos pair here shares its operand, i.e. is ONE sincos call in the
 //                reference (glm::sincos); the one isolated cosine, cos(dec_obs), is K1's (glm::cos1).
-constexpr int kFnPlatform = 0, kFnCr = 1, kFnGlibc = 2;
+constexpr int kFnPlatform = 0, kFnCr = 1, kFnGlibc = 2, kFnScreen = 3;
 template <int kFn> __device__ __forceinline__ void sincos_sel(double x, double& s, double& c, int math_mode = kMathCr) {
   if constexpr (kFn == kFnCr) sincos_mode(math_mode, x, s, c);
   else if constexpr (kFn == kFnGlibc) glm::sincos(x, s, c);
+  else if constexpr (kFn == kFnScreen) sincos_k(x, sincos_consts(), s, c);
   else ::sincos(x, &s, &c);
 }
 template <int kFn> __device__ __forceinline__ double atan2_sel(double y, double x) {
   if constexpr (kFn == kFnCr) return crm::atan2(y, x);
   else if constexpr (kFn == kFnGlibc) return glm::atan2(y, x);
+  else if constexpr (kFn == kFnScreen) return atan2_screen(y, x, screen_consts());
   else return ::atan2(y, x);
 }
 template <int kFn> __device__ __forceinline__ double tan_sel(double x) {
@@ -177,44 +222,6 @@ __device__ __forceinline__ Elements ccek1(const Vec3& pos, const Vec3& vel, doub
 struct Equinoctial {
   double epoch, a, h, k, p, q, lambda;
 };
-
-// ---- sin and cos for the residual loop of K2c -------------------------------------------------------------
-// The platform sincos costs ~100 VALU instructions per call here, ~40 of them v_mov: its polynomial constants are
-// 64-bit literals, which this ISA can only feed to a VALU instruction from a register, and the compiler
-// materialises them in VGPRs inside the loop. Constants that arrive as KERNEL ARGUMENTS sit in SGPRs and are read
-// as operands directly (one scalar operand per instruction is all a Horner step needs): same ~1 ulp accuracy in ~40
-// instructions. Cody-Waite by pi/2 in three parts (k * P1 and k * P2 exact for |k| < 2^20), fdlibm's minimax
-// polynomials (k_sin.c / k_cos.c, degree 13 / 14 on [-pi/4, pi/4]). Only where a last place does not reach the
-// returned elements: the RMS of a candidate (it moves by <= 1e-9 relative against the platform functions).
-struct SinCosConsts {
-  double two_over_pi, p1, p2, p3;
-  double s1, s2, s3, s4, s5, s6;
-  double c1, c2, c3, c4, c5, c6;
-};
-__host__ __device__ inline SinCosConsts sincos_consts() {
-  return {0.6366197723675814, 1.5707963267341256, 6.077100506303966e-11, 2.0222662487959506e-21,
-          -1.66666666666666324348e-01, 8.33333333332248946124e-03, -1.98412698298579493134e-04,
-          2.75573137070700676789e-06, -2.50507602534068634195e-08, 1.58969099521155010221e-10,
-          4.16666666666666019037e-02, -1.38888888888741095749e-03, 2.48015872894767294178e-05,
-          -2.75573143513906633035e-07, 2.08757232129817482790e-09, -1.13596475577881948265e-11};
-}
-__device__ __forceinline__ void sincos_k(double x, const SinCosConsts& K, double& s, double& c) {
-  if (!(fabs(x) < 1048576.0)) { ::sincos(x, &s, &c); return; }
-  const double k = rint(x * K.two_over_pi);
-  double r = fma(-k, K.p1, x);
-  r = fma(-k, K.p2, r);
-  r = fma(-k, K.p3, r);
-  const int q = (int)k;
-  const double z = r * r;
-  const double ps = K.s2 + z * (K.s3 + z * (K.s4 + z * (K.s5 + z * K.s6)));
-  const double sr = r + (z * r) * (K.s1 + z * ps);
-  const double pc = z * (K.c1 + z * (K.c2 + z * (K.c3 + z * (K.c4 + z * (K.c5 + z * K.c6)))));
-  const double hz = 0.5 * z, w = 1.0 - hz;
-  const double cr = w + (((1.0 - w) - hz) + z * pc);
-  const double a = (q & 1) ? cr : sr, b = (q & 1) ? sr : cr;
-  s = (q & 2) ? -a : a;
-  c = ((q + 1) & 2) ? -b : b;
-}
 
 // equinoctial_element.rs:285-313
 template <int kCr = kFnPlatform>

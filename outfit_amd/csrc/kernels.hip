@@ -642,11 +642,13 @@ __device__ __forceinline__ void rms_candidate(const RmsArgs& a, unsigned long lo
   // build_result -> compute_orbit_from_state -> ccek1 (gauss.rs:906-923,1063-1076)
   // kFn = kFnPlatform (correctly-rounded mode): these elements only feed the candidate's RMS, the selected candidate's
   // are recomputed correctly rounded in K3 from the same state; kFn = kFnGlibc: glibc's bits all the way (orbit.hpp)
-  const Elements el = ccek1<kFn>(equ_to_ecl(r2), equ_to_ecl(v2), epoch);
+  // (the conversion in front of a screening loop takes the screen's own atan2 / sincos: orbit.hpp kFnScreen)
+  constexpr int kConv = kScreen ? kFnScreen : kFn;
+  const Elements el = ccek1<kConv>(equ_to_ecl(r2), equ_to_ecl(v2), epoch);
   unsigned flags = (f0 & (kFlagOk | kFlagCorrected | kFlagSlow)) | (el.kind ? kFlagCometary : 0u);
 
   Equinoctial eq;
-  const int conv = to_equinoctial<kFn>(el, eq);
+  const int conv = to_equinoctial<kConv>(el, eq);
   if (conv != 0) {  // `?` at trajectory.rs:493 aborts the trajectory: K3 replays that
     a.W.flags[cid] = flags | ((unsigned)conv << kFlagConvShift);
     return;
@@ -660,7 +662,7 @@ __device__ __forceinline__ void rms_candidate(const RmsArgs& a, unsigned long lo
   if (sqrt(eq.h * eq.h + eq.k * eq.k) >= 1.0) {
     err = true;  // check_elliptical_orbit (observation_ephemeris.rs:288-296)
   } else {
-    const TwoBodyFrame F = twobody_frame<kFn>(eq);
+    const TwoBodyFrame F = twobody_frame<kConv>(eq);
     bool exact = !kScreen;
     if (kScreen) {
       const ScreenFrame G = screen_frame(eq, F);
