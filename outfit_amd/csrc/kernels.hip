@@ -244,7 +244,13 @@ __device__ __forceinline__ CandidateGeometry load_geometry(const CandidateIndex&
 // ------------------------------------------------------------------------------
 // K2a: direction matrix, 8th-degree polynomial, Aberth roots, root filter
 // ------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 4)
+#ifndef OUTFIT_ROOTS_WAVES
+#define OUTFIT_ROOTS_WAVES 4
+#endif
+#ifndef OUTFIT_ROOTS_BLOCK
+#define OUTFIT_ROOTS_BLOCK 256
+#endif
+__global__ void __launch_bounds__(OUTFIT_ROOTS_BLOCK, OUTFIT_ROOTS_WAVES)
 k_gauss_roots(RootsArgs a) {
   const unsigned long long lid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (lid >= a.cand_count) return;
@@ -1469,8 +1475,8 @@ hipError_t launch_observer_prepass(const PrepassArgs& a, hipStream_t s) {
 }
 hipError_t launch_gauss_roots(const RootsArgs& a, hipStream_t s) {
   if (a.cand_count == 0) return hipSuccess;
-  const unsigned grid = (unsigned)((a.cand_count + 255) / 256);
-  hipLaunchKernelGGL(k_gauss_roots, dim3(grid), dim3(256), 0, s, a);
+  const unsigned grid = (unsigned)((a.cand_count + OUTFIT_ROOTS_BLOCK - 1) / OUTFIT_ROOTS_BLOCK);
+  hipLaunchKernelGGL(k_gauss_roots, dim3(grid), dim3(OUTFIT_ROOTS_BLOCK), 0, s, a);
   return hipGetLastError();
 }
 // the slow list is filled by K2a (fused cold start): reset it before the first K2a slice of a chunk
