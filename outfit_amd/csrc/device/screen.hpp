@@ -44,26 +44,29 @@ struct ScreenKepler {
   double lam;        // the right-hand side it solved
   double off;        // lam - (lambda + n dt): the multiple of 2 pi the reference's principal_angle removed
   double dmin;       // smallest dlam/dF = 1 - k cos F - h sin F met so far (-> screen_level)
+  double inv_rho_max;  // largest 1 / topocentric distance met so far (-> screen_level)
 };
 // The reference's Newton iteration stops as soon as |f| < 100 eps = 2.2e-14 (equinoctial_element.rs:339), i.e. with an
 // error of up to 2.2e-14 / (dlam/dF) in F — part of its result, reproduced by the exact evaluation only because that
-// follows the same iterates. Any other solver, however accurate, differs from it by that much, and dlam/dF =
-// 1 - e cos E gets arbitrarily small for a near-parabolic candidate at perihelion (measured: the RMS of 3 in 10^7
-// candidates off by 0.1 - 1.4 %, of 3 in 10^4 by more than 1e-8). The screen therefore reports, with its sum, how
-// small dlam/dF got: `level` = -exponent(dmin) clamped to 0..31, i.e. dmin >= 2^-(level+1), in five bits of the
-// candidate's flag word, and k_refine_best widens that candidate's window by the matching bound (screen_slack_rad).
+// follows the same iterates. Any other solver, however accurate, differs from it by that much; dlam/dF = 1 - e cos E
+// gets arbitrarily small for a near-parabolic candidate at perihelion, and on the sky the error is multiplied by
+// |dr/dF| / rho <= a / rho, large for a close approach (measured against the exact evaluation: 3 candidates in 10^7 off
+// by 0.1 - 1.4 % of their RMS, 3 in 10^4 by more than 1e-8). The screen therefore reports its own bound with every sum:
+//   bound_rad = 8 x 2.2e-14 x a x max_i(1 / rho_i) / min_i(dlam/dF)_i        (8 = safety; |dr/dF| <= a)
+// rounded up to 1e-13 x 2^E rad, E in five bits of the candidate's flag word (E = 31: unbounded), and k_refine_best
+// widens that candidate's window by it (screen_slack_rad). Typical main-belt candidate: E = 2 - 3, i.e. 4 - 8e-13 rad
+// = 3 - 6e-7 of an RMS normalised by 0.3"; the screen's own roundings (Newton to 1e-16, ~1e-15 rad of drift in the
+// carried sine / cosine, 2e-16 in atan2) are < 1 % of that.
 constexpr unsigned kFlagLevelShift = 23, kFlagLevelMask = 0x1Fu << kFlagLevelShift;
-__device__ __forceinline__ unsigned screen_level(double dmin) {
-  if (!(dmin > 0.0)) return 31u;
-  const int e = __builtin_amdgcn_frexp_exp(dmin);  // dmin = m 2^e, 0.5 <= m < 1
-  return (unsigned)(e >= 0 ? 0 : (e <= -31 ? 31 : -e));
+__device__ __forceinline__ unsigned screen_level(double a, double inv_rho_max, double dmin) {
+  const double x = 1.76 * a * inv_rho_max / dmin;   // bound_rad / 1e-13
+  if (!(x < 1.0e9) || !(dmin > 0.0)) return 31u;
+  if (x <= 1.0) return 0u;
+  return (unsigned)__builtin_amdgcn_frexp_exp(x);   // x = m 2^e, 0.5 <= m < 1: x < 2^e, e <= 30
 }
-// Bound, in radians on the sky, of what the stopping rule can move a candidate of that level: 2.2e-14 * 2^(level+1) in F,
-// times 227 for semi-major axis over topocentric distance and the observations adding up (= 1.6e-10 rad at level <= 4,
-// where the measured maximum is 5.5e-11); level 31 = unbounded.
 __device__ __forceinline__ double screen_slack_rad(unsigned level) {
   if (level >= 31u) return INFINITY;
-  return ldexp(5.0e-12, (int)(level < 4u ? 4u : level) + 1);
+  return ldexp(1.0e-13, (int)level);
 }
 
 // false = Err(RootFindingError), decided by the reference's own iteration
@@ -125,7 +128,8 @@ __device__ __forceinline__ ScreenFrame screen_frame(const Equinoctial& q, const 
 // observation_ephemeris.rs:222-275,388-416 (incl. the sign-keeping `%` of quirk Q6), in the screen's arithmetic.
 __device__ __forceinline__ double screen_term(const Equinoctial& q, const TwoBodyFrame& F, const ScreenFrame& G,
                                               double sx, double cx, double ra, double dec, double cos_dec, double sra,
-                                              double sdec, const Vec3& obs_pos_equ, const ScreenConsts& C) {
+                                              double sdec, const Vec3& obs_pos_equ, const ScreenConsts& C,
+                                              double& inv_rho_max) {
   const double xe = q.a * fma(F.one_bh2, cx, fma(F.bet, sx, -q.k));
   const double ye = q.a * fma(F.one_bk2, sx, fma(F.bet, cx, -q.h));
   double r, inv_r;
@@ -138,6 +142,7 @@ __device__ __forceinline__ double screen_term(const Equinoctial& q, const TwoBod
   const Vec3 vq = {fma(vxe, G.f.x, vye * G.g.x), fma(vxe, G.f.y, vye * G.g.y), fma(vxe, G.f.z, vye * G.g.z)};
   double dist, inv_dist;
   sqrt_rsqrt(fma(rel.x, rel.x, fma(rel.y, rel.y, rel.z * rel.z)), dist, inv_dist);
+  inv_rho_max = fmax(inv_rho_max, inv_dist);
   const double lt = dist * C.inv_vlight;
   const Vec3 cor = {fma(-lt, vq.x, rel.x), fma(-lt, vq.y, rel.y), fma(-lt, vq.z, rel.z)};
   double rho, inv_rho;

@@ -676,6 +676,7 @@ __device__ __forceinline__ void rms_candidate(const RmsArgs& a, unsigned long lo
       ScreenKepler S;
       S.warm = false;
       S.dmin = 1.0;
+      S.inv_rho_max = 0.0;
       for (unsigned long long i = i_start; i <= i_end; ++i) {
         const unsigned long long o = c.base + i;
         if (!screen_kepler(eq, F, a.I.mjd[o] - eq.epoch, S, a.sc, SCR)) {
@@ -683,13 +684,13 @@ __device__ __forceinline__ void rms_candidate(const RmsArgs& a, unsigned long lo
           break;
         }
         const Vec3 op = {a.obs_pos[3 * o], a.obs_pos[3 * o + 1], a.obs_pos[3 * o + 2]};
-        acc += screen_term(eq, F, G, S.sx, S.cx, a.I.ra[o], a.I.dec[o], a.cos_dec[o], a.I.sra[o], a.I.sdec[o], op, SCR);
+        acc += screen_term(eq, F, G, S.sx, S.cx, a.I.ra[o], a.I.dec[o], a.cos_dec[o], a.I.sra[o], a.I.sdec[o], op, SCR, S.inv_rho_max);
       }
       // anything the screen's shortcuts were not made for (non-finite or absurd inputs: overflow, 0 / 0, a zero
       // uncertainty) shows up as a non-finite sum: such a candidate takes the reference's expressions instead — here
       // in the slow-list pass; the main pass hands it to that pass through the redo list (the tail of slow_list: a
       // candidate is on one list at most), which keeps the second loop out of the main pass's register budget
-      flags |= screen_level(S.dmin) << kFlagLevelShift;
+      flags |= screen_level(eq.a, S.inv_rho_max, S.dmin) << kFlagLevelShift;
       if (!err && !(fabs(acc) < 1e300)) {
         if (!kSlowList) {
           const unsigned long long at = atomicAdd(a.W.slow_count + 1, 1ull);
@@ -1010,9 +1011,9 @@ k_refine_best(RmsArgs r, GaussResultRec* out_all, const double* bound, unsigned 
   const bool ok = live && out_all[r.I.traj0 + lt].status == 0;
   if (sub == 0) s_nc[g] = ok ? r.I.n_triplets[lt] * r.I.n_real : 0u;
   __syncthreads();
-  // The contender rule. The screen's error is an error in the computed ANGLES (screen_slack_rad of the candidate's
-  // level), so in the normalised RMS it has an absolute part — that angle over the smallest uncertainty of the
-  // trajectory — beside the relative one (roundings: kContenderWindow). With slack_c = screen_slack_rad(level_c) /
+  // The contender rule. The screen's error is an error in the computed ANGLES (its own bound per candidate, device/screen.hpp:
+  // screen_slack_rad of the level it stored), so in the normalised RMS it has an absolute part — that angle over the smallest
+  // uncertainty of the trajectory — beside the relative one (roundings: kContenderWindow). With slack_c = screen_slack_rad(level_c) /
   // sigma_min the exact RMS of candidate c lies in screened_c (1 -+ w) -+ slack_c, so the exact minimum is at most
   //   m = min_c (screened_c + slack_c)                          (folded by K3: bound[])
   // and c can be that minimum only if   screened_c <= m (1 + kContenderWindow) + slack_c:   the contenders.

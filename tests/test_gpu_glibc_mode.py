@@ -202,8 +202,8 @@ def test_contender_refinement_equals_the_exhaustive_exact_evaluation(tmp_path, m
     report = []
     for i in range(3):
         a, b = np.load(tmp_path / ("screen%d.npz" % i)), np.load(tmp_path / ("exact%d.npz" % i))
-        level = (a["flags"] & LEVEL_MASK) >> LEVEL_SHIFT   # set by the screen only: dlam/dF got as small as 2^-(level+1)
-        fragile = level > 4
+        level = (a["flags"] & LEVEL_MASK) >> LEVEL_SHIFT   # set by the screen only: its error bound is 1e-13 * 2^level rad
+        fragile = level > 7
         assert np.array_equal(a["flags"] & ~np.uint32(LEVEL_MASK), b["flags"])
         fl = a["flags"]  # kernels.h: 0x10 a preliminary orbit exists, 0x80 an ephemeris_error failed, bits 8-10 conversion error
         scored = ((fl & 0x10) != 0) & ((fl >> 8 & 0x7) == 0) & ((fl & 0x80) == 0) & ((fl & 0x80000000) == 0)
@@ -216,11 +216,17 @@ def test_contender_refinement_equals_the_exhaustive_exact_evaluation(tmp_path, m
         frag = fragile[idx]
         dev = np.abs(ra - rb)
         # K3b's bound for a candidate of that level (screen_slack_rad / sigma_min, sigma >= 0.3" = 1.45e-6 rad here)
-        bound = 5.0e-12 * 2.0 ** (np.maximum(level[idx], 4) + 1.0) / 1.45e-6 + 1e-4 * rb
+        bound = np.where(level[idx] >= 31, np.inf, 1.0e-13 * 2.0 ** level[idx].astype(float) / 1.45e-6) + 1e-4 * rb
         assert (dev < 0.25 * bound).all(), (i, float((dev / bound).max()))
+        ratio = float((dev / bound).max())
+        # the angle bound alone (no relative part), where the RMS is moderate: how much of it the error ever uses
+        angle = np.where(level[idx] >= 31, np.inf, 1.0e-13 * 2.0 ** level[idx].astype(float) / 1.45e-6)
+        moderate = rb < 100.0
+        ratio_angle = float((dev[moderate] / angle[moderate]).max())
         rel = dev / rb
         worst = np.argsort(np.where(frag, 0.0, dev))[-5:][::-1]
-        report.append({"workload": i, "candidates": int(scored.sum()), "fragile": int(frag.sum()),
+        report.append({"workload": i, "candidates": int(scored.sum()), "fragile": int(frag.sum()), "largest_error_over_bound": ratio, "largest_error_over_angle_bound_rms_below_100": ratio_angle,
+                       "level_histogram": np.bincount(level[idx], minlength=32).tolist(),
                        "robust_max_abs": float(dev[~frag].max()), "robust_max_rel": float(rel[~frag].max()),
                        "robust_p999_abs": float(np.quantile(dev[~frag], 0.999)), "robust_median_abs": float(np.median(dev[~frag])),
                        "fragile_max_rel": float(rel[frag].max()) if frag.any() else 0.0,
