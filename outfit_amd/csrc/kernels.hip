@@ -931,7 +931,7 @@ k_select_best(SelectArgs a) {
 // Two stages instead: K2c screens every candidate (device/screen.hpp: its own cheap arithmetic, with a per-candidate error
 // level), K3 folds those values and the bound m = min_c (screened_c + slack_c), and this kernel re-evaluates EXACTLY — with
 // the glibc-faithful functions — every candidate that can still be the exact minimum (screened_c <= m (1 + 1e-4) +
-// slack_c: 1.014 candidates per trajectory on the bench workload) and keeps the smallest (rms, index), i.e. the first
+// slack_c: 1.005 candidates per trajectory on the bench workload) and keeps the smallest (rms, index), i.e. the first
 // minimum of the reference's strict-`<` fold. The winner, its `rms` and its elements are then those of the exhaustive
 // exact evaluation as long as every candidate's screening error stays inside its bound (tests/test_gpu_glibc_mode.py:
 // all of 1.5 x 10^7 candidates within a quarter of it); OUTFIT_RMS_EXACT_ALL=1 runs the exhaustive evaluation instead, and
