@@ -18,6 +18,12 @@ import os
 import sys
 import time
 
+T_PROCESS_START = time.perf_counter()
+# RCCL between processes needs dmabuf IPC on this pool's host driver (hipIpcGetMemHandle fails with "invalid argument"
+# in the legacy mode): must be in the environment BEFORE the first HIP call of the process. The driver's launcher and
+# the image export it already; set here so that `python -m torch.distributed.run ... bench.py` works from a bare shell.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
@@ -79,10 +85,10 @@ def cpu_baseline(batch, ephem, params, n_obj_max, budget_s=15.0, cores=None, hoi
 
 
 def host_libm():
-    """What the oracle's `orc_use_libm = 1` mode evaluates with on this host (the reference's arithmetic when glibc)."""
-    import platform
-    name, ver = platform.libc_ver()
-    return f"{name or 'unknown'} {ver} {platform.machine()}".strip()
+    """What the oracle's `orc_use_libm = 1` mode evaluates with on this host, and whether that is the ONE build the
+    glibc-faithful device mode restates (outfit_amd/libm_pin.py): only then is `parity_vs_libm` a parity statement."""
+    from outfit_amd import libm_pin
+    return libm_pin.describe()
 
 
 def parity_vs_libm(batch, ephem, params, records_by_mode, n_sample):
@@ -96,8 +102,15 @@ def parity_vs_libm(batch, ephem, params, records_by_mode, n_sample):
     with O.math_flags(libm=1):
         rc, ref = O.fit_full_iod(params.as_c(), sub.as_c(), ephem.as_c(), n_threads=host_cores(), hoist=1)
     assert rc == 0
+    from outfit_amd import libm_pin
+    pinned = libm_pin.host_has_pinned_libm()
     out = {"sample": f"first {n_sample} objects of the timed batch", "oracle": "CPU restatement, platform libm (orc_use_libm=1)",
-           "host_libm": host_libm(), "oracle_seconds": time.perf_counter() - t,
+           "host_libm": host_libm(), "host_libm_is_the_pinned_build": pinned,
+           "meaning": ("platform libm = the glibc build OUTFIT_MATH_GLIBC restates: byte identity is expected in the glibc mode"
+                       if pinned else
+                       "platform libm is ANOTHER build than the one OUTFIT_MATH_GLIBC restates: the figures below are "
+                       "distances to this host's libm, not a parity statement (" + str(libm_pin.host_libm_identity()["why_not"]) + ")"),
+           "oracle_seconds": time.perf_counter() - t,
            "tolerance": {"len_AU": 1e-10, "angle_rad": 1e-12}}
     ints = ("status", "cause", "stage", "kind", "attempts", "n_triplets", "best_triplet", "best_realization")
     ok = ref["status"] == 0
@@ -117,7 +130,7 @@ def parity_vs_libm(batch, ephem, params, records_by_mode, n_sample):
     return out
 
 
-def noise_point(label, ds, ephem, params, device, stream, steps, seed):
+def noise_point(label, ds, ephem, params, device, stream, steps, seed, workload):
     """SURVEY §8(d)'s second point: noisy realisations with HOST-drawn standard normals (gauss.rs:323-387,
     trajectory.rs:462-477), inputs and normals resident; one warm-up, `steps` timed steps, per-kernel HIP-event times."""
     import numpy as np
@@ -131,7 +144,8 @@ def noise_point(label, ds, ephem, params, device, stream, steps, seed):
     for a in range(0, n_z, step_n):      # in place, 512 MiB at a time
         rng.standard_normal(out=z[a:a + step_n])
     d = dict(ds)
-    d["noise_z"] = z
+    if n_z:
+        d["noise_z"] = z
     batch = outfit_amd.ObsBatch.from_dict(d)
     t = time.perf_counter()
     s = outfit_amd.IODSession(batch, ephem, params, device=device)
@@ -149,14 +163,43 @@ def noise_point(label, ds, ephem, params, device, stream, steps, seed):
     rec = s.results()
     s.close()
     cand = n_obj * params.max_triplets * (1 + params.n_noise_realizations)
-    return {"what": label, "objects": n_obj, "max_triplets": params.max_triplets,
+    n_obs = int(batch.traj_offset[-1])
+    # algorithmic bytes: the observation columns, the record, and the host-drawn normals (an input of this workload)
+    bytes_per_obj = (n_obs / n_obj) * (BYTES_PER_OBS_IN + BYTES_PER_OBS_GEO) + BYTES_PER_RESULT + 8.0 * n_z / n_obj
+    return {"what": label, "roofline": roofline_block(kt, n_obj, steps, dt, bytes_per_obj, workload), "objects": n_obj, "max_triplets": params.max_triplets,
             "n_noise_realizations": params.n_noise_realizations, "candidates_per_step": cand,
             "normals": f"{n_z} host-drawn standard normals ({n_z * 8 / 1e9:.2f} GB, numpy PCG64), resident in HBM",
+            "obs_per_object": n_obs / n_obj,
             "steps": steps, "ms_per_step": 1e3 * dt, "objects_per_s": n_obj / dt, "candidates_per_s": cand / dt,
             "kernel_avg_ms_per_step": {k: v[0] / steps for k, v in kt.items()},
             "orbits_found": int((rec["status"] == 0).sum()),
             "noisy_winners": int(((rec["status"] == 0) & (rec["best_realization"] > 0)).sum()),
             "session_build_and_first_run_s": setup}
+
+
+def long_arc_points(outfit_amd, synth, device, stream, steps, which=(100, 300), n_obj=10000):
+    """Long trajectories under the reference's own defaults (VERDICT r3 item 2): `IODParams::default()` caps the
+    triplet search at max_obs_for_triplets = 100 epochs, i.e. up to C(100,3) = 161 700 scored triplets per trajectory
+    (triplet_generation/mod.rs:365-408, index_generator.rs:133-271), and the RMS window covers the whole arc
+    (extf = -1). n_obs = 100: the cap is not hit; n_obs = 300: down-sampling + quirk Q1. Two parameter sets each:
+    IODParams::default() (10 triplets x 21 realisations, host-drawn normals) and 100 triplets without noise."""
+    out = {}
+    for n_obs in which:
+        ds = synth.make_long_arc_dataset(n_obj, n_obs)
+        ephem = outfit_amd.Ephemeris.from_dict(ds["ephem"])
+        p_def = outfit_amd.IODParams()
+        p_100 = outfit_amd.IODParams()
+        p_100.max_triplets = 100
+        p_100.n_noise_realizations = 0
+        for tag, what, prm in (("iod_params_default", "IODParams::default()", p_def),
+                               ("100_triplets_no_noise", "IODParams::default() except max_triplets = 100, "
+                                                         "n_noise_realizations = 0", p_100)):
+            r = noise_point(f"{n_obj} objects x {n_obs} observations, {what}", ds, ephem, prm, device, stream, steps,
+                            20261100 + n_obs, f"long_arcs_{n_obs}_{tag}")
+            k0 = r["kernel_avg_ms_per_step"].get("k_triplet_select", 0.0)
+            r["k_triplet_select_share_of_step"] = k0 / r["ms_per_step"] if r["ms_per_step"] > 0 else None
+            out[f"{n_obs}_obs_{tag}"] = r
+    return out
 
 
 def source_hash():
@@ -171,6 +214,176 @@ def source_hash():
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
+
+
+MAIN_STREAM_KERNELS = ("k_gauss_roots", "k_gauss_correct_fast", "k_orbit_rms", "k_orbit_rms_slow", "k_select_best",
+                       "k_refine_best", "k_diffcor")
+# live HIP-event timers (outfit_hip_session_kernel_times) -> which rocprofv3 kernel names (template instances) they cover
+PMC_MATCH = {
+    "k_triplet_select": lambda k: k.startswith("k_triplet_select"),
+    "k_observer_prepass": lambda k: k.startswith("k_observer_prepass"),
+    "k_gauss_roots": lambda k: k.startswith("k_gauss_roots"),
+    "k_gauss_correct_fast": lambda k: k.startswith("k_gauss_correct_fast"),
+    "k_gauss_correct": lambda k: k.startswith("k_gauss_correct<"),
+    "k_orbit_rms": lambda k: k.startswith("k_orbit_rms<false"),
+    "k_orbit_rms_slow": lambda k: k.startswith("k_orbit_rms<true"),
+    "k_select_best": lambda k: k.startswith("k_select_best"),
+    "k_refine_best": lambda k: k.startswith("k_refine_best"),
+    "k_diffcor": lambda k: k.startswith("k_diffcor"),
+}
+
+
+def _pmc_workload(workload):
+    """The committed PMC profile of `workload`, or None unless it was taken from THIS build (source hash)."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
+    except (OSError, ValueError):
+        return None
+    if pmc.get("source_hash") != source_hash():
+        return None
+    w = pmc.get("workloads", {}).get(workload)
+    if w is None and workload == "headline" and "kernels" in pmc:      # layout of rounds 2-3
+        w = {"kernels": pmc["kernels"], "objects_per_step": pmc["objects_per_step"]}
+    if w is None:
+        return None
+    w = dict(w)
+    w["source"], w["source_hash"] = pmc.get("source"), pmc.get("source_hash")
+    return w
+
+
+def _pmc_rows(w, timer):
+    """Profile rows of the kernel(s) behind one live timer (template instances are summed)."""
+    match = PMC_MATCH.get(timer, lambda k: k == timer)
+    return [v for k, v in w["kernels"].items() if match(k)]
+
+
+def roofline_block(ktimes, n_obj, steps, step_s, bytes_per_obj, workload, objects_per_s_per_gpu=None,
+                   exclude=("k_diffcor",), only=None):
+    """The `roofline` object of one timed region: the contract figure (algorithmic bytes of the dominant
+    kernel against the HBM peak) and, from the hash-matched PMC profile of the same workload, what actually limits the
+    path: VALU issue, executed fp64, lanes per instruction and counter bytes against algorithmic bytes — per kernel
+    and for the step. Counter-derived fields are null when no profile of THIS build exists (a stale one says nothing)."""
+    pick = [k for k in ktimes if (only is None or k in only) and k not in exclude]
+    main = [k for k in pick if k in MAIN_STREAM_KERNELS]
+    if not main:
+        return None
+    dom = max(main, key=lambda k: ktimes[k][0])
+    total_ms, launches = ktimes[dom]
+    avg_ms = total_ms / launches
+    units = n_obj * steps / launches                 # objects one launch processes (this rank's shard)
+    achieved = units * bytes_per_obj / (avg_ms * 1e-3) / 1e9
+    w = _pmc_workload(workload)
+    per_kernel, traffic, issue, executed, step_traffic = [], None, None, None, None
+    alg_step = n_obj * bytes_per_obj
+    if w is not None:
+        sc = n_obj / w["objects_per_step"]
+        tot_instr = tot_f64i = tot_ops = tot_bytes = 0.0
+        for k in sorted(pick, key=lambda k: -ktimes[k][0]):
+            rows = _pmc_rows(w, k)
+            if not rows:
+                continue
+            instr = sum(r["valu_wave_instr"] for r in rows) * sc
+            f64i = sum(r.get("fp64_wave_instr", 0.0) for r in rows) * sc
+            ops = sum(r.get("fp64_lane_ops_upper", 0.0) for r in rows) * sc
+            byt = sum(r["hbm_bytes_per_step"] for r in rows) * sc
+            thr = sum(r.get("thread_cycles_valu", 0.0) for r in rows)
+            act = sum(r.get("active_inst_valu", 0.0) for r in rows)
+            ms = ktimes[k][0] / steps
+            tot_instr += instr; tot_f64i += f64i; tot_ops += ops; tot_bytes += byt
+            per_kernel.append({
+                "kernel": k, "stream": "main" if k in MAIN_STREAM_KERNELS else "side (overlapped; its time includes waiting for CUs)",
+                "ms_per_step": ms, "valu_wave_instr_per_step": instr,
+                "issue_frac": instr / VALU_ISSUE_PEAK / (ms * 1e-3) if ms > 0 else None,
+                "lanes_per_instruction": thr / act if act > 0 else None,
+                "non_fp64_share": 1.0 - f64i / instr if instr > 0 and f64i > 0 else None,
+                "counter_bytes_per_step": byt, "counter_over_algorithmic_bytes": byt / alg_step})
+            if k == dom:
+                traffic = byt * steps / launches
+        issue = {"step_wave_instr": tot_instr, "step_issue_frac": tot_instr / VALU_ISSUE_PEAK / step_s,
+                 "peak_wave_instr_per_s": VALU_ISSUE_PEAK,
+                 "peak_is": "1024 SIMDs x 2.4 GHz / 4 cycles per 64-lane fp64 instruction"}
+        if tot_ops > 0:
+            tf = tot_ops / step_s / 1e12
+            executed = {"fp64_lane_ops_per_object_upper": tot_ops / n_obj, "achieved_tflops": tf,
+                        "peak_tflops": FP64_PEAK_TFLOPS, "frac": tf / FP64_PEAK_TFLOPS,
+                        "non_fp64_share_of_valu": 1.0 - tot_f64i / tot_instr if tot_f64i > 0 else None,
+                        "what": "SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 lanes (FMA = 2; inactive lanes included)"}
+        step_traffic = {"counter_bytes": tot_bytes, "algorithmic_bytes": alg_step, "ratio": tot_bytes / alg_step,
+                        "GBps": tot_bytes / step_s / 1e9, "frac_of_hbm_peak": tot_bytes / step_s / 1e9 / HBM_PEAK_GBS}
+    ref_equiv = None
+    if workload == "headline" and objects_per_s_per_gpu:
+        try:   # counted on the CPU restatement (tools/count_flops.py): work RETIRED in the reference's terms, not a utilisation
+            fl = json.load(open(os.path.join(ROOT, "profiles", "flops_per_object.json")))
+            f_obj = fl["hoisted"]["total_fp64_ops_per_object"]
+            ref_equiv = {"reference_equivalent_tflops": objects_per_s_per_gpu * f_obj / 1e12,
+                         "algorithmic_fp64_ops_per_object": f_obj,
+                         "of_which_libm_nominal": fl["hoisted"]["libm_fp64_ops_per_object_nominal"],
+                         "reference_decomposition_ops_per_object": fl["reference"]["total_fp64_ops_per_object"],
+                         "note": "what the reference's arithmetic would execute for these objects per second (counted on "
+                                 "the CPU restatement, Earth hoisted, libm calls at nominal cost). NOT a utilisation: the "
+                                 "device skips part of that work exactly (fixed-point exit of the correction loop: 55 % "
+                                 "of its iterations), and the fp64 peak counts an FMA as 2 while the path may not "
+                                 "contract a*b+c. The utilisations are `issue.step_issue_frac` and `fp64_executed.frac`."}
+        except (OSError, KeyError, ValueError):
+            pass
+    return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "limited_by": "fp64 VALU issue, not HBM: `frac` (algorithmic bytes of the dominant kernel against the HBM "
+                          "peak, the contract figure) is ~1e-3 by construction; read issue.step_issue_frac and "
+                          "fp64_executed.frac",
+            "issue": issue, "fp64_executed": executed, "step_traffic": step_traffic, "per_kernel": per_kernel or None,
+            "reference_equivalent": ref_equiv,
+            "counters": None if w is None else {"kind": "static_profile", "workload": workload, "source": w["source"],
+                                                "source_hash": w["source_hash"]},
+            "avg_launch_ms": avg_ms, "units_per_launch": units, "algorithmic_bytes_per_object": bytes_per_obj,
+            "all_kernels_avg_ms_per_step": {k: v[0] / steps for k, v in ktimes.items()}}
+
+
+def lsq_configs(outfit_amd):
+    """(name, description, config): the reference's default, and two workloads on which the corrector CORRECTS — on the
+    bench population the default divergence rule (diff_cor.rs:354-358, ratio 1.5 at :183) ends two thirds of the
+    trajectories at Newton iteration 2, which times the exit path; the reference's own integration test raises the ratio
+    to 10 for that reason (tests/test_diff_cor.rs:50-56)."""
+    D = outfit_amd.DifferentialCorrectionConfig
+    return [("default", "DifferentialCorrectionConfig::default() (rms_divergence_ratio 1.5)", D()),
+            ("ratio10", "rms_divergence_ratio = 10, the value of the reference's own test (tests/test_diff_cor.rs:52-55)",
+             D(rms_divergence_ratio=10.0)),
+            ("no_divergence_check", "rms_divergence_ratio = 1e300 (the divergence rule never fires: every trajectory "
+                                    "iterates to convergence, stagnation or the iteration cap)", D(rms_divergence_ratio=1e300))]
+
+
+def lsq_point(session, cfg, what, stream, steps, fence, n_obj, n_obs, iod_step_s, workload):
+    """k_diffcor on the session's resident IOD seeds: W = 1 warm-up pass, `steps` timed passes between fences."""
+    import numpy as np
+    session.run_lsq(cfg, stream=stream)   # warm-up (allocates the corrector's scratch)
+    fence()
+    session.set_profiling(True)
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        session.run_lsq(cfg, stream=stream)
+    fence()
+    el = time.perf_counter() - t1
+    kt = session.kernel_times()
+    session.set_profiling(False)
+    lrec, _ = session.lsq_results()
+    ms = 1e3 * el / steps
+    it = lrec["total_newton_iterations"]
+    hist = np.bincount(np.minimum(it, 20).astype(np.int64), minlength=21)
+    bytes_per_obj = (n_obs / n_obj) * (BYTES_PER_OBS_IN + 32) + BYTES_PER_RESULT + 480   # inputs, fit rows, seed, record
+    kd = kt.get("k_diffcor", (0.0, 1))
+    return {"what": "differential correction stage alone (k_diffcor on the resident IOD seeds), rank 0; BASELINE "
+                    "configs[4] per-GPU shape; config: " + what,
+            "ms_per_step": ms, "objects_per_s_stage": n_obj * steps / el,
+            "objects_per_s_iod_plus_lsq": n_obj / (1e-3 * ms + iod_step_s),
+            "kernel_avg_ms": kd[0] / max(1, kd[1]),
+            "converged": int((lrec["status"] == 0).sum()), "kept_iod_orbit": int((lrec["status"] == 1).sum()),
+            "dc_error_counts": {str(k): int(v) for k, v in zip(*np.unique(lrec["dc_error"][lrec["status"] == 1], return_counts=True))},
+            "dc_error_names": {"1": "DifferentialCorrectionFailed", "2": "BizarreOrbit", "3": "DifferentialCorrectionDiverged"},
+            "mean_newton_iterations": float(it.mean()),
+            "newton_iteration_histogram": {str(i) if i < 20 else "20+": int(c) for i, c in enumerate(hist) if c},
+            "outlier_passes_mean": float(lrec["outer_passes"].mean()), "rejected_observations": int(lrec["n_rejected"].sum()),
+            "roofline": roofline_block(kt, n_obj, steps, el / steps, bytes_per_obj, "lsq_" + workload, exclude=(),
+                                       only=("k_diffcor",))}
 
 
 def cpu_baseline_lsq(batch, ephem, params, seeds, n_obj_max, budget_s=5.0):
@@ -201,6 +414,7 @@ def main():
                     help="weak: --objects per GPU (default); strong: --total-objects split over the GPUs (BASELINE configs[3])")
     ap.add_argument("--total-objects", type=int, default=1_000_000, help="objects of the whole job for --scaling strong")
     ap.add_argument("--no-noise", action="store_true", help="skip the noisy-realisation side measurements (SURVEY 8d)")
+    ap.add_argument("--no-long-arcs", action="store_true", help="skip the long-trajectory side measurements (100 / 300 observations)")
     ap.add_argument("--no-modes", action="store_true", help="skip timing the other math mode and the parity sample")
     ap.add_argument("--parity-sample", type=int, default=2000, help="objects of the timed batch checked against the libm oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -211,6 +425,11 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal only: create the process group and run the gather path even with one rank "
                          "(exercises the RCCL calls and their stream ordering on a one-GPU box)")
+    ap.add_argument("--workload", default="all", choices=["all", "headline", "noise_default", "noise_8d", "lsq_default",
+                                                          "lsq_ratio10", "lsq_no_divergence_check", "long_arcs_100",
+                                                          "long_arcs_300"],
+                    help="profiling aid (tools/profile_gpu.sh): run ONLY that workload's timed region, so that a "
+                         "rocprofv3 pass attributes its counters to it; `all` is the bench line")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal only: every rank uses GPU 0 (needs --backend gloo)")
     args = ap.parse_args()
@@ -218,7 +437,7 @@ def main():
     import numpy as np
     import torch
     import outfit_amd
-    from outfit_amd import synth
+    from outfit_amd import libm_pin, synth
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -285,6 +504,29 @@ def main():
     # the headline runs in the library's default math mode (OUTFIT_MATH_GLIBC: the reference-faithful one, §4.0)
     mode_names = {outfit_amd.MATH_GLIBC: "glibc", outfit_amd.MATH_CORRECTLY_ROUNDED: "cr"}
     head_mode = outfit_amd.get_math_mode()
+    if args.workload == "headline":
+        args.no_modes = args.no_side = args.no_lsq = args.no_cpu_baseline = True
+    elif args.workload.startswith("lsq_"):
+        args.no_modes = args.no_side = args.no_cpu_baseline = True
+    elif args.workload != "all":
+        # profiling aid: ONLY that side workload's timed region runs in this process (tools/profile_gpu.sh)
+        assert world == 1, "--workload is a single-GPU profiling aid"
+        ts = torch.cuda.Stream()
+        torch.cuda.set_stream(ts)
+        nsteps = max(1, args.steps)
+        if args.workload == "noise_default":
+            r = noise_point("IODParams::default()", ds, ephem, outfit_amd.IODParams(), local_rank, ts.cuda_stream, nsteps,
+                            20261004, "noise_default")
+        elif args.workload == "noise_8d":
+            p_8d = synth.bench_params(outfit_amd.IODParams())
+            p_8d.n_noise_realizations = 10
+            r = noise_point("bench params with n_noise_realizations = 10", ds, ephem, p_8d, local_rank, ts.cuda_stream,
+                            nsteps, 20261005, "noise_8d")
+        else:
+            r = long_arc_points(outfit_amd, synth, local_rank, ts.cuda_stream, nsteps,
+                                which=(int(args.workload.rsplit("_", 1)[1]),))
+        print(json.dumps({"workload": args.workload, "result": r}), flush=True)
+        return
     session = outfit_amd.IODSession(batch, ephem, params, device=local_rank, math_mode=head_mode)
     # result buffers are double-buffered so that the gather of step i (RCCL, its own stream) overlaps the kernels
     # of step i+1; a buffer is reused only after the gather that read it has been waited for
@@ -300,14 +542,19 @@ def main():
     stream = tstream.cuda_stream
     assert stream != 0
     pending = [None, None]
-    state = {"step": 0}
+    state = {"step": 0, "gather_wait_s": 0.0}
+
+    def wait_gather(b):
+        if pending[b] is not None:
+            t = time.perf_counter()
+            pending[b].wait()
+            state["gather_wait_s"] += time.perf_counter() - t
+            pending[b] = None
 
     def step(sess=None):
         b = state["step"] & 1
         state["step"] += 1
-        if pending[b] is not None:
-            pending[b].wait()
-            pending[b] = None
+        wait_gather(b)
         (sess or session).run(stream=stream, d_out=out_local[b].data_ptr())
         if multi:
             if args.backend == "nccl":
@@ -317,9 +564,7 @@ def main():
 
     def fence():
         for b in (0, 1):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
+            wait_gather(b)
         if multi:
             dist.barrier()
         torch.cuda.synchronize()
@@ -330,9 +575,11 @@ def main():
             step(sess)
         fence()
         sess.set_profiling(True)
+        state["gather_wait_s"] = 0.0
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step(sess)
+        state["enqueue_s"] = time.perf_counter() - t0   # host time to enqueue the K steps (incl. waits on old gathers)
         fence()
         dt = time.perf_counter() - t0
         kt = sess.kernel_times()     # HIP events on the run's stream over the whole timed region
@@ -340,7 +587,9 @@ def main():
         sess.check()                 # an epoch outside the ephemeris table is an error here as in the blocking API
         return dt, kt
 
+    setup_s = time.perf_counter() - T_PROCESS_START      # imports, process group, dataset, upload, session
     elapsed, ktimes = timed(session)
+    my_elapsed, my_wait, my_enqueue = elapsed, state["gather_wait_s"], state["enqueue_s"]
     last_b = (state["step"] - 1) & 1
     res = np.frombuffer(out_local[last_b][:n_obj].cpu().numpy().tobytes(), dtype=outfit_amd._abi.RESULT_DTYPE).copy()
     gathered = out_all[last_b].cpu().numpy().copy() if multi else None
@@ -417,30 +666,20 @@ def main():
             side["noise"] = {
                 "iod_params_default": noise_point("IODParams::default(): max_triplets 10, n_noise_realizations 20, "
                                                   "max_obs_for_triplets 100 (mod.rs:308-344)", ds, ephem, p_def,
-                                                  local_rank, stream, nsteps, 20261004),
+                                                  local_rank, stream, nsteps, 20261004, "noise_default"),
                 "survey_8d": noise_point("bench params with n_noise_realizations = 10 (SURVEY 8d: 100 triplets x 11)",
-                                         ds, ephem, p_8d, local_rank, stream, nsteps, 20261005)}
+                                         ds, ephem, p_8d, local_rank, stream, nsteps, 20261005, "noise_8d")}
+        if not args.no_long_arcs:
+            side["long_arcs"] = long_arc_points(outfit_amd, synth, local_rank, stream, max(2, min(args.steps, 3)))
 
     # ---- next row (BASELINE configs[4]): IOD seed -> differential correction ----
     # Measured after the headline region and reported beside it, never mixed into `value`.
     lsq = None
-    if not args.no_lsq:
-        cfg = outfit_amd.DifferentialCorrectionConfig()
+    if not args.no_lsq and (args.workload == "all" or args.workload.startswith("lsq_")):
         session.run(stream=stream)            # the seeds: this session's own IOD records
-        session.run_lsq(cfg, stream=stream)   # warm-up (allocates the corrector's scratch)
-        fence()
-        session.set_profiling(True)
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            session.run_lsq(cfg, stream=stream)
-        fence()
-        lsq_elapsed = time.perf_counter() - t1
-        kt = session.kernel_times()
-        session.set_profiling(False)
-        lrec, _ = session.lsq_results()
-        lsq = {"elapsed": lsq_elapsed, "kernel_ms": kt.get("k_diffcor", (0.0, 1)),
-               "n_diffcor": int((lrec["status"] == 0).sum()), "n_iod_kept": int((lrec["status"] == 1).sum()),
-               "mean_newton_iterations": float(lrec["total_newton_iterations"].mean())}
+        lsq = {name: lsq_point(session, cfg, what, stream, args.steps, fence, n_obj, n_obs, elapsed / args.steps, name)
+               for name, what, cfg in lsq_configs(outfit_amd)
+               if args.workload == "all" or args.workload == "lsq_" + name}
 
     gather_check = None
     if multi:
@@ -461,95 +700,35 @@ def main():
                 bad.append(r)
         assert not bad, f"rank {rank}: gathered records of rank(s) {bad} differ from what those ranks computed"
         assert gathered[rank * n_max: rank * n_max + n_obj].tobytes() == res.tobytes()
-        gather_check = {"ranks_verified_by_every_rank": world, "records": int(sum(counts)), "crc32_per_rank": sums}
+        # per-rank timing of the timed region (the headline uses the MAX): step time, host time blocked on gathers,
+        # host set-up time before the timed region — what to look at when the N-GPU value is not N x the 1-GPU value
+        mine_t = torch.tensor([my_elapsed, my_wait, my_enqueue, setup_s,
+                               sum(v[0] for k, v in ktimes.items() if k in MAIN_STREAM_KERNELS) * 1e-3],
+                              dtype=torch.float64, device=gather_dev)
+        all_t = torch.zeros(world * 5, dtype=torch.float64, device=gather_dev)
+        dist.all_gather_into_tensor(all_t, mine_t)
+        all_t = all_t.cpu().numpy().reshape(world, 5)
+        gather_check = {"ranks_verified_by_every_rank": world, "records": int(sum(counts)), "crc32_per_rank": sums,
+                        "per_rank": {"ms_per_step": [1e3 * x / args.steps for x in all_t[:, 0]],
+                                     "gather_wait_ms_per_step": [1e3 * x / args.steps for x in all_t[:, 1]],
+                                     "host_enqueue_ms_per_step": [1e3 * x / args.steps for x in all_t[:, 2]],
+                                     "main_stream_kernel_ms_per_step": [1e3 * x / args.steps for x in all_t[:, 4]],
+                                     "setup_s_before_timed_region": [float(x) for x in all_t[:, 3]]},
+                        "ipc_mode": "HSA_ENABLE_IPC_MODE_LEGACY=" + os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "<unset>")}
     n_ok = int((res["status"] == 0).sum())
 
     if rank == 0:
         total_objects = sum(counts)
         value = total_objects * args.steps / elapsed
-        # dominant kernel and its roofline (algorithmic bytes, SURVEY §8d / DESIGN.md)
-        # ... among the kernels of the critical path: K0, K1 and the general correction kernel run on side
-        # streams in the shadow of these and their event times include waiting for a free CU
-        main_stream = [k for k in ktimes if k in ("k_gauss_roots", "k_gauss_correct_fast",
-                                                    "k_orbit_rms", "k_orbit_rms_slow", "k_select_best")]
-        dom = max(main_stream, key=lambda k: ktimes[k][0]) if main_stream else None
         bytes_per_obj = (n_obs / n_obj) * (BYTES_PER_OBS_IN + BYTES_PER_OBS_GEO) + BYTES_PER_RESULT
-        roof = None
-        if dom:
-            total_ms, launches = ktimes[dom]
-            avg_ms = total_ms / launches
-            units = n_obj * args.steps / launches          # objects one launch processes (rank 0's shard)
-            achieved = units * bytes_per_obj / (avg_ms * 1e-3) / 1e9
-            # HBM bytes of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
-            # separate runs; profiles/), scaled to one launch; null when no profile matches
-            # Counter-derived fields come from the committed rocprofv3 PMC passes (separate runs, as the guide
-            # prescribes) and are reported ONLY when that profile was taken from this very build (content hash of the
-            # kernel sources); otherwise null — a stale profile says nothing about this code.
-            traffic = None
-            valu = None
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
-                if pmc.get("source_hash") != source_hash():
-                    raise KeyError("profile taken from another build")
-                key = dom.replace("k_orbit_rms_slow", "k_orbit_rms<true>").replace("k_orbit_rms", "k_orbit_rms<false>") \
-                    if dom.startswith("k_orbit_rms") else dom
-                key = {"k_triplet_select": "k_triplet_select_lds"}.get(key, key)
-                scale = (n_obj / pmc["objects_per_step"]) * args.steps / launches
-                traffic = pmc["kernels"][key]["hbm_bytes_per_step"] * scale
-                instr = pmc["kernels"][key]["valu_wave_instr"] * scale
-                step_instr = sum(k["valu_wave_instr"] for n, k in pmc["kernels"].items() if not n.startswith("k_diffcor")) \
-                    * (n_obj / pmc["objects_per_step"])
-                valu = {"wave_instr_per_launch": instr, "issue_frac": instr / VALU_ISSUE_PEAK / (avg_ms * 1e-3),
-                        "step_wave_instr": step_instr,
-                        "step_issue_frac": step_instr / VALU_ISSUE_PEAK / (elapsed / args.steps),
-                        "peak_wave_instr_per_s": VALU_ISSUE_PEAK,
-                        "peak_is": "1024 SIMDs x 2.4 GHz / 4 cycles per 64-lane fp64 instruction",
-                        "kind": "static_profile", "source": pmc["source"], "source_hash": pmc["source_hash"]}
-            except (OSError, KeyError, ValueError):
-                pass
-            # the counted algorithmic fp64 work (tools/count_flops.py on the 1 000-object fixture) against the fp64 peak
-            fp64 = None
-            executed = None
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
-                if pmc.get("source_hash") == source_hash():
-                    ops = sum(k.get("fp64_lane_ops_upper", 0.0) for n, k in pmc["kernels"].items() if not n.startswith("k_diffcor"))
-                    if ops > 0:
-                        per_obj = ops / pmc["objects_per_step"]
-                        executed = {"fp64_lane_ops_per_object_upper": per_obj,
-                                    "achieved_tflops": value / world * per_obj / 1e12,
-                                    "frac": value / world * per_obj / 1e12 / FP64_PEAK_TFLOPS, "kind": "static_profile",
-                                    "what": "SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 lanes (FMA = 2; inactive lanes "
-                                            "included) of the committed profile of this build"}
-            except (OSError, KeyError, ValueError):
-                pass
-            try:
-                fl = json.load(open(os.path.join(ROOT, "profiles", "flops_per_object.json")))
-                f_obj = fl["hoisted"]["total_fp64_ops_per_object"]
-                fp64 = {"algorithmic_fp64_ops_per_object": f_obj,
-                        "of_which_libm_nominal": fl["hoisted"]["libm_fp64_ops_per_object_nominal"],
-                        "reference_decomposition_ops_per_object": fl["reference"]["total_fp64_ops_per_object"],
-                        "achieved_tflops": value / world * f_obj / 1e12, "peak_tflops": FP64_PEAK_TFLOPS,
-                        "frac": value / world * f_obj / 1e12 / FP64_PEAK_TFLOPS,
-                        "executed": executed,
-                        "note": "algorithmic = what the reference's arithmetic executes per object (counted on the CPU "
-                                "restatement, Earth hoisted); the device SKIPS part of it exactly (fixed-point exit of the "
-                                "correction loop: 55 % of its iterations), so this is work retired, not instructions "
-                                "issued — and the peak counts an FMA as 2 while the path may not contract a*b+c"}
-            except (OSError, KeyError, ValueError):
-                pass
-            roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "limited_by": "fp64 VALU issue, not HBM (see valu / fp64): the HBM fraction is ~1e-3 by construction",
-                    "valu": valu, "fp64": fp64,
-                    "avg_launch_ms": avg_ms, "units_per_launch": units, "algorithmic_bytes_per_object": bytes_per_obj,
-                    "all_kernels_avg_ms_per_step": {k: v[0] / args.steps for k, v in ktimes.items()}}
+        roof = roofline_block(ktimes, n_obj, args.steps, elapsed / args.steps, bytes_per_obj, "headline",
+                              objects_per_s_per_gpu=value / world)
         line = {
             "metric": "objects/s full Gauss IOD (20 obs, 100 triplets/obj)",
             "value": value, "unit": "objects/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "math_mode": mode_names[head_mode],
+            "math_mode": mode_names[head_mode], "host_libm": host_libm(),
             "config": {"workload": (f"{n_obj} synthetic objects per GPU x 20 obs, 100 triplets each "
                                     "(BASELINE configs[2] shape; synthetic DE440-layout table resident in HBM)")
                        if args.scaling == "weak" else
@@ -557,9 +736,11 @@ def main():
                         "(BASELINE configs[3]; synthetic DE440-layout table resident in HBM)"),
                        "objects_per_gpu": counts, "obs_per_object": n_obs / n_obj, "triplets_per_object": 100,
                        "n_noise_realizations": 0, "orbits_found_rank0": n_ok,
-                       "math_mode": mode_names[head_mode] + " (OUTFIT_MATH_GLIBC: sin/cos/sinh/cosh with glibc 2.35's bits — "
-                                    "the reference-faithful mode and the library's default)" if head_mode == outfit_amd.MATH_GLIBC
-                       else mode_names[head_mode],
+                       "math_mode": mode_names[head_mode] + " (OUTFIT_MATH_GLIBC, the library's default: every elementary "
+                                    "function of the path — sin, cos, sincos, tan, atan2, acos, hypot, log, exp / sinh / cosh — "
+                                    "with the bits of ONE libm build, " + libm_pin.PINNED_LIBM_WHAT + "; IOD and the "
+                                    "differential corrector both follow the mode)" if head_mode == outfit_amd.MATH_GLIBC
+                       else mode_names[head_mode] + " (OUTFIT_MATH_CORRECTLY_ROUNDED: platform-independent)",
                        "parallelism": f"objects sharded over {world} GPU(s); RCCL all_gather of 96-B results, overlapped with the next step"},
             "roofline": roof,
         }
@@ -570,15 +751,9 @@ def main():
         if gather_check is not None:
             line["gather_check"] = gather_check
         if lsq is not None:
-            ms = 1e3 * lsq["elapsed"] / args.steps
-            line["fit_lsq"] = {
-                "what": "differential correction stage alone (k_diffcor on the resident IOD seeds, default "
-                        "DifferentialCorrectionConfig), rank 0; BASELINE configs[4] per-GPU shape",
-                "ms_per_step": ms, "objects_per_s_stage": n_obj * args.steps / lsq["elapsed"],
-                "objects_per_s_iod_plus_lsq": n_obj / (1e-3 * ms + elapsed / args.steps),
-                "kernel_avg_ms": lsq["kernel_ms"][0] / max(1, lsq["kernel_ms"][1]),
-                "converged": lsq["n_diffcor"], "kept_iod_orbit": lsq["n_iod_kept"],
-                "mean_newton_iterations": lsq["mean_newton_iterations"]}
+            first = "default" if "default" in lsq else next(iter(lsq))
+            line["fit_lsq"] = dict(lsq[first])          # the reference's default config: the keys of rounds 1-3
+            line["fit_lsq"]["workloads"] = {k: v for k, v in lsq.items() if k != first}
         if side is not None:
             line["side"] = side
         if world == 1 and not args.no_cpu_baseline:

@@ -184,20 +184,23 @@ int  outfit_hip_iod_params_validate(const outfit_iod_params_t *p);
  * orb_elem.rs:58-226). The reference calls the platform libm there, so its own results depend on that libm; the
  * loop amplifies a last-place difference to ~1e-10.
  *   OUTFIT_MATH_GLIBC (default): sin, cos (the sincos pair AND the standalone entry points, which differ in glibc),
- *       sinh, cosh, atan2, tan, hypot, acos, log return the bits of glibc 2.35 on x86-64 with FMA (restated,
- *       device/glibcmath.hpp, glibcmath2.hpp, glibcmath3.hpp) — what the reference computes on the platform its known
- *       answers were recorded on. The RMS of every candidate is screened in a cheap arithmetic with an error bound and
+ *       sinh, cosh, atan2, tan, hypot, acos, log return the bits of ONE libm build — Ubuntu GLIBC 2.35-0ubuntu3.12,
+ *       x86-64, the FMA / AVX2 ifunc variants (libm.so.6 sha256 e5141752c850ea45...; restated in
+ *       device/glibcmath.hpp, glibcmath2.hpp, glibcmath3.hpp; outfit_amd/libm_pin.py tells whether a host runs that
+ *       build) — what the reference computes on the platform its known answers were recorded on. The RMS of every candidate is screened in a cheap arithmetic with an error bound and
  *       the contenders (those that can still be the minimum) are re-evaluated with glibc's functions (kernel K3b).
  *       Measured against the reference's arithmetic on glibc (the CPU restatement with the platform libm): 300 000 of
  *       300 000 (bench workload) and 200 000 of 200 000 (topocentric) records byte-identical, `rms` included
- *       (profiles/round03b_parity_glibc_bench_300000_screen.json, round03e_parity_glibc_topo_200000.json).
+ *       (profiles/round03g_parity_glibc_bench_300000_final.json, round03e_parity_glibc_topo_200000.json).
  *   OUTFIT_MATH_CORRECTLY_ROUNDED: every such function correctly rounded — platform independent (what a reference
  *       built against another libm would be compared with); against a glibc run of the reference ~0.8 % of the
  *       orbits move by more than 1e-12 rad.
  * The mode is a property of a CALL (outfit_hip_call_options_t below) or of a session (fixed at creation); the
  * process-wide value set here is only the default for calls that do not name one. Its initial value comes from
  * the environment variable OUTFIT_MATH_MODE ("glibc" / "cr"), else OUTFIT_MATH_GLIBC.
- * The differential corrector (fit_lsq) evaluates all its functions correctly rounded in both modes. */
+ * The differential corrector (fit_lsq) follows the mode of its call or session as the IOD does: glibc's bits in
+ * OUTFIT_MATH_GLIBC (its LSQ records and fit rows are then byte-identical to the CPU restatement run with that libm),
+ * correctly rounded in OUTFIT_MATH_CORRECTLY_ROUNDED. */
 #define OUTFIT_MATH_DEFAULT           (-1) /* in call options: the process-wide default at the time of the call */
 #define OUTFIT_MATH_CORRECTLY_ROUNDED 0
 #define OUTFIT_MATH_GLIBC             1

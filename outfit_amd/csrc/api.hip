@@ -6,6 +6,7 @@
 // tasks of one device are batched into four kernels per chunk of trajectories.
 // There is no CPU fallback: without a usable HIP device every entry point fails.
 #include <hip/hip_runtime.h>
+#include <cstddef>
 
 #include <algorithm>
 #include <atomic>
@@ -43,11 +44,22 @@ int current_math_mode() {
 }
 // the mode one call runs in: what its options name, else the process-wide default at this moment
 int resolve_math_mode(const outfit_hip_call_options_t* o, int* out) {
-  if (!o || o->math_mode == OUTFIT_MATH_DEFAULT) { *out = current_math_mode(); return OUTFIT_OK; }
-  if (o->struct_size < sizeof(outfit_hip_call_options_t)) {
-    g_last_error = "call options: struct_size is smaller than this library's outfit_hip_call_options_t";
+  if (!o) { *out = current_math_mode(); return OUTFIT_OK; }
+  // struct_size first: only the bytes it covers may be read. A struct of an OLDER (shorter) ABI is accepted as long as
+  // it reaches math_mode; fields it does not have take their defaults. reserved[] must be zero so that a later version
+  // can give it a meaning.
+  if (o->struct_size < offsetof(outfit_hip_call_options_t, math_mode) + sizeof(o->math_mode)) {
+    g_last_error = "call options: struct_size does not cover math_mode (set it to sizeof(outfit_hip_call_options_t))";
     return OUTFIT_ERR_INVALID_PARAM;
   }
+  for (size_t k = 0; k < 3; ++k) {
+    const size_t end = offsetof(outfit_hip_call_options_t, reserved) + (k + 1) * sizeof(uint64_t);
+    if (o->struct_size >= end && o->reserved[k] != 0) {
+      g_last_error = "call options: reserved words must be zero";
+      return OUTFIT_ERR_INVALID_PARAM;
+    }
+  }
+  if (o->math_mode == OUTFIT_MATH_DEFAULT) { *out = current_math_mode(); return OUTFIT_OK; }
   if (o->math_mode != OUTFIT_MATH_CORRECTLY_ROUNDED && o->math_mode != OUTFIT_MATH_GLIBC) {
     g_last_error = "call options: math_mode must be OUTFIT_MATH_DEFAULT, _CORRECTLY_ROUNDED or _GLIBC";
     return OUTFIT_ERR_INVALID_PARAM;

@@ -1,3 +1,16 @@
+// SPDX-License-Identifier: LGPL-2.1-or-later
+// This file restates algorithms and/or carries constant tables of the GNU C Library (glibc) 2.35 math library:
+//   Copyright (C) 1993-2022 Free Software Foundation, Inc.
+//   sin/cos/tan/atan2/acos: IBM Accurate Mathematical Library, written by International Business Machines Corp.,
+//     Copyright (C) 2001-2022 Free Software Foundation, Inc.
+//   exp/log: contributed to glibc by Arm Ltd. (Szabolcs Nagy), Copyright (C) 2018-2022 Free Software Foundation, Inc.
+//   sinh/cosh/expm1: derived from FreeBSD/Sun fdlibm — Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.
+//     Permission to use, copy, modify, and distribute this software is freely granted, provided that this notice is preserved.
+// glibc is free software; you can redistribute it and/or modify it under the terms of the GNU Lesser General Public
+// License as published by the Free Software Foundation; either version 2.1 of the License, or (at your option) any later
+// version. It is distributed WITHOUT ANY WARRANTY. The license text is in LICENSES/LGPL-2.1.txt; what that means for
+// liboutfit_hip.so, which compiles this file in, is in NOTICE.
+//
 // glibcmath3.hpp — acos and log with the bits glibc 2.35 (x86-64, FMA-capable CPU) returns. Companion of glibcmath.hpp (sin, cos,
 // sinh, cosh) and glibcmath2.hpp (atan2, tan, hypot).
 //

@@ -996,9 +996,12 @@ constexpr unsigned kRefineList = 256;  // contenders a wave holds between two ev
 // latency bound (dependent double-double chains, table look-ups), a third wave hides more than the spills cost.
 // Measured and dropped (round 3): the fold and this kernel run slice by slice on the side stream under the next slice's
 // K2c — same step time (18.05 ms): each of its long-lived waves displaces a K2c wave (registers), K2c 3.05 -> 3.65 ms.
+// inject_fail: test aid (OUTFIT_TEST_EXACT_RMS_FAILS=1, read by the launcher): every exact evaluation reports an Err,
+// so that the path "the screen accepted candidates the exact evaluation rejects" can be exercised
+// (tests/test_gpu_glibc_mode.py); always 0 otherwise.
 template <int kFn>  // kFnGlibc: the glibc-faithful mode; kFnPlatform: the correctly-rounded mode's RMS (platform functions)
 __global__ void __launch_bounds__(64, 3)
-k_refine_best(RmsArgs r, GaussResultRec* out_all, const double* bound, unsigned long long n_traj) {
+k_refine_best(RmsArgs r, GaussResultRec* out_all, const double* bound, unsigned long long n_traj, int inject_fail) {
   __shared__ unsigned s_item_c[kRefineList];      // candidate index within its trajectory
   __shared__ unsigned char s_item_t[kRefineList]; // trajectory of the wave (0..kRefineTraj-1)
   __shared__ double s_item_rms[kRefineList];      // its exact RMS (NaN: cannot be selected)
@@ -1072,7 +1075,7 @@ k_refine_best(RmsArgs r, GaussResultRec* out_all, const double* bound, unsigned 
       if (k < count) {
         const unsigned long long cid = (blk0 + s_item_t[k]) * r.I.cand_per_traj + s_item_c[k];
         const double e = exact_candidate_rms<kFn>(r, cid, sub, group_base);
-        if (sub == 0) s_item_rms[k] = e;
+        if (sub == 0) s_item_rms[k] = inject_fail ? nan("") : e;
       }
     }
     __syncthreads();
@@ -1102,9 +1105,26 @@ k_refine_best(RmsArgs r, GaussResultRec* out_all, const double* bound, unsigned 
 #endif
   const unsigned long long c0 = lt * r.I.cand_per_traj;
   if (!ok || sub != 0) return;
-  if (best_c < 0) {  // no finite exact value: K3's choice stands, with its screened RMS
-    best_c = (long long)(out_all[r.I.traj0 + lt].best_triplet * r.I.n_real + out_all[r.I.traj0 + lt].best_realization);
-    best = out_all[r.I.traj0 + lt].rms;
+  GaussResultRec* out = out_all + r.I.traj0 + lt;
+  if (best_c < 0) {
+    // No candidate has a finite exact RMS, not even in the exhaustive second round: the exact evaluation rejects
+    // what the screen accepted. The reference skips every Err / non-finite score and ends in
+    // NoViableOrbit{cause: last error, attempts} (trajectory.rs:499-541) — so does this record: K3 counted the
+    // attempts (no `?` abort, or status would not be 0); the cause is the LAST candidate's error in fold order: a
+    // prelim_orbit Err keeps its code, a candidate that reached the RMS now scores non-finite (NonFiniteScore).
+    int last_error = 0;
+    const unsigned n_c = r.I.n_triplets[lt] * r.I.n_real;
+    for (unsigned c = 0; c < n_c; ++c) {
+      const unsigned f = r.W.flags[c0 + c];
+      last_error = (f & kFlagOk) ? 4 : (int)(f & 0xFu);
+    }
+    out->status = 2;
+    out->cause = last_error;
+    out->stage = 0; out->kind = 0;
+    out->best_triplet = 0; out->best_realization = 0;
+    out->epoch = 0.0; out->rms = 0.0;
+    for (int k = 0; k < 6; ++k) out->elem[k] = 0.0;
+    return;
   }
   // the winner's record: build_result -> compute_orbit_from_state -> ccek1 with glibc's bits (K3 filled the counters)
   const unsigned long long cid = c0 + (unsigned long long)best_c, nc = r.I.n_cand;
@@ -1113,7 +1133,6 @@ k_refine_best(RmsArgs r, GaussResultRec* out_all, const double* bound, unsigned 
   const Vec3 v2 = {r.W.state[3 * nc + cid], r.W.state[4 * nc + cid], r.W.state[5 * nc + cid]};
   const Elements el = kFn == kFnGlibc ? ccek1<kFnGlibc>(equ_to_ecl(r2), equ_to_ecl(v2), r.W.state[6 * nc + cid])
                                       : ccek1<kFnCr>(equ_to_ecl(r2), equ_to_ecl(v2), r.W.state[6 * nc + cid], kMathCr);
-  GaussResultRec* out = out_all + r.I.traj0 + lt;
   out->stage = (f & kFlagCorrected) ? 1 : 0;
   out->best_triplet = (unsigned)best_c / r.I.n_real;
   out->best_realization = (unsigned)best_c % r.I.n_real;
@@ -1128,8 +1147,9 @@ hipError_t launch_refine_best(const SelectArgs& a, const RmsArgs& r, hipStream_t
   { static const unsigned long long z[4] = {}; (void)hipStreamSynchronize(s); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_refine_stats), z, sizeof z); }
 #endif
   const dim3 grid((unsigned)((a.n_traj + kRefineTraj - 1) / kRefineTraj));
-  if (a.math_mode == kMathGlibc) hipLaunchKernelGGL(k_refine_best<kFnGlibc>, grid, dim3(64), 0, s, r, a.out, a.bound, a.n_traj);
-  else hipLaunchKernelGGL(k_refine_best<kFnPlatform>, grid, dim3(64), 0, s, r, a.out, a.bound, a.n_traj);
+  static const int inject_fail = std::getenv("OUTFIT_TEST_EXACT_RMS_FAILS") != nullptr;  // test aid, see the kernel
+  if (a.math_mode == kMathGlibc) hipLaunchKernelGGL(k_refine_best<kFnGlibc>, grid, dim3(64), 0, s, r, a.out, a.bound, a.n_traj, inject_fail);
+  else hipLaunchKernelGGL(k_refine_best<kFnPlatform>, grid, dim3(64), 0, s, r, a.out, a.bound, a.n_traj, inject_fail);
 #ifdef OUTFIT_REFINE_STATS
   { unsigned long long h[4] = {}; (void)hipStreamSynchronize(s); (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_refine_stats), sizeof h);
     fprintf(stderr, "[refine stats] trajectories %llu contenders %llu (%.4f each) list passes %llu largest list of a wave %llu\n", h[0], h[1], h[0] ? (double)h[1] / h[0] : 0.0, h[2], h[3]); }

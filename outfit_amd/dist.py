@@ -6,8 +6,17 @@ src/initial_orbit_determination/obs_dataset_api.rs:277-296; the Rayon
 rank takes a contiguous range of trajectories balanced by observation count, runs
 the kernels on its own GPU with no data-path exchange, and the fixed-size result
 records are gathered once at the end (all_gather over xGMI; 96 B per trajectory).
+
+Environment: RCCL between processes shares device memory through IPC handles; on hosts whose driver supports only
+dmabuf IPC (this MI355X pool) `HSA_ENABLE_IPC_MODE_LEGACY=0` must be in the environment BEFORE the process makes its
+first HIP call, otherwise communicator set-up fails with `hipIpcGetMemHandle: invalid argument`. Importing this module
+sets it when the variable is absent (an explicit value is respected); bench.py does the same at its first line.
 """
+import os
+
 import numpy as np
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 from ._abi import LSQ_DTYPE, RESULT_DTYPE
 

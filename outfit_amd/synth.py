@@ -194,6 +194,27 @@ def _propagate_kepler_ecl(a, e, inc, node, argp, m0, dt):
     return np.stack([x, y, z], axis=-1)
 
 
+def night_offsets(n_nights):
+    """Day offsets of the observing nights: the bench cadence {0, 3, 7, 12, 20, 27, 35, 44}, continued for long arcs
+    with gaps cycling through 3, 5, 4, 8 days (25 nights span 129 days, 50 nights 254 days)."""
+    off = [0.0, 3.0, 7.0, 12.0, 20.0, 27.0, 35.0, 44.0]
+    gaps = (3.0, 5.0, 4.0, 8.0)
+    while len(off) < n_nights:
+        off.append(off[-1] + gaps[(len(off) - 8) % 4])
+    return np.array(off[:n_nights])
+
+
+def make_long_arc_dataset(n_obj, n_obs, seed=DEFAULT_SEED + 1000, **kw):
+    """Long trajectories: n_obs = 100 -> 25 nights x 4 exposures (129-day arcs, exactly
+    `IODParams::default().max_obs_for_triplets`: the cap is not hit), n_obs = 300 -> 50 nights x 6 exposures (254-day
+    arcs: down-sampling to 100 epochs, quirk Q1, and the dt_max_triplet = 150 d window really cuts). The Chebyshev
+    table is extended to 24 blocks (768 days) so that every epoch is inside it."""
+    n_exp = 4 if n_obs <= 128 else 6
+    assert n_obs % n_exp == 0, "n_obs must be a multiple of the exposures per night"
+    ephem = kw.pop("ephem", None) or make_ephemeris(n_blocks=24)
+    return make_dataset(n_obj, seed=seed, ephem=ephem, n_nights=n_obs // n_exp, n_exp=n_exp, **kw)
+
+
 def make_dataset(n_obj, seed=DEFAULT_SEED, ephem=None, topocentric=False, n_nights=5, n_exp=4,
                  start_spread=300.0, sigma_arcsec=0.3, night_scale=1.0, a_min=1.8, a_span=1.8, e_max=0.35):
     """Synthetic batch in the SoA layout of outfit_obs_batch_t.
@@ -212,7 +233,7 @@ def make_dataset(n_obj, seed=DEFAULT_SEED, ephem=None, topocentric=False, n_nigh
     argp = 2 * np.pi * rng.uniform(n_obj)
     m0 = 2 * np.pi * rng.uniform(n_obj)
     start = 60000.0 + start_spread * rng.uniform(n_obj)
-    night_off = night_scale * np.array([0.0, 3.0, 7.0, 12.0, 20.0, 27.0, 35.0, 44.0])[:n_nights]
+    night_off = night_scale * night_offsets(n_nights)
     jitter = (0.2 * night_scale) * rng.uniform(n_obj * n_nights).reshape(n_obj, n_nights)
     nights = start[:, None] + night_off[None, :] + jitter
     mjd = (nights[:, :, None] + 0.02 * np.arange(n_exp)[None, None, :]).reshape(n_obj, n_nights * n_exp)

@@ -17,14 +17,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def host_is_glibc_x86_64():
-    libc, ver = platform.libc_ver()
-    if libc != "glibc" or platform.machine() != "x86_64":
-        return False
-    try:
-        flags = open("/proc/cpuinfo").read()
-    except OSError:
-        return False
-    return " fma " in flags and " avx2 " in flags  # the ifunc variant of exp the restatement follows
+    """True only on the ONE libm build the glibc-faithful mode restates (glibc 2.35, x86-64, FMA/AVX2 ifunc variants,
+    the libm.so.6 whose sha256 tools/extract_glibc_tables.py knows): on any other libc the "== platform libm" tests
+    skip instead of failing (outfit_amd/libm_pin.py)."""
+    from outfit_amd.libm_pin import host_has_pinned_libm
+    return host_has_pinned_libm()
+
+
+def pinned_libm_reason():
+    from outfit_amd.libm_pin import host_libm_identity
+    return "platform libm is not the build OUTFIT_MATH_GLIBC restates: " + str(host_libm_identity()["why_not"])
 
 
 @pytest.fixture(scope="module")
@@ -32,7 +34,7 @@ def L():
     return O.lib()
 
 
-@pytest.mark.skipif(not host_is_glibc_x86_64(), reason="host libm is not glibc on x86-64 with FMA/AVX2")
+@pytest.mark.skipif(not host_is_glibc_x86_64(), reason=pinned_libm_reason())
 def test_restatement_returns_the_host_libm_bits(L):
     """Zero differences on 8 x 10^6 arguments per function (tools/glibc_pin.c ran 1.5e9 / 1e8 when this was written)."""
     counts = (C.c_uint64 * 6)()

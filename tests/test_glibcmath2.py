@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from test_glibcmath import host_is_glibc_x86_64
+from test_glibcmath import host_is_glibc_x86_64, pinned_libm_reason
 
 dp = C.POINTER(C.c_double)
 N = 2_000_000
@@ -64,7 +64,7 @@ def vec(f, *a):
     return np.array([f(*(float(v) for v in row)) for row in zip(*a)])
 
 
-@pytest.mark.skipif(not host_is_glibc_x86_64(), reason="the platform libm is the reference here: needs glibc on x86-64 with FMA")
+@pytest.mark.skipif(not host_is_glibc_x86_64(), reason=pinned_libm_reason())
 def test_restatements_equal_the_platform_libm(L):
     libm = C.CDLL("libm.so.6")   # the entry points themselves (numpy may route through its own SIMD kernels)
     for name, nargs in (("sin", 1), ("cos", 1), ("tan", 1), ("atan2", 2), ("hypot", 2), ("acos", 1), ("log", 1)):
@@ -87,7 +87,7 @@ def test_restatements_equal_the_platform_libm(L):
     assert np.array_equal(vec(L.orc_glibc_log, v).view(np.uint64), vec(libm.log, v).view(np.uint64))
 
 
-@pytest.mark.skipif(not host_is_glibc_x86_64(), reason="needs glibc on x86-64 with FMA")
+@pytest.mark.skipif(not host_is_glibc_x86_64(), reason=pinned_libm_reason())
 def test_glibc_sin_and_sincos_are_different_functions(L):
     """sincos(x) (one SSE2 variant) and sin(x) / cos(x) (FMA variants) of glibc 2.35 disagree in the last bit for
     0.03 - 0.2 % of arguments; the two restatements reproduce their respective originals exactly."""

@@ -19,8 +19,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def run_bench(*extra, port="29541"):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    # bench.py itself puts HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC, what RCCL needs on this pool) into its environment
+    # before the first HIP call: the child starts WITHOUT the variable, as under a launcher that does not export it
+    env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
                         "--no-cpu-baseline", "--no-side", "--no-lsq", "--no-modes", *extra],
                        env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
@@ -60,8 +62,8 @@ def test_two_ranks_share_the_gpu_through_gloo_unequal_shards():
     """World size 2 on the one GPU (rehearsal mode: gloo gathers host copies, both ranks use GPU 0): the barrier /
     max-over-ranks timing, the padded gather of UNEQUAL shards (75 000 objects as 3 blocks over 2 ranks: 25 000 +
     50 000) and the whole-table check on every rank — each rank verifies both shards against the CRCs exchanged."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29543", os.path.join(ROOT, "bench.py"),
@@ -75,4 +77,10 @@ def test_two_ranks_share_the_gpu_through_gloo_unequal_shards():
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["objects_per_gpu"] == [25000, 50000]
     gc = line["gather_check"]
     assert gc["ranks_verified_by_every_rank"] == 2 and gc["records"] == 75000 and len(set(gc["crc32_per_rank"])) == 2
+    # per-rank timing of the timed region, and the IPC mode the ranks ran with (set by bench.py itself)
+    pr = gc["per_rank"]
+    assert all(len(pr[k]) == 2 for k in ("ms_per_step", "gather_wait_ms_per_step", "host_enqueue_ms_per_step",
+                                         "main_stream_kernel_ms_per_step", "setup_s_before_timed_region"))
+    assert max(pr["ms_per_step"]) <= line["ms_per_step"] * (1 + 1e-9) and min(pr["ms_per_step"]) > 0
+    assert gc["ipc_mode"] == "HSA_ENABLE_IPC_MODE_LEGACY=0"
     assert abs(line["value"] - 75000 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]

@@ -19,7 +19,7 @@ import pytest
 import oracle_lib as O
 import outfit_amd
 from outfit_amd import synth
-from test_glibcmath import host_is_glibc_x86_64
+from test_glibcmath import host_is_glibc_x86_64, pinned_libm_reason
 
 pytestmark = pytest.mark.gpu
 TOL_LEN, TOL_ANG = 1e-10, 1e-12
@@ -115,7 +115,7 @@ def test_sessions_keep_the_mode_they_were_created_with():
 
 def test_noisy_realisations_and_the_corrector_in_glibc_mode():
     """Noisy realisations rebuild the direction cosines per candidate (gauss.rs:341-386 -> unit_matrix) with the mode's
-    sin/cos; the corrector stays correctly rounded in both modes. Device (glibc mode) == oracle (restated mode), bytes."""
+    sin/cos; the corrector follows the mode too (glibc's bits here). Device (glibc mode) == oracle (restated mode), bytes."""
     eph_d = synth.make_ephemeris()
     ds = synth.make_dataset(400, seed=31337, ephem=eph_d, topocentric=True)
     params = outfit_amd.IODParams()                      # 10 triplets x (1 + 20 realisations)
@@ -239,7 +239,67 @@ def test_contender_refinement_equals_the_exhaustive_exact_evaluation(tmp_path, m
         assert r["fragile"] < 0.01 * r["candidates"], r
 
 
-@pytest.mark.skipif(not host_is_glibc_x86_64(), reason="the platform libm is the reference here: needs glibc on x86-64 with FMA")
+def test_exact_evaluation_rejecting_every_candidate_is_no_viable_orbit(tmp_path):
+    """K3b when NO candidate of a trajectory has a finite exact RMS (the exact evaluation fails where the screen did
+    not — e.g. a Kepler solve of propagate_twobody that the warm-started screen gets through): the reference skips every
+    Err / non-finite score and returns NoViableOrbit{cause: last error, attempts} (trajectory.rs:499-541). The device
+    used to keep K3's screened winner there. OUTFIT_TEST_EXACT_RMS_FAILS=1 (a test aid read by the launcher) makes every
+    exact evaluation report an Err, so every trajectory that had an orbit must come back as status 2 with the cause of
+    its LAST candidate in fold order (NonFiniteScore = 4 when that candidate reached the RMS, its prelim_orbit error
+    otherwise), the attempts K3 counted, and an all-zero orbit."""
+    import subprocess
+    import sys
+    code = r"""
+import sys
+import numpy as np
+sys.path[:0] = [sys.argv[1], sys.argv[1] + "/tests"]
+import outfit_amd
+from outfit_amd import synth
+eph_d = synth.make_ephemeris()
+ephem = outfit_amd.Ephemeris.from_dict(eph_d)
+for i, (n, seed, params) in enumerate(((3000, 20264001, synth.bench_params(outfit_amd.IODParams())),
+                                       (1500, 20264002, outfit_amd.IODParams()))):
+    ds = synth.make_dataset(n, seed=seed, ephem=eph_d)
+    nz = n * params.max_triplets * params.n_noise_realizations * 6
+    if nz:
+        ds["noise_z"] = np.random.default_rng(seed).standard_normal(nz)
+    sess = outfit_amd.IODSession(outfit_amd.ObsBatch.from_dict(ds), ephem, params, math_mode=outfit_amd.MATH_GLIBC)
+    sess.run()
+    rec = sess.results()
+    total, n_win, flags = sess.candidate_scores()
+    sess.close()
+    np.savez(sys.argv[2] + "%d.npz" % i, rec=rec, flags=flags, cand_per_traj=params.max_triplets * (1 + params.n_noise_realizations),
+             n_real=1 + params.n_noise_realizations)
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for tag, env in (("plain", {}), ("inject", {"OUTFIT_TEST_EXACT_RMS_FAILS": "1"})):
+        e = dict(os.environ, **env)
+        if not env:
+            e.pop("OUTFIT_TEST_EXACT_RMS_FAILS", None)
+        p = subprocess.run([sys.executable, "-c", code, root, str(tmp_path / tag)], env=e, capture_output=True, text=True,
+                           timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+    for i in range(2):
+        a, b = np.load(tmp_path / ("plain%d.npz" % i)), np.load(tmp_path / ("inject%d.npz" % i))
+        ra, rb, fl = a["rec"], b["rec"], b["flags"]
+        assert np.array_equal(a["flags"], fl)                      # the candidates are the same; only K3b's verdict differs
+        had = ra["status"] == 0
+        assert had.sum() > 0.9 * len(ra)
+        assert np.array_equal(ra[~had].tobytes(), rb[~had].tobytes())   # trajectories without an orbit: untouched
+        assert (rb["status"][had] == 2).all()
+        assert np.array_equal(rb["attempts"], ra["attempts"]) and np.array_equal(rb["n_triplets"], ra["n_triplets"])
+        cpt, n_real = int(a["cand_per_traj"]), int(a["n_real"])
+        last = np.arange(len(ra)) * cpt + ra["n_triplets"].astype(np.int64) * n_real - 1
+        f_last = fl[last[had]]
+        expect = np.where((f_last & 0x10) != 0, 4, f_last & 0xF)          # kernels.h: 0x10 = kFlagOk, low nibble = cause
+        assert np.array_equal(rb["cause"][had], expect.astype(rb["cause"].dtype))
+        assert (expect == 4).sum() > 0
+        for k in ("stage", "kind", "best_triplet", "best_realization"):
+            assert (rb[k][had] == 0).all(), k
+        assert (rb["epoch"][had] == 0).all() and (rb["rms"][had] == 0).all() and (rb["elem"][had] == 0).all()
+
+
+@pytest.mark.skipif(not host_is_glibc_x86_64(), reason=pinned_libm_reason())
 def test_corrector_equals_the_platform_libm_oracle():
     """Row n1 in the glibc-faithful mode (round 3): IOD -> differential correction on the device against the oracle with
     the PLATFORM libm (no restated function, no correctly-rounded scope: the reference's arithmetic on this host) —

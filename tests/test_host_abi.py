@@ -249,8 +249,23 @@ def test_call_options_abi_v6_without_a_gpu(L):
     o.math_mode = 7
     assert L.outfit_hip_fit_full_iod_ex(C.byref(pc), C.byref(bc), C.byref(ec), 1, C.byref(o), out) == -1
     assert b"math_mode" in L.outfit_hip_last_error()
-    o.math_mode, o.struct_size = 1, 8
+    # struct_size is checked FIRST and only the bytes it covers are read: 4 bytes do not reach math_mode -> refused,
+    # whatever the mode field would say (OUTFIT_MATH_DEFAULT included)
+    for mode in (1, -1):
+        o.math_mode, o.struct_size = mode, 4
+        assert L.outfit_hip_fit_full_iod_ex(C.byref(pc), C.byref(bc), C.byref(ec), 1, C.byref(o), out) == -1
+        assert b"struct_size" in L.outfit_hip_last_error()
+    # reserved words must be zero (so that a later ABI can give them a meaning) ...
+    L.outfit_hip_call_options_default(C.byref(o))
+    o.reserved[1] = 5
     assert L.outfit_hip_fit_full_iod_ex(C.byref(pc), C.byref(bc), C.byref(ec), 1, C.byref(o), out) == -1
-    assert b"struct_size" in L.outfit_hip_last_error()
+    assert b"reserved" in L.outfit_hip_last_error()
+    # ... but are not read beyond struct_size: a caller struct that ends after math_mode is a valid shorter ABI
+    o.math_mode, o.struct_size = 1, 8
+    rc = L.outfit_hip_fit_full_iod_ex(C.byref(pc), C.byref(bc), C.byref(ec), 1, C.byref(o), out)
+    assert b"reserved" not in L.outfit_hip_last_error() and b"struct_size" not in L.outfit_hip_last_error()
+    assert rc in (0, _abi_const("OUTFIT_ERR_NO_DEVICE"))    # options accepted: the call gets as far as the device
+    o.reserved[1] = 0
+    o.math_mode, o.struct_size = 1, 4
     h = C.c_void_p()
     assert L.outfit_hip_session_create_ex(C.byref(pc), C.byref(bc), C.byref(ec), 0, C.byref(o), C.byref(h)) == -1

@@ -18,7 +18,7 @@ import pytest
 import oracle_lib as O
 import outfit_amd
 from outfit_amd import synth
-from test_glibcmath import host_is_glibc_x86_64
+from test_glibcmath import host_is_glibc_x86_64, pinned_libm_reason
 
 INTS = ("status", "cause", "stage", "kind", "attempts", "n_triplets", "best_triplet", "best_realization")
 
@@ -70,7 +70,7 @@ def test_aberth_horner_fusion_changes_roots_but_no_result():
     assert fused.tobytes() == unfused.tobytes()
 
 
-@pytest.mark.skipif(not host_is_glibc_x86_64(), reason="the platform libm is the thing measured: needs glibc on x86-64")
+@pytest.mark.skipif(not host_is_glibc_x86_64(), reason=pinned_libm_reason())
 def test_distance_between_the_math_modes_and_the_platform_libm():
     """On 3 000 objects of the bench workload, against the oracle with the PLATFORM libm (the reference-faithful mode
     on this host): the correctly-rounded mode keeps every integer output but leaves 0.2 - 3 % of the orbits beyond

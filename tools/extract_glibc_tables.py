@@ -31,6 +31,15 @@ KNOWN3 = {  # sha256 -> (asncs, inroot, powtwo): the addresses __ieee754_acos_fm
 }
 
 
+
+def license_header(style):
+    """The LGPL notice every glibc-derived file carries (tools/glibc_license_header.txt), as a C or C++ comment."""
+    txt = open(os.path.join(ROOT, "tools", "glibc_license_header.txt")).read().rstrip("\n").split("\n")
+    if style == "c":
+        return "/*\n" + "\n".join((" * " + l) if l else " *" for l in txt) + "\n */\n"
+    return "\n".join(("// " + l) if l else "//" for l in txt) + "\n//\n"
+
+
 def main():
     data = open(LIBM, "rb").read()
     sha = hashlib.sha256(data).hexdigest()
@@ -51,11 +60,11 @@ def main():
 
     def rows(tab):
         return ",\n".join("  {" + ", ".join(float.hex(v) for v in r) + "}" for r in tab)
-    c = ("/* " + header.replace("\n", "\n * ") + " */\n#pragma once\n"
+    c = (license_header("c") + "/* " + header.replace("\n", "\n * ") + " */\n#pragma once\n"
          f"static const double orc_glibc_cij[241][7] = {{\n{rows(cij)}\n}};\n"
          f"static const double orc_glibc_xfg[186][4] = {{\n{rows(xfg)}\n}};\n")
     open(os.path.join(ROOT, "oracle", "glibc_tables2.h"), "w").write(c)
-    d = ("// " + header.replace("\n", "\n// ") + "\n#pragma once\nnamespace outfit {\nnamespace glm {\n"
+    d = (license_header("cpp") + "// " + header.replace("\n", "\n// ") + "\n#pragma once\nnamespace outfit {\nnamespace glm {\n"
          f"__device__ const double kCij[241][7] = {{\n{rows(cij)}\n}};\n"
          f"__device__ const double kXfg[186][4] = {{\n{rows(xfg)}\n}};\n}}  // namespace glm\n}}  // namespace outfit\n")
     open(os.path.join(ROOT, "outfit_amd", "csrc", "device", "glibc_tables2.hpp"), "w").write(d)
@@ -84,14 +93,14 @@ def main():
 
     def flat(tab, per=4):
         return ",\n".join("  " + ", ".join(float.hex(v) for v in tab[i:i + per]) for i in range(0, len(tab), per))
-    c3 = ("/* " + header3.replace("\n", "\n * ") + " */\n#pragma once\n"
+    c3 = (license_header("c") + "/* " + header3.replace("\n", "\n * ") + " */\n#pragma once\n"
           f"static const double orc_glibc_asncs[2568] = {{\n{flat(asncs)}\n}};\n"
           f"static const double orc_glibc_inroot[128] = {{\n{flat(inroot)}\n}};\n"
           f"static const double orc_glibc_powtwo[28] = {{\n{flat(powtwo)}\n}};\n"
           f"/* ln2hi, ln2lo, A[5], B[11], then 128 x (invc, logc) */\n"
           f"static const double orc_glibc_logdata[274] = {{\n{flat(logd)}\n}};\n")
     open(os.path.join(ROOT, "oracle", "glibc_tables3.h"), "w").write(c3)
-    d3 = ("// " + header3.replace("\n", "\n// ") + "\n#pragma once\nnamespace outfit {\nnamespace glm {\n"
+    d3 = (license_header("cpp") + "// " + header3.replace("\n", "\n// ") + "\n#pragma once\nnamespace outfit {\nnamespace glm {\n"
           f"__device__ const double kAsncs[2568] = {{\n{flat(asncs)}\n}};\n"
           f"__device__ const double kInroot[128] = {{\n{flat(inroot)}\n}};\n"
           f"// ln2hi, ln2lo, A[5], B[11], then 128 x (invc, logc)\n"

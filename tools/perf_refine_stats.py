@@ -1,7 +1,12 @@
+"""GPU box: K3b's contender statistics (diagnostic build: `make -C outfit_amd/csrc variant NAME=rstats
+DEFS=-DOUTFIT_REFINE_STATS`) — trajectories, contenders per trajectory, list passes, largest list of a wave — for the
+bench workload and for IODParams::default() with noise; the kernel prints them to stderr.
+    python tools/perf_refine_stats.py [path of the stats library]"""
 import os, sys
-sys.path[:0] = ["/root/repo"]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT]
 import outfit_amd._lib as L
-L.LIB_PATH = "/root/repo/outfit_amd/csrc/_build/variant_rstats/liboutfit_hip.so"
+L.LIB_PATH = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "outfit_amd/csrc/_build/variant_rstats/liboutfit_hip.so")
 import numpy as np, outfit_amd
 from outfit_amd import synth
 ed = synth.make_ephemeris(); eph = outfit_amd.Ephemeris.from_dict(ed)
