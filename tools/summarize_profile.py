@@ -16,12 +16,32 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, name = sys.argv[1], sys.argv[2]
 n_obj = int(sys.argv[3]) if len(sys.argv) > 3 else 100000
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
-LAUNCHES_PER_STEP = {"k_gauss_roots": 4, "k_triplet_select_lds": 4, "k_triplet_select": 4, "k_observer_prepass": 2}
 
 
-def launches_per_step(k):
-    """launches of kernel k in one step (template arguments stripped: k_gauss_roots<4u> -> k_gauss_roots)"""
-    return LAUNCHES_PER_STEP.get(k.split("<")[0], 1)
+def bench_runs(passdir):
+    """How many times the pass's bench.py process ran the IOD kernels / the corrector: read from the JSON line it
+    printed (bench_<pass>.log). Counters are summed per kernel name over the process, so per-step = sum / runs."""
+    iod = lsq = 1
+    try:
+        line = [ln for ln in open(os.path.join(src, f"bench_{passdir}.log")) if ln.startswith("{")][-1]
+        j = json.loads(line)
+        if "workload" in j:                      # --workload noise_* / long_arcs_*: one set-up run + `steps` timed runs
+            r = j["result"]
+            r = r if "steps" in r else next(iter(r.values()))
+            iod = 1 + int(r["steps"])
+        else:
+            iod = int(j["steps"]) + int(j["warmup"])
+            if "fit_lsq" in j:                   # --workload lsq_*: + the seed run; corrector: one warm-up + steps
+                iod += 1
+                lsq = 1 + int(j["steps"])
+    except (OSError, IndexError, KeyError, ValueError):
+        pass
+    return iod, lsq
+
+
+def runs_of(k, passdir):
+    iod, lsq = bench_runs(passdir)
+    return float(lsq if k.startswith("k_diffcor") else iod)
 
 
 def short(k):
@@ -29,17 +49,20 @@ def short(k):
 
 
 def counters(sub):
+    """({(kernel, counter): sum over the process}, {kernel: runs of that kernel's stage in the process})"""
     agg, calls = collections.defaultdict(float), collections.Counter()
     for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
-        seen = set()
+        seen, disp = set(), set()
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
             if k.startswith("__amd"):
                 continue
             agg[(k, r["Counter_Name"])] += float(r["Counter_Value"])
-            if (r["Dispatch_Id"], k) not in seen:
-                seen.add((r["Dispatch_Id"], k))
-                calls[k] += 1
+            seen.add(k)
+            disp.add((k, r["Dispatch_Id"]))
+        for k in seen:
+            # the calibration program is not bench.py: there the divisor is the number of launches
+            calls[k] = runs_of(k, sub) if not sub.startswith("calib") else sum(1 for q, _ in disp if q == k)
     return agg, calls
 
 
@@ -94,7 +117,7 @@ hdr = "%-24s%7s" % ("kernel", "steps") + "".join("%16s" % c[:15] for c in sq_nam
 lines.append(hdr)
 for k in kernels:
     def steps(c):
-        return max(1.0, c.get(k, 0) / launches_per_step(k))
+        return max(1.0, c.get(k, 0))
     row = {c: sq.get((k, c), 0.0) / steps(cs) for c in sq_names}
     row["FETCH_SIZE"] = fetch.get((k, "FETCH_SIZE"), 0.0) / steps(cf)
     row["WRITE_SIZE"] = write.get((k, "WRITE_SIZE"), 0.0) / steps(cw)
@@ -132,7 +155,7 @@ with open(out, "w") as f:
         f.write("\nfp64 instruction mix (wave-instructions per step; SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64):\n")
         tot = collections.Counter()
         for k in kernels:
-            st = max(1.0, c64.get(k, 0) / launches_per_step(k))
+            st = max(1.0, c64.get(k, 0))
             row = {c: f64.get((k, c), 0.0) / st for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")}
             f.write("%-24s add %.3e  mul %.3e  fma %.3e  trans %.3e\n" % (k, *row.values()))
             if not k.startswith("k_diffcor"):
@@ -144,18 +167,59 @@ with open(out, "w") as f:
         f.write("\nengine clock under this load (separate pass, --pmc GRBM_GUI_ACTIVE; kernels on side streams overlap others and read high):\n")
         f.write("\n".join(clk_lines) + "\n")
     f.write("```\n")
+lanes, cl = counters("pmc_lanes")
+
+
+def kernel_rows(kernel_names, sq_, cs_, fetch_, cf_, write_, cw_, f64_, c64_, lanes_, cl_):
+    """Per-step figures of one workload for latest_pmc.json (bench.py roofline_block reads them)."""
+    rows = {}
+    for k in kernel_names:
+        def per(agg, calls, c):
+            return agg.get((k, c), 0.0) / max(1.0, calls.get(k, 0))
+        fb = per(fetch_, cf_, "FETCH_SIZE") * 1024 * (fetch_factor or 1.0)
+        wb = per(write_, cw_, "WRITE_SIZE") * 1024 * (write_factor or 1.0)
+        g = lambda c: per(f64_, c64_, c)  # noqa: E731
+        rows[k] = {"hbm_bytes_per_step": fb + wb, "fetch_bytes": fb, "write_bytes": wb,
+                   "fp64_wave_instr": g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64") + g("SQ_INSTS_VALU_FMA_F64")
+                                      + g("SQ_INSTS_VALU_TRANS_F64"),
+                   "fp64_lane_ops_upper": 64.0 * (g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64")
+                                                  + 2.0 * g("SQ_INSTS_VALU_FMA_F64") + g("SQ_INSTS_VALU_TRANS_F64")),
+                   "valu_wave_instr": per(sq_, cs_, "SQ_INSTS_VALU"),
+                   # lanes per VALU instruction = thread_cycles_valu / active_inst_valu (both in quad-cycles), of 64
+                   "thread_cycles_valu": per(lanes_, cl_, "SQ_THREAD_CYCLES_VALU"),
+                   "active_inst_valu": per(lanes_, cl_, "SQ_ACTIVE_INST_VALU")}
+    return rows
+
+
 pmc = {"source": f"profiles/{name}_rocprof_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_*, separate passes; "
                  "byte counters calibrated on 8-B-per-lane streams)",
        "source_hash": source_hash, "fetch_factor": fetch_factor, "write_factor": write_factor,
-       "objects_per_step": n_obj, "kernels": {}}
-for k in kernels:
-    r = per_step[k]
-    fb, wb = r["FETCH_SIZE"] * 1024 * (fetch_factor or 1.0), r["WRITE_SIZE"] * 1024 * (write_factor or 1.0)
-    st64 = max(1.0, c64.get(k, 0) / launches_per_step(k))
-    g = lambda c: f64.get((k, c), 0.0) / st64  # noqa: E731
-    pmc["kernels"][k] = {"hbm_bytes_per_step": fb + wb, "fetch_bytes": fb, "write_bytes": wb,
-                         "fp64_lane_ops_upper": 64.0 * (g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64")
-                                                        + 2.0 * g("SQ_INSTS_VALU_FMA_F64") + g("SQ_INSTS_VALU_TRANS_F64")),
-                         "valu_wave_instr": r["SQ_INSTS_VALU"]}
+       "objects_per_step": n_obj,
+       "kernels": kernel_rows(kernels, sq, cs, fetch, cf, write, cw, f64, c64, lanes, cl), "workloads": {}}
+pmc["workloads"]["headline"] = {"objects_per_step": n_obj, "kernels": pmc["kernels"]}
+# the extra workloads of tools/profile_gpu.sh (bench.py --workload W: only that region ran in the process)
+WORKLOAD_OBJECTS = {"long_arcs_100": 10000, "long_arcs_300": 10000}
+try:
+    extra = open(os.path.join(src, "extra_workloads.txt")).read().split()
+except OSError:
+    extra = []
+with open(out, "a") as f:
+    for w in extra:
+        wsq, wcs = counters(f"w_{w}_sq")
+        wf, wcf = counters(f"w_{w}_fetch")
+        ww, wcw = counters(f"w_{w}_write")
+        w64, wc64 = counters(f"w_{w}_f64")
+        names = sorted({k for k, _ in wsq})
+        if not names:
+            continue
+        rows = kernel_rows(names, wsq, wcs, wf, wcf, ww, wcw, w64, wc64, wsq, wcs)
+        pmc["workloads"][w] = {"objects_per_step": WORKLOAD_OBJECTS.get(w, n_obj), "kernels": rows}
+        f.write(f"\n## workload `{w}` (bench.py --workload {w} --steps 1 --warmup 0; per step)\n```\n")
+        for k in names:
+            r = rows[k]
+            f.write("%-26s VALU wave-instr %.3e  lanes/instr %5.1f  fp64 share %.2f  fetch %8.1f MB  write %8.1f MB\n"
+                    % (k, r["valu_wave_instr"], r["thread_cycles_valu"] / max(1.0, r["active_inst_valu"]),
+                       r["fp64_wave_instr"] / max(1.0, r["valu_wave_instr"]), r["fetch_bytes"] / 1e6, r["write_bytes"] / 1e6))
+        f.write("```\n")
 json.dump(pmc, open(os.path.join(ROOT, "profiles", "latest_pmc.json"), "w"), indent=1)
 print(open(out).read())
