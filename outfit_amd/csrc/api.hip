@@ -292,6 +292,11 @@ struct outfit_hip_session {
   DevBuf<unsigned> n_triplets[2], flags, n_win;
   unsigned n_cu = 256;
   bool triplet_lds = false;  // K0 keeps its heap in LDS (small k_cap, <= 1024 reduced observations)
+  // K0, wave form: trajectories whose reduced length reaches wave_min_obs (absolute ids, ascending; 0 = form unused)
+  unsigned wave_min_obs = 0;
+  size_t wave_lds = 0;
+  std::vector<unsigned> wave_list_host;
+  DevBuf<unsigned> wave_list;
   DevBuf<outfit::GaussResultRec> results;
   DevBuf<int> error_flag;
   // differential correction (allocated by the first run_lsq)
@@ -348,7 +353,7 @@ struct outfit_hip_session {
     helio.release(); geo.release(); obs_pos.release(); cos_dec.release(); unit[0].release(); unit[1].release(); noise.release(); coef.release();
     heap_w.release(); sum.release(); dirS.release(); roots.release(); state.release();
     psi0.release(); slow_list.release(); slow_count.release(); sel_bound.release();
-    heap_id.release(); triplets[0].release(); triplets[1].release(); queue.release();
+    heap_id.release(); triplets[0].release(); triplets[1].release(); queue.release(); wave_list.release();
     n_triplets[0].release(); n_triplets[1].release(); flags.release();
     n_win.release(); results.release(); error_flag.release();
     dc_res.release(); dc_cov.release(); dc_qr.release(); dc_sel.release();
@@ -647,6 +652,26 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
     for (uint64_t t = 0; t < s->n_traj; ++t) max_len = std::max<uint64_t>(max_len, off[t + 1] - off[t]);
     const uint64_t reduced = std::min<uint64_t>(max_len, std::max<uint64_t>(params->max_obs_for_triplets, 3));
     s->triplet_lds = reduced <= 1024 && (uint64_t)s->k_cap * 64 * 12 <= 160 * 1024 - 1024 && s->k_cap > 0;
+    // Long trajectories go to the wave-per-trajectory form of K0 (device/triplets.hpp): from 48 reduced epochs on
+    // (C(48,3) = 17 296 scored triplets) one lane's chain is longer than a whole small batch's other kernels; the
+    // bench cadence (20 epochs) stays with the lane form. LDS per wave: epochs + heap (weight, 64-bit id).
+    unsigned wave_min = 48;
+    if (const char* e = std::getenv("OUTFIT_K0_WAVE_MIN")) {  // testing / measurement aid: 3 = every trajectory, 0 = never
+      const long long v = std::atoll(e);
+      if (v >= 0) wave_min = (unsigned)std::min<long long>(v, 1ll << 30);
+    }
+    const uint64_t lds = (reduced + 2ull * s->k_cap) * sizeof(double);
+    if (wave_min && s->k_cap > 0 && reduced >= wave_min && lds <= 60ull * 1024 && s->n_traj < (1ull << 32)) {
+      const uint64_t keep = std::max<uint64_t>(params->max_obs_for_triplets, 3);
+      for (uint64_t t = 0; t < s->n_traj; ++t)
+        if (std::min<uint64_t>(off[t + 1] - off[t], keep) >= wave_min && off[t + 1] - off[t] >= 3)
+          s->wave_list_host.push_back((unsigned)t);
+      if (!s->wave_list_host.empty()) {
+        s->wave_min_obs = wave_min;
+        s->wave_lds = (size_t)lds;
+        TRY_RC(upload(s->wave_list, s->wave_list_host.data(), s->wave_list_host.size()));
+      }
+    }
   }
   return OUTFIT_OK;
 }
@@ -759,9 +784,17 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
       ta.heap_w = s->heap_w.p; ta.heap_id = s->heap_id.p;
       ta.heap_stride = (unsigned long long)((s->chunk + 63) / 64 * 64);
       ta.n_triplets = s->n_triplets[tb].p + a0; ta.triplets = s->triplets[tb].p + a0 * s->k_cap;
+      // the slice's long trajectories: one wave each; the lane kernel skips them (and is not launched for a slice
+      // made of long trajectories only)
+      ta.wave_min_obs = s->wave_min_obs;
+      const auto w0 = std::lower_bound(s->wave_list_host.begin(), s->wave_list_host.end(), (unsigned)(t0 + a0));
+      const auto w1 = std::lower_bound(w0, s->wave_list_host.end(), (unsigned)(t0 + a1));
+      ta.wave_list = s->wave_list.p ? s->wave_list.p + (w0 - s->wave_list_host.begin()) : nullptr;
+      ta.n_wave_list = (unsigned)(w1 - w0);
       {
         Stamp stamp(s, k0, K_TRIPLETS);
-        HIP_TRY(outfit::launch_triplet_select(ta, s->triplet_lds, k0));
+        if (ta.n_wave_list < a1 - a0) HIP_TRY(outfit::launch_triplet_select(ta, s->triplet_lds, k0));
+        HIP_TRY(outfit::launch_triplet_select_wave(ta, s->wave_lds, k0));
       }
       HIP_TRY(hipEventRecord(s->ev_sub[i], k0));
     }

@@ -189,6 +189,13 @@ __device__ __forceinline__ unsigned select_triplets(const double* mjd /* this tr
     for (unsigned middle = anchor + 1; middle < hi; ++middle) {
       const double tm = ep(middle);
       const double g12 = s_gap(tm - t0, P.inv_dtw);
+      // Exact row skip. s_gap(dt) >= 1 for every dt >= 0 (1/r with r <= 1, else 1 + r; NaN stays NaN), and epochs
+      // are sorted, so every weight of this (anchor, middle) row is >= fl(g12 + 1) or not finite. With the heap full
+      // its top only decreases, and a candidate with w >= top is not pushed (`w < heap[0].w`, mod.rs:396-403): if
+      // fl(g12 + 1) >= top now, no candidate of the row can change the heap — the row is not enumerated. With the
+      // reference's defaults (K = 10 of up to C(100,3) = 161 700 triplets) this removes all but the rows whose
+      // first gap is near the optimal interval.
+      if (len == P.k_cap && !(g12 + 1.0 < root_w)) continue;
       unsigned last = lo > middle + 1 ? lo : middle + 1;
       double t_last = last <= hi ? ep(last) : 0.0;
       for (; last <= hi; ++last) {
@@ -224,6 +231,131 @@ __device__ __forceinline__ unsigned select_triplets(const double* mjd /* this tr
     }
     for (unsigned j = i; j > lo; --j) h.move(j, j - 1);
     h.set_raw(lo, xw, xr);
+  }
+  return len;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same selection by ONE WAVE per trajectory, for long trajectories (the reference's default caps the search at
+// max_obs_for_triplets = 100 epochs: up to C(100,3) = 161 700 scored triplets, a chain of that length for the
+// one-lane form above whatever the batch size).
+//
+// Exact, because of what the reference's loop (mod.rs:365-408) can and cannot observe:
+//   * a candidate whose weight is not below the heap's top is dropped without touching the heap, and with the heap
+//     full the top only decreases — so a candidate with w >= top(now) is dropped whenever it comes;
+//   * the candidates that DO touch the heap must do so in the generator's order (index_generator.rs:228-271:
+//     anchor, then middle, then last), each seeing the top its predecessors left.
+// The wave therefore scores 64 consecutive `last` indices of one (anchor, middle) row at once, ballots
+// `finite && (heap not full || w < top)`, and only the survivors go through the literal heap operations, in lane
+// order = generator order, with the top re-read after each — lane 0 runs the very sift code of the one-lane form on
+// a heap in LDS. Rows and whole groups of rows are skipped by the same argument (every weight of a row is
+// >= fl(g12 + 1)): 64 middles of an anchor are tested at once. The final stable sort is a rank computation
+// (rank = #{w_j < w_i} + #{j < i : w_j == w_i}), which is what a stable insertion sort produces.
+// LDS: the reduced epochs [n] and the heap [k_cap] x (weight, 64-bit id); the launcher checks that it fits.
+// Returns the number of triplets (wave-uniform) and writes them, sorted, to `out` (global).
+struct WaveHeap {   // heap of one trajectory in LDS; same interface as HeapView (stride 1)
+  double* w;
+  unsigned long long* id;
+  __device__ __forceinline__ double W(unsigned s) const { return w[s]; }
+  __device__ __forceinline__ unsigned long long I(unsigned s) const { return id[s]; }
+  __device__ __forceinline__ void move(unsigned dst, unsigned src) const { w[dst] = w[src]; id[dst] = id[src]; }
+  typedef unsigned long long Raw;
+  __device__ __forceinline__ Raw raw(unsigned s) const { return id[s]; }
+  __device__ __forceinline__ Raw encode(unsigned long long ii) const { return ii; }
+  __device__ __forceinline__ void set_raw(unsigned s, double ww, Raw r) const { w[s] = ww; id[s] = r; }
+};
+
+__device__ __forceinline__ unsigned select_triplets_wave(const double* mjd /* this trajectory */, unsigned long long n_obs64,
+                                                         const TripletParams& P, double* ep /* LDS [n] */,
+                                                         const WaveHeap& h, unsigned long long* out) {
+  if (P.k_cap == 0 || n_obs64 < 3) return 0;
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned n_obs = (unsigned)n_obs64;
+  const unsigned n = (unsigned)reduced_len(n_obs64, P.max_keep);
+  for (unsigned i = lane; i < n; i += 64u) ep[i] = mjd[(unsigned)keep_index(i, n_obs, P.max_keep)];
+  __syncthreads();
+  unsigned len = 0;       // wave-uniform
+  double root_w = 0.0;    // wave-uniform copy of the heap's top weight
+  // survivors of one ballot, in lane order; `w` / `id` are the lanes' candidates
+  auto absorb = [&](unsigned long long mask, double w, unsigned long long id) {
+    while (mask) {
+      const int l = __ffsll((long long)mask) - 1;
+      mask &= mask - 1ull;
+      const double wl = __shfl(w, l);
+      const unsigned long long il = __shfl(id, l);
+      if (len < P.k_cap) {
+        if (lane == 0) heap_sift_up(h, 0, len, wl, il);
+        ++len;
+      } else if (wl < root_w) {
+        if (lane == 0) {
+          unsigned ll = len;
+          heap_pop(h, ll);
+          heap_sift_up(h, 0, ll, wl, il);
+        }
+      } else {
+        continue;  // the top has dropped below this candidate since the ballot
+      }
+      __syncthreads();
+      root_w = h.W(0);
+    }
+  };
+  for (unsigned anchor = 0; anchor + 2 < n; ++anchor) {
+    const double t0 = ep[anchor];
+    // LastWindow::compute (index_generator.rs:94-114): the two `while` scans, 64 indices per step; each stops at
+    // the first index that fails its test, exactly as the sequential loops do (no monotonicity is assumed)
+    unsigned lo = anchor + 2;
+    for (;;) {
+      const unsigned i = lo + lane;
+      const unsigned long long fail = __ballot(!(i < n && ep[i < n ? i : 0] - t0 < P.dt_min));
+      const unsigned adv = fail ? (unsigned)__ffsll((long long)fail) - 1u : 64u;
+      lo += adv;
+      if (adv < 64u) break;
+    }
+    unsigned hi = lo - 1;
+    if (hi < anchor + 1) hi = anchor + 1;
+    for (;;) {
+      const unsigned i = hi + 1 + lane;
+      const unsigned long long fail = __ballot(!(i < n && ep[i < n ? i : 0] - t0 <= P.dt_max));
+      const unsigned adv = fail ? (unsigned)__ffsll((long long)fail) - 1u : 64u;
+      hi += adv;
+      if (adv < 64u) break;
+    }
+    if (lo >= n || lo > hi || hi <= anchor + 1) continue;  // LastWindow::is_empty
+    for (unsigned mb = anchor + 1; mb < hi; mb += 64u) {
+      // 64 middles at once: first-gap term of the weight and the row test
+      const unsigned m_mine = mb + lane;
+      const bool m_in = m_mine < hi;
+      const double tm_mine = ep[m_in ? m_mine : 0];
+      const double g12_mine = s_gap(tm_mine - t0, P.inv_dtw);
+      unsigned long long rows = __ballot(m_in && (len < P.k_cap || g12_mine + 1.0 < root_w));
+      while (rows) {
+        const int rl = __ffsll((long long)rows) - 1;
+        rows &= rows - 1ull;
+        const double g12 = __shfl(g12_mine, rl);
+        if (len == P.k_cap && !(g12 + 1.0 < root_w)) continue;  // the top has dropped since the row ballot
+        const unsigned middle = mb + (unsigned)rl;
+        const double tm = __shfl(tm_mine, rl);
+        const unsigned first = lo > middle + 1 ? lo : middle + 1;
+        for (unsigned lb = first; lb <= hi; lb += 64u) {
+          const unsigned last = lb + lane;
+          const bool in = last <= hi;
+          const double w = g12 + s_gap(ep[in ? last : 0] - tm, P.inv_dtw);
+          const unsigned long long mask = __ballot(in && isfinite(w) && (len < P.k_cap || w < root_w));
+          if (mask) absorb(mask, w, pack_triplet(anchor, middle, last));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // sort_unstable_by(weight) as the stable order of the heap's vector (see select_triplets): rank of every slot
+  for (unsigned i = lane; i < len; i += 64u) {
+    const double wi = h.W(i);
+    unsigned rank = 0;
+    for (unsigned j = 0; j < len; ++j) {
+      const double wj = h.W(j);
+      rank += (wj < wi || (wj == wi && j < i)) ? 1u : 0u;
+    }
+    out[rank] = h.I(i);
   }
   return len;
 }

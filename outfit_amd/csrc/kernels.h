@@ -53,6 +53,12 @@ struct TripletArgs {
   unsigned long long heap_stride;
   unsigned* n_triplets;                 // [n_traj] (chunk-local)
   unsigned long long* triplets;         // [n_traj][k_cap] packed (i,j,k)
+  // Two forms of the same selection (device/triplets.hpp): one LANE per trajectory, and one WAVE per trajectory for
+  // those whose reduced length is >= wave_min_obs (0 = the wave form is not used in this session). The lane kernels
+  // leave such trajectories alone; k_triplet_select_wave runs over `wave_list` (absolute trajectory ids, ascending).
+  unsigned wave_min_obs;
+  const unsigned* wave_list;
+  unsigned n_wave_list;
 };
 
 // the two halves of K1 (they run on different streams: the direction cosines ahead of K2a, the observer
@@ -187,6 +193,7 @@ struct DiffCorArgs {
 };
 
 hipError_t launch_triplet_select(const TripletArgs& a, bool lds_heap, hipStream_t s);
+hipError_t launch_triplet_select_wave(const TripletArgs& a, size_t lds_bytes, hipStream_t s);
 hipError_t launch_observer_prepass(const PrepassArgs& a, hipStream_t s);
 hipError_t launch_gauss_roots(const RootsArgs& a, hipStream_t s);
 hipError_t reset_slow_list(const CandidateScratch& w, hipStream_t s);

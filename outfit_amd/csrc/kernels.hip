@@ -43,6 +43,7 @@ k_triplet_select(TripletArgs a) {
   const unsigned long long traj = a.traj0 + lt;
   const unsigned long long base = a.traj_offset[traj];
   const unsigned long long n_obs = a.traj_offset[traj + 1] - base;
+  if (a.wave_min_obs && reduced_len(n_obs, a.P.max_keep) >= a.wave_min_obs) return;  // k_triplet_select_wave's
   // heap slot s of lane lt: scratch[(s * n_lanes_padded) + lt]
   HeapView h{a.heap_w + lt, a.heap_id + lt, a.heap_stride};
   const unsigned n = select_triplets(a.mjd + base, n_obs, a.P, h);
@@ -61,11 +62,29 @@ k_triplet_select_lds(TripletArgs a) {
   const unsigned long long traj = a.traj0 + lt;
   const unsigned long long base = a.traj_offset[traj];
   const unsigned long long n_obs = a.traj_offset[traj + 1] - base;
+  if (a.wave_min_obs && reduced_len(n_obs, a.P.max_keep) >= a.wave_min_obs) return;  // k_triplet_select_wave's
   LdsHeapView h{lds_heap + threadIdx.x, reinterpret_cast<unsigned*>(lds_heap + (size_t)a.P.k_cap * 64) + threadIdx.x,
                 64u};
   const unsigned n = select_triplets(a.mjd + base, n_obs, a.P, h);
   a.n_triplets[lt] = n;
   for (unsigned s = 0; s < n; ++s) a.triplets[lt * a.P.k_cap + s] = h.I(s);
+}
+
+// One wave per LONG trajectory (device/triplets.hpp, select_triplets_wave): 64 lanes score a row of the generator at
+// once, only the survivors of the ballot go through the literal heap operations. LDS: reduced epochs [n], then the
+// heap's weights [k_cap] and 64-bit ids [k_cap].
+__global__ void __launch_bounds__(64)
+k_triplet_select_wave(TripletArgs a) {
+  extern __shared__ double lds_wave[];
+  const unsigned long long traj = a.wave_list[blockIdx.x];
+  const unsigned long long lt = traj - a.traj0;
+  const unsigned long long base = a.traj_offset[traj];
+  const unsigned long long n_obs = a.traj_offset[traj + 1] - base;
+  const unsigned n = (unsigned)reduced_len(n_obs, a.P.max_keep);
+  double* ep = lds_wave;
+  WaveHeap h{lds_wave + n, reinterpret_cast<unsigned long long*>(lds_wave + n + a.P.k_cap)};
+  const unsigned len = select_triplets_wave(a.mjd + base, n_obs, a.P, ep, h, a.triplets + lt * a.P.k_cap);
+  if (threadIdx.x == 0) a.n_triplets[lt] = len;
 }
 
 // ------------------------------------------------------------------------------
@@ -1486,6 +1505,11 @@ hipError_t launch_triplet_select(const TripletArgs& a, bool lds_heap, hipStream_
   } else {
     hipLaunchKernelGGL(k_triplet_select, dim3(grid), dim3(64), 0, s, a);
   }
+  return hipGetLastError();
+}
+hipError_t launch_triplet_select_wave(const TripletArgs& a, size_t lds_bytes, hipStream_t s) {
+  if (a.n_wave_list == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_triplet_select_wave, dim3(a.n_wave_list), dim3(64), lds_bytes, s, a);
   return hipGetLastError();
 }
 hipError_t launch_observer_prepass(const PrepassArgs& a, hipStream_t s) {
