@@ -346,10 +346,12 @@ enum CorrStep { kCorrContinue = 0, kCorrSome = 1, kCorrNone = 2, kCorrSlow = 3 }
 // cold-start value prelim_kepuni(params) there before the first iteration (solve_kepuni_with_guess(None) IS
 // run_newton(prelim_kepuni(params)), and a first iteration whose solves fail ends the loop: the cold start is
 // never needed again), so the correctly-rounded cold-start code stays out of the loop body.
-template <bool kFast, bool kWarmOnly = kFast>
+// Params: GaussParams, or a type with the same field names whose fields convert to their values where they are read
+// (kernels.hip KernargGaussParams: parameters re-read from the kernarg segment instead of being held in SGPRs).
+template <bool kFast, bool kWarmOnly = kFast, class Params = GaussParams>
 __device__ __forceinline__ CorrStep correction_iteration(const Mat3& obs, const Mat3& S, const Mat3& Sinv,
                                                          double t_mid, double dt01, double dt21,
-                                                         const GaussParams& P, CorrectionState& st) {
+                                                         const Params& P, CorrectionState& st) {
   KSTAT(3);
   st.it += 1;
   const bool last = st.it >= P.newton_max_it;

@@ -22,6 +22,7 @@
 //
 // Compiled with -ffp-contract=off: the reference (Rust) never fuses a*b+c.
 #include <hip/hip_runtime.h>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include "kernels.h"
@@ -365,6 +366,45 @@ k_gauss_roots(RootsArgs a) {
 #endif
 constexpr unsigned kRefillThreshold = OUTFIT_K2B_THRESHOLD;  // idle lanes per wave before the queue is touched
 
+// The kernel's own argument block, re-read from the kernarg segment at the point of use. The persistent kernels hold
+// ~35 pointers and sizes (CandidateIndex, CandidateScratch) that only their REFILL path needs; kept live across the
+// iteration loop they overflow the scalar register file and come back through v_readlane in the hot loop (K2b: 97
+// spilled SGPRs, 31 of the 424 instructions of its iteration core). The empty asm makes the pointer opaque at this
+// point, so the loads below it cannot be hoisted out of the branch they are in: the refill path pays ~10 scalar loads
+// (cached, once per ~7 trips) and the loop keeps only what it uses.
+template <class T>
+__device__ __forceinline__ T kernarg_field(unsigned offset) {
+  typedef const __attribute__((address_space(4))) char* kptr;
+  kptr p = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  T out;
+  __builtin_memcpy(&out, p + offset, sizeof(T));
+  return out;
+}
+#ifndef OUTFIT_KERNARG_RELOAD       // the refill path's pointers (CandidateIndex, CandidateScratch) re-read at the refill
+#define OUTFIT_KERNARG_RELOAD 1
+#endif
+#ifndef OUTFIT_KERNARG_LAZY_PARAMS  // GaussParams fields and the result pointers re-read where they are used
+#define OUTFIT_KERNARG_LAZY_PARAMS 1
+#endif
+// GaussParams of a kernel whose argument struct holds it at byte `kOff`, every field read from the kernarg segment where
+// it is used (an s_load on the scalar memory path, not a v_readlane on the VALU): same field names as GaussParams,
+// so the device functions templated on the parameter type read `P.max_ecc` either way.
+template <unsigned kOff>
+struct KernargGaussParams {
+  template <class T, unsigned kField>
+  struct Lazy {
+    __device__ __forceinline__ operator T() const { return kernarg_field<T>(kOff + kField); }
+  };
+#define OUTFIT_LAZY(type, name) Lazy<type, (unsigned)offsetof(GaussParams, name)> name
+  OUTFIT_LAZY(double, max_ecc); OUTFIT_LAZY(double, max_perihelion_au); OUTFIT_LAZY(double, min_rho2_au);
+  OUTFIT_LAZY(double, aberth_eps); OUTFIT_LAZY(double, kepler_eps); OUTFIT_LAZY(double, r2_min_au);
+  OUTFIT_LAZY(double, r2_max_au); OUTFIT_LAZY(double, newton_eps); OUTFIT_LAZY(double, root_imag_eps);
+  OUTFIT_LAZY(unsigned, aberth_max_iter); OUTFIT_LAZY(unsigned, max_tested_solutions);
+  OUTFIT_LAZY(unsigned, newton_max_it); OUTFIT_LAZY(int, math_mode);
+#undef OUTFIT_LAZY
+};
+
 // wave-wide grab of the next queue entries for the lanes in need_mask
 __device__ __forceinline__ unsigned long long wave_grab(unsigned long long* queue, unsigned long long need_mask) {
   const unsigned lane = __lane_id();
@@ -408,13 +448,20 @@ k_gauss_correct_fast(CorrectArgs a) {
         if (my >= n) {
           exhausted = true;
         } else {
-          const unsigned f = a.W.flags[my];
+#if OUTFIT_KERNARG_RELOAD
+          const CandidateIndex I = kernarg_field<CandidateIndex>((unsigned)offsetof(CorrectArgs, I));
+          const CandidateScratch W = kernarg_field<CandidateScratch>((unsigned)offsetof(CorrectArgs, W));
+#else
+          const CandidateIndex& I = a.I;
+          const CandidateScratch& W = a.W;
+#endif
+          const unsigned f = W.flags[my];
           if ((f & kFlagOk) && !(f & (kFlagEmpty | kFlagSlow))) {
-            const CandidateGeometry g = load_geometry(a.I, a.W, my);
+            const CandidateGeometry g = load_geometry(I, W, my);
             const unsigned slot = (f >> kFlagFirstShift) & 0xFu;
             double e_pre;
             // same inputs as in K2a' -> same (pos, vel, vc); accepted there, so accepted here
-            (void)accept_root(g.obs, g.S, g.Sinv, g.t[1], g.q, a.P, a.W.roots[(unsigned long long)slot * n + my],
+            (void)accept_root(g.obs, g.S, g.Sinv, g.t[1], g.q, a.P, W.roots[(unsigned long long)slot * n + my],
                               st.pos, st.vel, e_pre, st.vc);
 #pragma unroll
             for (int r = 0; r < 3; ++r)
@@ -428,8 +475,8 @@ k_gauss_correct_fast(CorrectArgs a) {
             dt01 = g.t[0] - g.t[1];
             dt21 = g.t[2] - g.t[1];
             st.epoch = 0.0; st.it = 0;
-            st.has01 = true; st.chi01 = a.W.psi0[my];
-            st.has21 = true; st.chi21 = a.W.psi0[n + my];
+            st.has01 = true; st.chi01 = W.psi0[my];
+            st.has21 = true; st.chi21 = W.psi0[n + my];
             cand = (long long)my;
           }
         }
@@ -453,23 +500,34 @@ k_gauss_correct_fast(CorrectArgs a) {
         Sinv.m[r][k] = L(9 + 3 * r + k);
         obs.m[r][k] = L(18 + 3 * r + k);
       }
-    const CorrStep step = correction_iteration<true>(obs, S, Sinv, t_mid, dt01, dt21, a.P, st);
+#if OUTFIT_KERNARG_LAZY_PARAMS
+    const KernargGaussParams<(unsigned)offsetof(CorrectArgs, P)> P;
+#else
+    const GaussParams& P = a.P;
+#endif
+    const CorrStep step = correction_iteration<true>(obs, S, Sinv, t_mid, dt01, dt21, P, st);
     const unsigned long long ucand = (unsigned long long)cand;
-    if (step == kCorrSome) {
-      a.W.state[0 * n + ucand] = st.pos.m[0][1];
-      a.W.state[1 * n + ucand] = st.pos.m[1][1];
-      a.W.state[2 * n + ucand] = st.pos.m[2][1];
-      a.W.state[3 * n + ucand] = st.vel.x;
-      a.W.state[4 * n + ucand] = st.vel.y;
-      a.W.state[5 * n + ucand] = st.vel.z;
-      a.W.state[6 * n + ucand] = st.epoch;
-      a.W.flags[ucand] = kFlagOk | kFlagCorrected;
-      cand = -1;
-    } else if (step == kCorrSlow) {
-      // None inside the loop (eccentricity_control rejected an iterate): the root walk continues in the general
-      // kernel, which does not replay this root's loop; kFlagSlow also selects the second RMS pass
-      a.W.flags[ucand] |= kFlagSlow | kFlagFirstNone;
-      append_slow(a.W, ucand);
+    if (step == kCorrSome || step == kCorrSlow) {
+#if OUTFIT_KERNARG_LAZY_PARAMS
+      const CandidateScratch W = kernarg_field<CandidateScratch>((unsigned)offsetof(CorrectArgs, W));
+#else
+      const CandidateScratch& W = a.W;
+#endif
+      if (step == kCorrSome) {
+        W.state[0 * n + ucand] = st.pos.m[0][1];
+        W.state[1 * n + ucand] = st.pos.m[1][1];
+        W.state[2 * n + ucand] = st.pos.m[2][1];
+        W.state[3 * n + ucand] = st.vel.x;
+        W.state[4 * n + ucand] = st.vel.y;
+        W.state[5 * n + ucand] = st.vel.z;
+        W.state[6 * n + ucand] = st.epoch;
+        W.flags[ucand] = kFlagOk | kFlagCorrected;
+      } else {
+        // None inside the loop (eccentricity_control rejected an iterate): the root walk continues in the general
+        // kernel, which does not replay this root's loop; kFlagSlow also selects the second RMS pass
+        W.flags[ucand] |= kFlagSlow | kFlagFirstNone;
+        append_slow(W, ucand);
+      }
       cand = -1;
     }
   }

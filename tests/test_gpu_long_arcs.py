@@ -116,8 +116,13 @@ def test_wave_form_of_k0_equals_the_lane_form(case, monkeypatch):
         monkeypatch.setenv("OUTFIT_K0_WAVE_MIN", "3")
         rec_wave, sc_wave = _run(batch, ephem, params)
         assert rec_lane.tobytes() == rec_wave.tobytes(), label
-        for a, b in zip(sc_lane, sc_wave):
-            assert a.tobytes() == b.tobytes(), label     # NaN-safe: byte comparison
+        (sum_l, win_l, fl_l), (sum_w, win_w, fl_w) = sc_lane, sc_wave
+        assert np.array_equal(fl_l, fl_w), label         # every candidate's flags (written for every slot)
+        # kernels.h: 0x10 a preliminary orbit exists, bits 8-10 conversion error, 0x80 an ephemeris_error failed,
+        # 0x80000000 empty slot — the score of the others is never written (stale scratch)
+        scored = ((fl_l & 0x10) != 0) & ((fl_l >> 8 & 0x7) == 0) & ((fl_l & 0x80) == 0) & ((fl_l & 0x80000000) == 0)
+        assert np.array_equal(win_l[scored], win_w[scored]), label
+        assert sum_l[scored].tobytes() == sum_w[scored].tobytes(), label     # NaN-safe: byte comparison
         monkeypatch.delenv("OUTFIT_K0_WAVE_MIN")
         rec_auto, _ = _run(batch, ephem, params)       # the host's own choice (wave form from 48 reduced epochs on)
         assert rec_auto.tobytes() == rec_lane.tobytes(), label
