@@ -655,7 +655,10 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
     // Long trajectories go to the wave-per-trajectory form of K0 (device/triplets.hpp): from 48 reduced epochs on
     // (C(48,3) = 17 296 scored triplets) one lane's chain is longer than a whole small batch's other kernels; the
     // bench cadence (20 epochs) stays with the lane form. LDS per wave: epochs + heap (weight, 64-bit id).
-    unsigned wave_min = 48;
+    // A SMALL batch takes the wave form whatever the length: with <= 4096 trajectories every wave is resident at once and
+    // a trajectory's selection is as long as ITS chain (64 triplets scored per step, heap operations only for the
+    // survivors), not as long as one lane's walk over all C(n,3) — what an isolated run or a blocking call waits for.
+    unsigned wave_min = s->n_traj <= 4096 ? 3 : 48;
     if (const char* e = std::getenv("OUTFIT_K0_WAVE_MIN")) {  // testing / measurement aid: 3 = every trajectory, 0 = never
       const long long v = std::atoll(e);
       if (v >= 0) wave_min = (unsigned)std::min<long long>(v, 1ll << 30);

@@ -348,7 +348,18 @@ enum CorrStep { kCorrContinue = 0, kCorrSome = 1, kCorrNone = 2, kCorrSlow = 3 }
 // never needed again), so the correctly-rounded cold-start code stays out of the loop body.
 // Params: GaussParams, or a type with the same field names whose fields convert to their values where they are read
 // (kernels.hip KernargGaussParams: parameters re-read from the kernarg segment instead of being held in SGPRs).
-template <bool kFast, bool kWarmOnly = kFast, class Params = GaussParams>
+//
+// kPair: LANE-PAIR form for small batches, where a candidate's chain — not the device's throughput — is what the run
+// waits for. Lanes 2k and 2k+1 hold the SAME candidate and the same state; each runs ONE of the two independent
+// Lagrange corrections (even lane: t1 <- t2, odd lane: t3 <- t2), the two exchange their (v, f, g, chi) through the
+// quad permute, and both evaluate the identical tail. Every operation is the one the single-lane form performs, on the
+// same operands: same bits. The iteration's chain loses one of its two universal-Kepler solves (~ a quarter of it).
+__device__ __forceinline__ double pair_swap(double x) {  // the partner lane's x (lanes 2k <-> 2k+1)
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), 0xB1, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+template <bool kFast, bool kWarmOnly = kFast, class Params = GaussParams, bool kPair = false>
 __device__ __forceinline__ CorrStep correction_iteration(const Mat3& obs, const Mat3& S, const Mat3& Sinv,
                                                          double t_mid, double dt01, double dt21,
                                                          const Params& P, CorrectionState& st) {
@@ -368,6 +379,22 @@ __device__ __forceinline__ CorrStep correction_iteration(const Mat3& obs, const 
   // the two Lagrange corrections (t1<-t2 and t3<-t2) are independent; a rolled loop keeps ONE
   // copy of the universal-Kepler solver in the instruction stream
   VelCorr a, b;
+  if constexpr (kPair) {
+    const bool odd = (__lane_id() & 1u) != 0u;
+    const double dt = odd ? dt21 : dt01;
+    const double chi = odd ? st.chi21 : st.chi01;
+    const KeplerProblem p = velocity_problem(st.vc, dt, P.kepler_eps, P.math_mode);
+    const KeplerSolution sol = kWarmOnly ? run_newton(p, chi) : solve_kepuni(p, odd ? st.has21 : st.has01, chi);
+    const Vec3 x1 = {odd ? r3.x : r1.x, odd ? r3.y : r1.y, odd ? r3.z : r1.z};
+    VelCorr mine = velocity_finish(sol, x1, r2, st.vc.r2, dt);
+    if (!mine.ok) { mine.v = {0.0, 0.0, 0.0}; mine.f = mine.g = mine.chi = 0.0; }  // defined values to exchange
+    VelCorr other;
+    other.ok = __builtin_amdgcn_mov_dpp((int)mine.ok, 0xB1, 0xF, 0xF, false) != 0;
+    other.v = {pair_swap(mine.v.x), pair_swap(mine.v.y), pair_swap(mine.v.z)};
+    other.f = pair_swap(mine.f); other.g = pair_swap(mine.g); other.chi = pair_swap(mine.chi);
+    a = odd ? other : mine;
+    b = odd ? mine : other;
+  } else {
 #pragma unroll 1
   for (int side = 0; side < 2; ++side) {
     const double dt = side ? dt21 : dt01;
@@ -379,6 +406,7 @@ __device__ __forceinline__ CorrStep correction_iteration(const Mat3& obs, const 
 #endif
     const VelCorr vc = velocity_finish(sol, side ? r3 : r1, r2, st.vc.r2, dt);
     if (side) b = vc; else a = vc;
+  }
   }
   KSTAT(4);
   if (!(a.ok && b.ok)) return rare;

@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <cstddef>
 #include <cstdio>
+#include <type_traits>
 #include <cstdlib>
 #include "kernels.h"
 #include "device/ephem.hpp"
@@ -365,6 +366,21 @@ k_gauss_roots(RootsArgs a) {
 #define OUTFIT_K2B_THRESHOLD 24  // measured (round 3, 100 000 objects): 8 -> 7.48 ms, 16 -> 6.64, 24 -> 6.50, 32 -> 6.57
 #endif
 constexpr unsigned kRefillThreshold = OUTFIT_K2B_THRESHOLD;  // idle lanes per wave before the queue is touched
+#ifndef OUTFIT_PAIR_MAX_CANDIDATES
+#define OUTFIT_PAIR_MAX_CANDIDATES (1u << 17)
+#endif
+// up to this many candidates in a chunk the correction kernels run in the lane-pair form (0 = never): 2 x 131 072 lanes
+// = 4 096 waves, about what the fast kernel keeps resident (3 per SIMD) — beyond it the lanes are better spent on
+// candidates than on halves of candidates
+constexpr unsigned long long kPairMaxCandidates = OUTFIT_PAIR_MAX_CANDIDATES;
+// OUTFIT_PAIR_MODE=0 / 1 forces the form whatever the batch size (testing aid: the two forms must give the same bytes)
+static bool use_pair_form(unsigned long long n_cand) {
+  if (const char* e = std::getenv("OUTFIT_PAIR_MODE")) {
+    if (e[0] == '0') return false;
+    if (e[0] == '1') return true;
+  }
+  return n_cand <= kPairMaxCandidates;
+}
 
 // The kernel's own argument block, re-read from the kernarg segment at the point of use. The persistent kernels hold
 // ~35 pointers and sizes (CandidateIndex, CandidateScratch) that only their REFILL path needs; kept live across the
@@ -384,8 +400,12 @@ __device__ __forceinline__ T kernarg_field(unsigned offset) {
 #ifndef OUTFIT_KERNARG_RELOAD       // the refill path's pointers (CandidateIndex, CandidateScratch) re-read at the refill
 #define OUTFIT_KERNARG_RELOAD 1
 #endif
+// Measured (round 4, 100 000 objects, three runs): spilled SGPRs 97 -> 48 with the refill reload, -> 26 with the lazy
+// parameters as well; k_gauss_correct_fast 6.51-6.60 ms without either, 6.51 with the reload, 6.65-6.71 with both — a
+// v_readlane costs no more than the s_load + wait that replaces it. The reload is kept (not slower, half the spills), the
+// lazy parameters are off.
 #ifndef OUTFIT_KERNARG_LAZY_PARAMS  // GaussParams fields and the result pointers re-read where they are used
-#define OUTFIT_KERNARG_LAZY_PARAMS 1
+#define OUTFIT_KERNARG_LAZY_PARAMS 0
 #endif
 // GaussParams of a kernel whose argument struct holds it at byte `kOff`, every field read from the kernarg segment where
 // it is used (an s_load on the scalar memory path, not a v_readlane on the VALU): same field names as GaussParams,
@@ -415,6 +435,19 @@ __device__ __forceinline__ unsigned long long wave_grab(unsigned long long* queu
   return base + (unsigned long long)__popcll(need_mask & ((1ull << lane) - 1ull));
 }
 
+// lane-pair form (gauss.hpp, correction_iteration<.., kPair>): lanes 2k and 2k+1 take the SAME queue entry; needy lanes
+// always come in pairs (both lanes of a pair finish together), so the pair's index is half the even lane's rank
+__device__ __forceinline__ unsigned long long wave_grab_pairs(unsigned long long* queue, unsigned long long need_mask) {
+  const unsigned lane = __lane_id();
+  const unsigned leader = (unsigned)__ffsll((long long)need_mask) - 1u;
+  unsigned long long base = 0;
+  if (lane == leader) base = atomicAdd(queue, (unsigned long long)(__popcll(need_mask) / 2));
+  base = __shfl(base, (int)leader);
+  return base + (unsigned long long)(__popcll(need_mask & ((1ull << lane) - 1ull)) / 2);
+}
+
+// kPair: two lanes per candidate, one Lagrange correction each (small batches: the launcher chooses)
+template <bool kPair>
 __global__ void __launch_bounds__(kFastBlock, kFastWavesPerSimd)
 k_gauss_correct_fast(CorrectArgs a) {
   extern __shared__ double lds[];  // [27][kFastBlock]: S, S^-1, observer matrix
@@ -443,7 +476,7 @@ k_gauss_correct_fast(CorrectArgs a) {
       const unsigned long long st_r0 = clock64();
       st_refills += 1; st_needy += (unsigned)__popcll(need_mask);
 #endif
-      const unsigned long long my = wave_grab(a.queue, need_mask);
+      const unsigned long long my = kPair ? wave_grab_pairs(a.queue, need_mask) : wave_grab(a.queue, need_mask);
       if (needy) {
         if (my >= n) {
           exhausted = true;
@@ -505,7 +538,8 @@ k_gauss_correct_fast(CorrectArgs a) {
 #else
     const GaussParams& P = a.P;
 #endif
-    const CorrStep step = correction_iteration<true>(obs, S, Sinv, t_mid, dt01, dt21, P, st);
+    const CorrStep step = correction_iteration<true, true, std::remove_cv_t<std::remove_reference_t<decltype(P)>>, kPair>(
+        obs, S, Sinv, t_mid, dt01, dt21, P, st);
     const unsigned long long ucand = (unsigned long long)cand;
     if (step == kCorrSome || step == kCorrSlow) {
 #if OUTFIT_KERNARG_LAZY_PARAMS
@@ -513,7 +547,9 @@ k_gauss_correct_fast(CorrectArgs a) {
 #else
       const CandidateScratch& W = a.W;
 #endif
-      if (step == kCorrSome) {
+      const bool writer = !kPair || (tid & 1u) == 0u;  // lane-pair form: both lanes hold the same result
+      if (!writer) {
+      } else if (step == kCorrSome) {
         W.state[0 * n + ucand] = st.pos.m[0][1];
         W.state[1 * n + ucand] = st.pos.m[1][1];
         W.state[2 * n + ucand] = st.pos.m[2][1];
@@ -550,7 +586,7 @@ k_gauss_correct_fast(CorrectArgs a) {
 // is the floor of the run; 3 = 168 VGPRs (+120 spilled): beside K2c, whose waves hold 3 x 154 of a SIMD's 512 registers, a
 // 256-register wave practically never finds room (measured: 3.4 ms beside a 3.0 ms K2c for 0.45 ms of work, i.e. K3 waited
 // for it), a 168-register one does as soon as one K2c wave retires (0.5 ms, hidden).
-template <int kWaves>
+template <int kWaves, bool kPair = false>  // kPair: the lane-pair form (gauss.hpp), small batches
 __global__ void __launch_bounds__(kCorrectBlock, kWaves)
 k_gauss_correct(CorrectArgs a) {
   extern __shared__ double lds[];  // [kCorrectLdsDoubles][kCorrectBlock]
@@ -565,8 +601,11 @@ k_gauss_correct(CorrectArgs a) {
   // which is what a small batch waits for. `quota` lanes per wave take work (64 when the list is long).
   const unsigned long long n_waves = (unsigned long long)gridDim.x * (bs / 64u);
   const unsigned long long per_wave = (n_items + n_waves - 1) / n_waves;
-  const unsigned quota = per_wave >= 64ull ? 64u : (per_wave < 1ull ? 1u : (unsigned)per_wave);
-  const unsigned refill_at = quota >= 4u * kRefillThreshold ? kRefillThreshold : (quota + 3u) / 4u;
+  constexpr unsigned kLanesPer = kPair ? 2u : 1u;     // lanes per candidate
+  constexpr unsigned kSlots = 64u / kLanesPer;        // candidates a wave can hold
+  const unsigned quota_c = per_wave >= kSlots ? kSlots : (per_wave < 1ull ? 1u : (unsigned)per_wave);
+  const unsigned quota = quota_c * kLanesPer;         // lanes of a wave that take work
+  const unsigned refill_at = quota >= 4u * kRefillThreshold ? kRefillThreshold : (quota_c + 3u) / 4u * kLanesPer;
 
   long long cand = -1;
   bool exhausted = (tid % 64u) >= quota, need_init = false, have_prelim = false, resume = false;
@@ -580,7 +619,7 @@ k_gauss_correct(CorrectArgs a) {
     const unsigned long long need_mask = __ballot(needy);
     const unsigned long long active_mask = __ballot(cand >= 0);
     if (need_mask && ((unsigned)__popcll(need_mask) >= refill_at || active_mask == 0ull)) {
-      const unsigned long long my = wave_grab(a.queue, need_mask);
+      const unsigned long long my = kPair ? wave_grab_pairs(a.queue, need_mask) : wave_grab(a.queue, need_mask);
       if (needy) {
         if (my >= n_items) {
           exhausted = true;
@@ -639,8 +678,16 @@ k_gauss_correct(CorrectArgs a) {
           // loop body below is the warm iteration only
           st.chi01 = st.chi21 = 0.0;
           if (st.vc.ok && !resume) {
-            st.chi01 = prelim_kepuni(velocity_problem(st.vc, dt01, a.P.kepler_eps, a.P.math_mode));
-            st.chi21 = prelim_kepuni(velocity_problem(st.vc, dt21, a.P.kepler_eps, a.P.math_mode));
+            if constexpr (kPair) {  // one cold start per lane of the pair, exchanged
+              const bool odd = (tid & 1u) != 0u;
+              const double mine = prelim_kepuni(velocity_problem(st.vc, odd ? dt21 : dt01, a.P.kepler_eps, a.P.math_mode));
+              const double other = pair_swap(mine);
+              st.chi01 = odd ? other : mine;
+              st.chi21 = odd ? mine : other;
+            } else {
+              st.chi01 = prelim_kepuni(velocity_problem(st.vc, dt01, a.P.kepler_eps, a.P.math_mode));
+              st.chi21 = prelim_kepuni(velocity_problem(st.vc, dt21, a.P.kepler_eps, a.P.math_mode));
+            }
           }
           break;
         }
@@ -652,10 +699,12 @@ k_gauss_correct(CorrectArgs a) {
       else if (fabs(dt01) <= kEps || fabs(dt21) <= kEps) step = kCorrNone;  // gauss.rs:1311-1313
       resume = false;
     } else {
-      step = correction_iteration<false, true>(obs, S, Sinv, t_mid, dt01, dt21, a.P, st);
+      step = correction_iteration<false, true, GaussParams, kPair>(obs, S, Sinv, t_mid, dt01, dt21, a.P, st);
     }
     const unsigned long long ucand = (unsigned long long)cand;
+    const bool writer = !kPair || (tid & 1u) == 0u;  // lane-pair form: both lanes hold the same result
     if (step == kCorrSome) {
+      if (writer) {
       a.W.state[0 * n + ucand] = st.pos.m[0][1];
       a.W.state[1 * n + ucand] = st.pos.m[1][1];
       a.W.state[2 * n + ucand] = st.pos.m[2][1];
@@ -664,12 +713,15 @@ k_gauss_correct(CorrectArgs a) {
       a.W.state[5 * n + ucand] = st.vel.z;
       a.W.state[6 * n + ucand] = st.epoch;
       a.W.flags[ucand] = kFlagOk | kFlagCorrected | kFlagSlow;
+      }
       cand = -1;
     } else if (step == kCorrNone) {
       if (!have_prelim) {  // the first PrelimOrbit is the fallback (gauss.rs:1245-1246)
         have_prelim = true;
+        if (writer) {
 #pragma unroll
-        for (unsigned k = 0; k < 7; ++k) a.W.state[(unsigned long long)k * n + ucand] = L(27 + k);
+          for (unsigned k = 0; k < 7; ++k) a.W.state[(unsigned long long)k * n + ucand] = L(27 + k);
+        }
       }
       ++pushes;
       ++slot;
@@ -677,7 +729,7 @@ k_gauss_correct(CorrectArgs a) {
       else need_init = true;
     }
     if (finished) {
-      a.W.flags[ucand] = have_prelim ? (kFlagOk | kFlagSlow) : (unsigned)kCauseNoRoots;
+      if (writer) a.W.flags[ucand] = have_prelim ? (kFlagOk | kFlagSlow) : (unsigned)kCauseNoRoots;
       cand = -1;
     }
   }
@@ -1590,8 +1642,11 @@ hipError_t launch_gauss_correct_fast(const CorrectArgs& a, unsigned n_cu, hipStr
   if (a.I.n_cand == 0) return hipSuccess;
   // persistent grid sized by residency (LDS: 27 doubles per lane; kFastWavesPerSimd waves per
   // SIMD), never more workgroups than there is work; every wave exits once the queue is drained
+  // small batch: two lanes per candidate (lane-pair form) — twice the lanes, each candidate's chain ~ a quarter shorter
+  const bool pair = use_pair_form(a.I.n_cand);
   const unsigned long long per_cu = (4ull * kFastWavesPerSimd * 64ull) / kFastBlock;
-  const unsigned long long want = (a.I.n_cand + kFastBlock - 1) / kFastBlock;
+  const unsigned long long lanes = pair ? 2ull * a.I.n_cand : a.I.n_cand;
+  const unsigned long long want = (lanes + kFastBlock - 1) / kFastBlock;
   const unsigned grid = (unsigned)(want < per_cu * n_cu ? want : per_cu * n_cu);
   const size_t lds = (size_t)27 * kFastBlock * sizeof(double);
   hipError_t e = hipMemsetAsync(a.queue, 0, sizeof(unsigned long long), s);
@@ -1605,7 +1660,8 @@ hipError_t launch_gauss_correct_fast(const CorrectArgs& a, unsigned n_cu, hipStr
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_kstat), zero, sizeof zero);
   }
 #endif
-  hipLaunchKernelGGL(k_gauss_correct_fast, dim3(grid), dim3(kFastBlock), lds, s, a);
+  if (pair) hipLaunchKernelGGL(k_gauss_correct_fast<true>, dim3(grid), dim3(kFastBlock), lds, s, a);
+  else hipLaunchKernelGGL(k_gauss_correct_fast<false>, dim3(grid), dim3(kFastBlock), lds, s, a);
 #ifdef OUTFIT_K2B_STATS
   {
     unsigned long long h[8] = {};
@@ -1642,6 +1698,7 @@ hipError_t launch_gauss_correct(const CorrectArgs& a, unsigned n_cu, hipStream_t
   hipError_t e = hipMemsetAsync(a.queue, 0, sizeof(unsigned long long), s);
   if (e != hipSuccess) return e;
   if (a.I.n_cand >= (1ull << 20)) hipLaunchKernelGGL(k_gauss_correct<3>, dim3(grid), dim3(kCorrectBlock), lds, s, a);
+  else if (use_pair_form(a.I.n_cand)) hipLaunchKernelGGL((k_gauss_correct<2, true>), dim3(grid), dim3(kCorrectBlock), lds, s, a);
   else hipLaunchKernelGGL(k_gauss_correct<2>, dim3(grid), dim3(kCorrectBlock), lds, s, a);
   return hipGetLastError();
 }

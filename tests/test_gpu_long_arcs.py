@@ -145,7 +145,8 @@ def test_mixed_batch_uses_both_forms():
                 parts[k].append(ds[k][lo * n:hi * n])
             helio.append(ds["obs_helio_equ"][3 * lo * n:3 * hi * n])
             geo.append(ds["obs_geo_ecl"][3 * lo * n:3 * hi * n])
-            off.extend(off[-1] + n * (i + 1) for i in range(hi - lo))
+            base = off[-1]
+            off.extend(base + n * (i + 1) for i in range(hi - lo))
     batch = outfit_amd.ObsBatch(np.array(off, dtype=np.uint64), *[np.concatenate(parts[k]) for k in cols],
                                 np.concatenate(helio), np.concatenate(geo))
     ephem = outfit_amd.Ephemeris.from_dict(e)

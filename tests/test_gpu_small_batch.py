@@ -1,0 +1,77 @@
+"""Forms of the correction kernels chosen by batch size — needs an MI355X.
+
+Up to 131 072 candidates per chunk the two correction kernels run in the LANE-PAIR form (device/gauss.hpp,
+`correction_iteration<.., kPair>`): two lanes hold one candidate, each runs one of the two independent Lagrange
+corrections of an iteration (gauss.rs:1325-1344), they exchange (v, f, g, chi) and evaluate the same tail — a shorter
+chain per candidate, which is what a small batch waits for. The operations and their operands are those of the one-lane
+form, so the two forms must return the same bytes; OUTFIT_PAIR_MODE=0 / 1 (read by the launchers) forces either.
+The suite's small parity tests run the pair form by default (they are below the threshold) against the oracle, the
+large ones the one-lane form; here the two forms are held against each other on the same batches, on both sides of
+the threshold, including parameter sets that send many candidates through the general kernel's root walk.
+"""
+import numpy as np
+import pytest
+
+import outfit_amd
+from outfit_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(batch, ephem, params, monkeypatch, pair):
+    if pair is None:
+        monkeypatch.delenv("OUTFIT_PAIR_MODE", raising=False)
+    else:
+        monkeypatch.setenv("OUTFIT_PAIR_MODE", "1" if pair else "0")
+    s = outfit_amd.IODSession(batch, ephem, params)
+    s.run()
+    rec = s.results()
+    total, n_win, flags = s.candidate_scores()
+    s.close()
+    return rec, total, n_win, flags
+
+
+def _same(a, b):
+    rec_a, sum_a, win_a, fl_a = a
+    rec_b, sum_b, win_b, fl_b = b
+    assert rec_a.tobytes() == rec_b.tobytes()
+    assert np.array_equal(fl_a, fl_b)
+    scored = ((fl_a & 0x10) != 0) & ((fl_a >> 8 & 0x7) == 0) & ((fl_a & 0x80) == 0) & ((fl_a & 0x80000000) == 0)
+    assert np.array_equal(win_a[scored], win_b[scored]) and sum_a[scored].tobytes() == sum_b[scored].tobytes()
+
+
+PARAM_SETS = [
+    {},
+    dict(max_tested_solutions=1),
+    dict(max_ecc=0.35, max_perihelion_au=3.5),                                   # None inside the loop: hand-over, root walk
+    dict(max_ecc=0.35, max_perihelion_au=3.5, max_tested_solutions=2, newton_max_it=7),
+]
+
+
+@pytest.mark.usefixtures("device_math_mode")
+@pytest.mark.parametrize("kw", PARAM_SETS, ids=lambda kw: ",".join(f"{k}={v}" for k, v in kw.items()) or "bench")
+def test_lane_pair_form_equals_the_one_lane_form(kw, monkeypatch):
+    e = synth.make_ephemeris()
+    ephem = outfit_amd.Ephemeris.from_dict(e)
+    for n, seed, extra in ((1000, 5, {}), (2600, 6, {"topocentric": True})):   # 100 000 (pair by default) and 260 000 candidates
+        batch = outfit_amd.ObsBatch.from_dict(synth.make_dataset(n, seed=seed, ephem=e, **extra))
+        params = synth.bench_params(outfit_amd.IODParams())
+        for k, v in kw.items():
+            setattr(params, k, v)
+        one = _run(batch, ephem, params, monkeypatch, False)
+        two = _run(batch, ephem, params, monkeypatch, True)
+        auto = _run(batch, ephem, params, monkeypatch, None)
+        _same(one, two)
+        _same(one, auto)
+        assert (one[0]["status"] == 0).sum() > 0.8 * n
+
+
+def test_lane_pair_form_with_noisy_realisations(monkeypatch):
+    """IODParams::default(): 10 triplets x 21 realisations, host-drawn normals (the direction matrix of a noisy candidate
+    comes from the per-candidate scratch, not from K1's table)."""
+    e = synth.make_ephemeris()
+    ds = synth.make_dataset(500, seed=77, ephem=e)
+    params = outfit_amd.IODParams()
+    ds["noise_z"] = synth.SplitMix64(9).normal(500 * params.max_triplets * params.n_noise_realizations * 6)
+    batch, ephem = outfit_amd.ObsBatch.from_dict(ds), outfit_amd.Ephemeris.from_dict(e)
+    _same(_run(batch, ephem, params, monkeypatch, False), _run(batch, ephem, params, monkeypatch, True))

@@ -1,8 +1,10 @@
 """GPU box: the device in OUTFIT_MATH_GLIBC mode against the oracle in platform-libm mode (= the reference's
 arithmetic on this host's glibc) on a LARGE batch — statistics for DESIGN.md §4.0. Also the default mode against the
 same, and the glibc mode against the oracle's restated mode (must be bit-identical).
-usage: parity_glibc_at_scale.py [n_objects] [seed] [bench|topo|noise]  -> gpurun_out/parity_glibc_<mode>_<n>.json
-(noise: IODParams::default() — 10 triplets x 21 realisations, host-drawn normals, SURVEY 8(d)'s second point)"""
+usage: parity_glibc_at_scale.py [n_objects] [seed] [bench|topo|noise|long100|long300]  -> gpurun_out/parity_glibc_<mode>_<n>.json
+(noise: IODParams::default() — 10 triplets x 21 realisations, host-drawn normals, SURVEY 8(d)'s second point;
+long100 / long300: trajectories of 100 / 300 observations (synth.make_long_arc_dataset) under IODParams::default() with
+noise — the wave-per-trajectory K0, down-sampling and quirk Q1, RMS windows over the whole arc)"""
 import ctypes as C
 import json
 import os
@@ -21,12 +23,17 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 20261005
 mode = sys.argv[3] if len(sys.argv) > 3 else "bench"
 threads = len(os.sched_getaffinity(0))
-ed = synth.make_ephemeris()
-ds = synth.make_dataset(n, seed=seed, ephem=ed, topocentric=(mode == "topo"))
+if mode.startswith("long"):
+    ds = synth.make_long_arc_dataset(n, int(mode[4:]), seed=seed)
+    ed = ds["ephem"]
+else:
+    ed = synth.make_ephemeris()
+    ds = synth.make_dataset(n, seed=seed, ephem=ed, topocentric=(mode == "topo"))
 batch, ephem = outfit_amd.ObsBatch.from_dict(ds), outfit_amd.Ephemeris.from_dict(ed)
-params = outfit_amd.IODParams() if mode == "noise" else synth.bench_params(outfit_amd.IODParams())
+noisy = mode == "noise" or mode.startswith("long")
+params = outfit_amd.IODParams() if noisy else synth.bench_params(outfit_amd.IODParams())
 per_traj = params.max_triplets * params.n_noise_realizations * 6
-if mode == "noise":
+if noisy:
     batch.noise_z = np.random.default_rng(seed).standard_normal(n * per_traj)
 L = O.lib()
 
@@ -40,7 +47,7 @@ def oracle(libm, glibc):
         for i in range(0, n, 10000):
             j = min(n, i + 10000)
             sub = batch.slice(i, j)
-            if mode == "noise":
+            if noisy:
                 sub.noise_z = batch.noise_z[i * per_traj: j * per_traj]
             rc, ref[i:j] = O.fit_full_iod(params.as_c(), sub.as_c(), ephem.as_c(), n_threads=threads, hoist=1)
             assert rc == 0
@@ -71,7 +78,8 @@ dev_g = outfit_amd.fit_full_iod_records(batch, ephem, params, n_devices=1, math_
 dev_c = outfit_amd.fit_full_iod_records(batch, ephem, params, n_devices=1, math_mode=outfit_amd.MATH_CORRECTLY_ROUNDED)
 ref_libm = oracle(1, 0)
 ref_rest = oracle(0, 1)
-out = {"objects": n, "seed": seed, "mode": mode, "glibc": os.confstr("CS_GNU_LIBC_VERSION"),
+from outfit_amd import libm_pin  # noqa: E402
+out = {"objects": n, "seed": seed, "mode": mode, "glibc": os.confstr("CS_GNU_LIBC_VERSION"), "host_libm": libm_pin.describe(),
        "device_glibc_vs_oracle_libm": distance(dev_g, ref_libm),
        "device_cr_vs_oracle_libm": distance(dev_c, ref_libm),
        "device_glibc_vs_oracle_restated": distance(dev_g, ref_rest)}
