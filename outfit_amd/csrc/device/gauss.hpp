@@ -192,6 +192,78 @@ __device__ __forceinline__ int aberth_deg8(double c0, double c3, double c6, unsi
   return 1;
 }
 
+// The same iteration with ONE ROOT PER LANE (north_star's "8 lanes <-> 8 roots"): eight consecutive lanes hold the eight
+// iterates of one polynomial. A sweep is Jacobi (every root from the previous sweep's iterates, see above), so the
+// eight updates are independent: each lane gathers the group's iterates, forms ITS sum of 1/(z_i - z_k) over k
+// ascending (the crate's literal form: plain divisions, no symmetry trick), its Horner pair and its update; the
+// group then agrees on failed / converged through a ballot. A candidate's chain is one root's work per sweep instead
+// of eight: the form for small batches, where the chain is what the run waits for (the lane-per-candidate form above
+// issues half the divisions and is the one for throughput). Same operations on the same operands: same bits
+// (tests/test_gpu_small_batch.py holds the two forms against each other). `z` = this lane's root (index lane & 7).
+// Returns 0 converged / 1 max-iteration / 2 failed, uniform over the group.
+__device__ __forceinline__ int aberth_deg8_lanes(double c0, double c3, double c6, unsigned max_iter, double eps, Cx& z) {
+  const unsigned lane = __lane_id(), r = lane & 7u, base = lane & ~7u;
+  const double a6 = -fabs(c6), a3 = -fabs(c3), a0 = -fabs(c0);
+  double r0 = 1.0;
+  for (int guard = 0; guard < 4096; ++guard) {
+    double re = 1.0;
+    re = fma(re, r0, 0.0);
+    re = fma(re, r0, a6);
+    re = fma(re, r0, 0.0);
+    re = fma(re, r0, 0.0);
+    re = fma(re, r0, a3);
+    re = fma(re, r0, 0.0);
+    re = fma(re, r0, 0.0);
+    re = fma(re, r0, a0);
+    if (re > 0.0) break;
+    r0 += 1.0;
+  }
+  {
+    double s, c;
+    crm::aberth_dir((int)r, c, s);
+    z = {fma(r0, c, -0.0), r0 * s};
+  }
+  const double c6x6 = 6.0 * c6, c3x3 = 3.0 * c3;
+  for (unsigned it = 1; it <= max_iter; ++it) {
+    Cx sum = {0.0, 0.0};
+#pragma unroll
+    for (unsigned k = 0; k < 8; ++k) {
+      const Cx zk = {__shfl(z.re, (int)(base + k)), __shfl(z.im, (int)(base + k))};
+      const Cx w = cdiv({1.0, 0.0}, csub(z, zk));  // 1/(z_i - z_k); for k == i a division by zero, discarded
+      const Cx added = cadd(sum, w);
+      if (k != r) sum = added;
+    }
+    const Cx zi = z;
+    Cx p = {1.0, 0.0};
+    p = cmul_add_real(p, zi, 0.0);
+    p = cmul_add_real(p, zi, c6);
+    p = cmul_add_real(p, zi, 0.0);
+    p = cmul_add_real(p, zi, 0.0);
+    p = cmul_add_real(p, zi, c3);
+    p = cmul_add_real(p, zi, 0.0);
+    p = cmul_add_real(p, zi, 0.0);
+    p = cmul_add_real(p, zi, c0);
+    Cx dp = {8.0, 0.0};
+    dp = cmul_add_real(dp, zi, 0.0);
+    dp = cmul_add_real(dp, zi, c6x6);
+    dp = cmul_add_real(dp, zi, 0.0);
+    dp = cmul_add_real(dp, zi, 0.0);
+    dp = cmul_add_real(dp, zi, c3x3);
+    dp = cmul_add_real(dp, zi, 0.0);
+    dp = cmul_add_real(dp, zi, 0.0);
+    const Cx den = csub(cmul(p, sum), dp);
+    const Cx zn = cadd(zi, cdiv(p, den));
+    z = zn;
+    const bool bad = isnan(zn.re) || isnan(zn.im) || isinf(zn.re) || isinf(zn.im);
+    const bool moved = !(fabs(zn.re - zi.re) < eps && fabs(zn.im - zi.im) < eps);
+    const unsigned any_bad = (unsigned)(__ballot(bad) >> base) & 0xFFu;
+    const unsigned any_moved = (unsigned)(__ballot(moved) >> base) & 0xFFu;
+    if (any_bad) return 2;
+    if (!any_moved) return 0;
+  }
+  return 1;
+}
+
 struct GaussTimes {
   double t[3];
 };

@@ -265,6 +265,32 @@ __device__ __forceinline__ CandidateGeometry load_geometry(const CandidateIndex&
 // ------------------------------------------------------------------------------
 // K2a: direction matrix, 8th-degree polynomial, Aberth roots, root filter
 // ------------------------------------------------------------------------------
+// S (direction matrix), epochs and observer matrix of a candidate as K2a takes them: the noise-free columns from K1's
+// table, a noisy realisation's from its own angles
+struct CandidateGeometryInputs {
+  Mat3 S, obs;
+  double t[3];
+};
+template <class Args>
+__device__ __forceinline__ CandidateGeometryInputs gather_inputs(const Args& a, const CandidateRef& c) {
+  CandidateGeometryInputs g;
+  if (c.r == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const unsigned long long o = c.base + c.idx[k];
+      g.S.m[0][k] = a.I.unit[o];
+      g.S.m[1][k] = a.I.unit[a.I.n_obs_total + o];
+      g.S.m[2][k] = a.I.unit[2 * a.I.n_obs_total + o];
+    }
+  } else {
+    double ra[3], dec[3];
+    gather_angles(a.I, c, ra, dec);
+    g.S = unit_matrix(ra, dec, a.P.math_mode);
+  }
+  gather_times_observer(a.I, c, g.t, g.obs);
+  return g;
+}
+
 #ifndef OUTFIT_ROOTS_WAVES
 #define OUTFIT_ROOTS_WAVES 4
 #endif
@@ -354,6 +380,66 @@ k_gauss_roots(RootsArgs a) {
   }
   a.W.flags[cid] = kFlagOk | (nf << kFlagRootsShift) | (slot << kFlagFirstShift) | (slow ? kFlagSlow : 0u);
   if (slow) append_slow(a.W, cid);
+}
+
+// K2a, root-per-lane form (small batches): eight consecutive lanes per candidate, one Aberth iterate each
+// (gauss.hpp aberth_deg8_lanes). Everything else of k_gauss_roots is evaluated by the group's lanes redundantly (same
+// inputs, same values), the root filter compacts through a ballot in solver order, lanes 0 and 1 of a group take one
+// cold start each. Writes exactly what k_gauss_roots writes.
+__global__ void __launch_bounds__(256)
+k_gauss_roots_lanes(RootsArgs a) {
+  const unsigned long long lid = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+  if (lid >= a.cand_count) return;  // whole groups leave together
+  const unsigned lane = __lane_id(), r = lane & 7u, base = lane & ~7u;
+  const unsigned long long cid = a.cand_begin + lid;
+  const CandidateRef c = decode_candidate(a.I, cid);
+  if (!c.live) { if (r == 0) a.W.flags[cid] = kFlagEmpty; return; }
+  const unsigned long long n = a.I.n_cand;
+  const CandidateGeometryInputs in = gather_inputs(a, c);
+  Mat3 S = in.S, Sinv;
+  if (c.r != 0 && r == 0) {
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) a.W.S[(unsigned long long)(3 * rr + k) * n + cid] = S.m[rr][k];
+  }
+  if (!try_inverse(S, Sinv)) { if (r == 0) a.W.flags[cid] = (unsigned)kCauseSingular; return; }
+  const GaussGeometry q = gauss_times(in.t);
+  double c6, c3, c0;
+  coeff_eight_poly(in.obs, S, Sinv, q, c6, c3, c0);
+  if (descartes_upper_bound(c0, c3, c6) == 0) { if (r == 0) a.W.flags[cid] = (unsigned)kCauseNoRoots; return; }
+  Cx z;
+  const int ab = aberth_deg8_lanes(c0, c3, c6, a.P.aberth_max_iter, a.P.aberth_eps, z);
+  if (ab == 2) { if (r == 0) a.W.flags[cid] = (unsigned)kCauseRootFinding; return; }
+  // visit_real_positive_roots + the r2 window (gauss.rs:964-986,1148): solver order = lane order within the group
+  const bool pass = z.re > 0.0 && fabs(z.im) < a.P.root_imag_eps && z.re >= a.P.r2_min_au && z.re <= a.P.r2_max_au;
+  const unsigned bits = (unsigned)(__ballot(pass) >> base) & 0xFFu;
+  const unsigned nf = (unsigned)__popc(bits);
+  if (pass) a.W.roots[(unsigned long long)__popc(bits & ((1u << r) - 1u)) * n + cid] = z.re;
+  if (nf == 0) { if (r == 0) a.W.flags[cid] = (unsigned)kCauseNoRoots; return; }
+  // first accepted root, in solver order (the roots come from their lanes, not back from memory)
+  Mat3 pos;
+  Vec3 vel;
+  double e_pre;
+  VelCommon vc;
+  unsigned slot = 0;
+  bool accepted = false;
+#pragma unroll 1
+  for (unsigned k = 0; k < 8; ++k) {
+    const double r2 = __shfl(z.re, (int)(base + k));
+    if (!((bits >> k) & 1u)) continue;
+    if (accept_root(in.obs, S, Sinv, in.t[1], q, a.P, r2, pos, vel, e_pre, vc)) { accepted = true; break; }
+    ++slot;
+  }
+  if (!accepted) { if (r == 0) a.W.flags[cid] = (unsigned)kCauseNoRoots; return; }
+  const double dt01 = in.t[0] - in.t[1], dt21 = in.t[2] - in.t[1];
+  const bool slow = !vc.ok || fabs(dt01) <= kEps || fabs(dt21) <= kEps;
+  if (!slow && r < 2u)
+    a.W.psi0[(unsigned long long)r * n + cid] = prelim_kepuni(velocity_problem(vc, r ? dt21 : dt01, a.P.kepler_eps, a.P.math_mode));
+  if (r == 0) {
+    a.W.flags[cid] = kFlagOk | (nf << kFlagRootsShift) | (slot << kFlagFirstShift) | (slow ? kFlagSlow : 0u);
+    if (slow) append_slow(a.W, cid);
+  }
 }
 
 // ------------------------------------------------------------------------------
@@ -1630,6 +1716,11 @@ hipError_t launch_observer_prepass(const PrepassArgs& a, hipStream_t s) {
 }
 hipError_t launch_gauss_roots(const RootsArgs& a, hipStream_t s) {
   if (a.cand_count == 0) return hipSuccess;
+  if (use_pair_form(a.I.n_cand)) {  // small batch: one Aberth iterate per lane, eight lanes per candidate
+    const unsigned long long lanes = a.cand_count * 8ull;
+    hipLaunchKernelGGL(k_gauss_roots_lanes, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+  }
   const unsigned grid = (unsigned)((a.cand_count + OUTFIT_ROOTS_BLOCK - 1) / OUTFIT_ROOTS_BLOCK);
   hipLaunchKernelGGL(k_gauss_roots, dim3(grid), dim3(OUTFIT_ROOTS_BLOCK), 0, s, a);
   return hipGetLastError();
