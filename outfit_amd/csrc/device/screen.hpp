@@ -27,16 +27,6 @@
 
 namespace outfit {
 
-// (sin, cos)(x) -> (sin, cos)(x + d), |d| <= 1/16
-__device__ __forceinline__ void rotate_small(double& sx, double& cx, double d, const ScreenConsts& C) {
-  const double z = d * d;
-  const double sd = fma(d * z, fma(z, fma(z, fma(z, C.s9, C.s7), C.s5), C.s3), d);
-  const double cd = fma(z, fma(z, fma(z, fma(z, C.c8, C.c6), C.c4), C.c2), 1.0);
-  const double ns = fma(sx, cd, cx * sd), nc = fma(cx, cd, -(sx * sd));
-  sx = ns;
-  cx = nc;
-}
-
 // The solution of F - k sin F + h cos F = lam carried from one observation of a candidate to the next.
 struct ScreenKepler {
   bool warm;
@@ -56,7 +46,7 @@ struct ScreenKepler {
 // rounded up to 1e-13 x 2^E rad, E in five bits of the candidate's flag word (E = 31: unbounded), and k_refine_best
 // widens that candidate's window by it (screen_slack_rad). Typical main-belt candidate: E = 2 - 3, i.e. 4 - 8e-13 rad
 // = 3 - 6e-7 of an RMS normalised by 0.3"; the screen's own roundings (Newton to 1e-16, ~1e-15 rad of drift in the
-// carried sine / cosine, 2e-16 in atan2) are < 1 % of that.
+// carried sine / cosine, <= 6e-16 in atan2: bounded per primitive by tests/test_screen_math.py on the host) are ~1 % of that.
 constexpr unsigned kFlagLevelShift = 23, kFlagLevelMask = 0x1Fu << kFlagLevelShift;
 __device__ __forceinline__ unsigned screen_level(double a, double inv_rho_max, double dmin) {
   const double x = 1.76 * a * inv_rho_max / dmin;   // bound_rad / 1e-13

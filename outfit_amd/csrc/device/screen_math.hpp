@@ -1,6 +1,8 @@
 // screen_math.hpp — the primitives of the screening arithmetic (device/screen.hpp explains what the screen is and why it may
-// be inexact): reciprocal / reciprocal square root from the hardware seeds with Newton steps, and an atan2 of ~2e-16
-// absolute error. Separate from screen.hpp because orbit.hpp's function selectors (kFnScreen) need them.
+// be inexact): reciprocal / reciprocal square root from the hardware seeds with Newton steps, and an atan2 of <= 6e-16
+// absolute error, the small-angle rotation of a (sin, cos) pair. Separate from screen.hpp because orbit.hpp's function
+// selectors (kFnScreen) need them — and so that tests/test_screen_math.py can compile exactly this file for the host
+// (hardware seeds emulated at their documented worst) and bound every primitive's error against long-double references.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -47,7 +49,17 @@ __device__ __forceinline__ void sqrt_rsqrt(double x, double& root, double& inv_r
   inv_root = ok ? 2.0 * h : 0.0;
 }
 
-// atan2(y, x) to ~2e-16 absolute; (0, 0) -> 0
+// (sin, cos)(x) -> (sin, cos)(x + d), |d| <= 1/16
+__device__ __forceinline__ void rotate_small(double& sx, double& cx, double d, const ScreenConsts& C) {
+  const double z = d * d;
+  const double sd = fma(d * z, fma(z, fma(z, fma(z, C.s9, C.s7), C.s5), C.s3), d);
+  const double cd = fma(z, fma(z, fma(z, fma(z, C.c8, C.c6), C.c4), C.c2), 1.0);
+  const double ns = fma(sx, cd, cx * sd), nc = fma(cx, cd, -(sx * sd));
+  sx = ns;
+  cx = nc;
+}
+
+// atan2(y, x) to 6e-16 absolute (2.5e-16 in the first octant; tests/test_screen_math.py); (0, 0) -> 0
 __device__ __forceinline__ double atan2_screen(double y, double x, const ScreenConsts& C) {
   const double ax = fabs(x), ay = fabs(y);
   const double mx = fmax(ax, ay), mn = fmin(ax, ay);
