@@ -1159,14 +1159,16 @@ k_select_best(SelectArgs a) {
 #define OUTFIT_CONTENDER_WINDOW 1.0e-4
 #endif
 constexpr double kContenderWindow = OUTFIT_CONTENDER_WINDOW;
-constexpr unsigned kRefineGroup = 4;                      // lanes per trajectory
-constexpr unsigned kRefineTraj = 64 / kRefineGroup;       // trajectories per wave
+// lanes per trajectory (kRefineGroup, a template parameter of the two functions below): 4 for throughput — a lane per
+// trajectory was a 45 k-instruction chain on 1.5 waves per SIMD: 1.6 ms; four lanes 0.6 ms —, 16 for small batches, where
+// the chain of the few waves there are is what the run waits for (1 000 trajectories: 0.22 -> see DESIGN.md §3).
+// The terms are added in observation order whatever the group size: same bytes.
 
 // rms_orbit_error of one candidate with the glibc-faithful functions, evaluated by the kRefineGroup lanes of a group:
 // lane `sub` takes the observations i_start + sub, + kRefineGroup, ...; the terms are then added one after the other in
 // observation order by every lane (the reference's left fold, bit for bit). NaN = the candidate cannot be selected
 // (conversion error, e >= 1, an Err of ephemeris_error). The prologue is evaluated redundantly by the lanes.
-template <int kFn>
+template <int kFn, unsigned kRefineGroup>
 __device__ __forceinline__ double exact_candidate_rms(const RmsArgs& a, unsigned long long cid, unsigned sub,
                                                       unsigned group_base) {
   const unsigned long long n = a.I.n_cand;
@@ -1214,9 +1216,12 @@ constexpr unsigned kRefineList = 256;  // contenders a wave holds between two ev
 // inject_fail: test aid (OUTFIT_TEST_EXACT_RMS_FAILS=1, read by the launcher): every exact evaluation reports an Err,
 // so that the path "the screen accepted candidates the exact evaluation rejects" can be exercised
 // (tests/test_gpu_glibc_mode.py); always 0 otherwise.
-template <int kFn>  // kFnGlibc: the glibc-faithful mode; kFnPlatform: the correctly-rounded mode's RMS (platform functions)
-__global__ void __launch_bounds__(64, 3)
+// (the small-batch form, 16 lanes per trajectory, is compiled for 2 waves per SIMD: there are few waves and their chain is
+// what counts, so no spills)
+template <int kFn, unsigned kRefineGroup>  // kFnGlibc: the glibc-faithful mode; kFnPlatform: the correctly-rounded mode's RMS (platform functions)
+__global__ void __launch_bounds__(64, kRefineGroup == 16u ? 2 : 3)
 k_refine_best(RmsArgs r, GaussResultRec* out_all, const double* bound, unsigned long long n_traj, int inject_fail) {
+  constexpr unsigned kRefineTraj = 64 / kRefineGroup;       // trajectories per wave
   __shared__ unsigned s_item_c[kRefineList];      // candidate index within its trajectory
   __shared__ unsigned char s_item_t[kRefineList]; // trajectory of the wave (0..kRefineTraj-1)
   __shared__ double s_item_rms[kRefineList];      // its exact RMS (NaN: cannot be selected)
@@ -1289,7 +1294,7 @@ k_refine_best(RmsArgs r, GaussResultRec* out_all, const double* bound, unsigned 
       const unsigned k = k0 + g;
       if (k < count) {
         const unsigned long long cid = (blk0 + s_item_t[k]) * r.I.cand_per_traj + s_item_c[k];
-        const double e = exact_candidate_rms<kFn>(r, cid, sub, group_base);
+        const double e = exact_candidate_rms<kFn, kRefineGroup>(r, cid, sub, group_base);
         if (sub == 0) s_item_rms[k] = inject_fail ? nan("") : e;
       }
     }
@@ -1361,10 +1366,18 @@ hipError_t launch_refine_best(const SelectArgs& a, const RmsArgs& r, hipStream_t
 #ifdef OUTFIT_REFINE_STATS
   { static const unsigned long long z[4] = {}; (void)hipStreamSynchronize(s); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_refine_stats), z, sizeof z); }
 #endif
-  const dim3 grid((unsigned)((a.n_traj + kRefineTraj - 1) / kRefineTraj));
   static const int inject_fail = std::getenv("OUTFIT_TEST_EXACT_RMS_FAILS") != nullptr;  // test aid, see the kernel
-  if (a.math_mode == kMathGlibc) hipLaunchKernelGGL(k_refine_best<kFnGlibc>, grid, dim3(64), 0, s, r, a.out, a.bound, a.n_traj, inject_fail);
-  else hipLaunchKernelGGL(k_refine_best<kFnPlatform>, grid, dim3(64), 0, s, r, a.out, a.bound, a.n_traj, inject_fail);
+  // small batch (the chunk's candidates, as for the correction kernels' forms): 16 lanes per trajectory
+  const unsigned group = use_pair_form(a.n_cand) ? 16u : 4u;
+  const dim3 grid((unsigned)((a.n_traj + 64 / group - 1) / (64 / group)));
+  const bool glibc = a.math_mode == kMathGlibc;
+  if (group == 16u) {
+    if (glibc) hipLaunchKernelGGL((k_refine_best<kFnGlibc, 16>), grid, dim3(64), 0, s, r, a.out, a.bound, a.n_traj, inject_fail);
+    else hipLaunchKernelGGL((k_refine_best<kFnPlatform, 16>), grid, dim3(64), 0, s, r, a.out, a.bound, a.n_traj, inject_fail);
+  } else {
+    if (glibc) hipLaunchKernelGGL((k_refine_best<kFnGlibc, 4>), grid, dim3(64), 0, s, r, a.out, a.bound, a.n_traj, inject_fail);
+    else hipLaunchKernelGGL((k_refine_best<kFnPlatform, 4>), grid, dim3(64), 0, s, r, a.out, a.bound, a.n_traj, inject_fail);
+  }
 #ifdef OUTFIT_REFINE_STATS
   { unsigned long long h[4] = {}; (void)hipStreamSynchronize(s); (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_refine_stats), sizeof h);
     fprintf(stderr, "[refine stats] trajectories %llu contenders %llu (%.4f each) list passes %llu largest list of a wave %llu\n", h[0], h[1], h[0] ? (double)h[1] / h[0] : 0.0, h[2], h[3]); }
