@@ -490,6 +490,13 @@ __device__ __forceinline__ T kernarg_field(unsigned offset) {
 // parameters as well; k_gauss_correct_fast 6.51-6.60 ms without either, 6.51 with the reload, 6.65-6.71 with both — a
 // v_readlane costs no more than the s_load + wait that replaces it. The reload is kept (not slower, half the spills), the
 // lazy parameters are off.
+// Measured and dropped (round 4): the fast kernel's queue in triplet-rank-major order (a wave's lanes = the same rank of 64
+// trajectories) — 6.46 -> 8.60 ms: round passes per trip 4.94 -> 6.05 at 34.6 instead of 47.8 lanes. How many Newton rounds
+// and series terms a solve takes is a property of the TRAJECTORY (its orbit), not of the triplet's gaps: the
+// trajectory-major order already is the one that puts like with like.
+#ifndef OUTFIT_K2B_RANK_MAJOR
+#define OUTFIT_K2B_RANK_MAJOR 0
+#endif
 #ifndef OUTFIT_KERNARG_LAZY_PARAMS  // GaussParams fields and the result pointers re-read where they are used
 #define OUTFIT_KERNARG_LAZY_PARAMS 0
 #endif
@@ -562,11 +569,20 @@ k_gauss_correct_fast(CorrectArgs a) {
       const unsigned long long st_r0 = clock64();
       st_refills += 1; st_needy += (unsigned)__popcll(need_mask);
 #endif
-      const unsigned long long my = kPair ? wave_grab_pairs(a.queue, need_mask) : wave_grab(a.queue, need_mask);
+      unsigned long long my = kPair ? wave_grab_pairs(a.queue, need_mask) : wave_grab(a.queue, need_mask);
       if (needy) {
         if (my >= n) {
           exhausted = true;
         } else {
+#if OUTFIT_K2B_RANK_MAJOR
+          // queue order = triplet rank first, trajectory second: the lanes a wave refills together hold the SAME rank of
+          // 64 different trajectories — triplets of similar weight, i.e. similar time gaps, hence similar numbers of
+          // Newton rounds and series terms — instead of ~2/3 of one trajectory's ranks (gaps from 0.02 d to 20 d)
+          {
+            const unsigned long long n_t = n / a.I.cand_per_traj;
+            my = (my % n_t) * a.I.cand_per_traj + my / n_t;
+          }
+#endif
 #if OUTFIT_KERNARG_RELOAD
           const CandidateIndex I = kernarg_field<CandidateIndex>((unsigned)offsetof(CorrectArgs, I));
           const CandidateScratch W = kernarg_field<CandidateScratch>((unsigned)offsetof(CorrectArgs, W));
