@@ -453,11 +453,12 @@ k_gauss_roots_lanes(RootsArgs a) {
 #endif
 constexpr unsigned kRefillThreshold = OUTFIT_K2B_THRESHOLD;  // idle lanes per wave before the queue is touched
 #ifndef OUTFIT_PAIR_MAX_CANDIDATES
-#define OUTFIT_PAIR_MAX_CANDIDATES (1u << 17)
+#define OUTFIT_PAIR_MAX_CANDIDATES (3u << 17)
 #endif
-// up to this many candidates in a chunk the correction kernels run in the lane-pair form (0 = never): 2 x 131 072 lanes
-// = 4 096 waves, about what the fast kernel keeps resident (3 per SIMD) — beyond it the lanes are better spent on
-// candidates than on halves of candidates
+// up to this many candidates in a chunk the candidate kernels run in their latency forms (lane pairs, root per lane,
+// 16-lane re-evaluation; 0 = never). Measured (tools/perf_form_threshold.py, step time latency / throughput forms):
+// 25 000 candidates 0.78 / 1.16 ms, 100 000: 1.05 / 1.45, 200 000: 1.35 / 1.65, 300 000: 1.71 / 1.80, 500 000: 2.15 / 2.19,
+// 1 000 000: 3.47 / 2.79 — beyond ~400 000 the lanes are better spent on candidates than on parts of candidates
 constexpr unsigned long long kPairMaxCandidates = OUTFIT_PAIR_MAX_CANDIDATES;
 // OUTFIT_PAIR_MODE=0 / 1 forces the form whatever the batch size (testing aid: the two forms must give the same bytes)
 static bool use_pair_form(unsigned long long n_cand) {

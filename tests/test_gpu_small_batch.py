@@ -1,6 +1,6 @@
 """Forms of the correction kernels chosen by batch size — needs an MI355X.
 
-Up to 131 072 candidates per chunk the two correction kernels run in the LANE-PAIR form (device/gauss.hpp,
+Up to 393 216 candidates per chunk the two correction kernels run in the LANE-PAIR form (device/gauss.hpp,
 `correction_iteration<.., kPair>`): two lanes hold one candidate, each runs one of the two independent Lagrange
 corrections of an iteration (gauss.rs:1325-1344), they exchange (v, f, g, chi) and evaluate the same tail — a shorter
 chain per candidate, which is what a small batch waits for. The operations and their operands are those of the one-lane
@@ -53,7 +53,7 @@ PARAM_SETS = [
 def test_lane_pair_form_equals_the_one_lane_form(kw, monkeypatch):
     e = synth.make_ephemeris()
     ephem = outfit_amd.Ephemeris.from_dict(e)
-    for n, seed, extra in ((1000, 5, {}), (2600, 6, {"topocentric": True})):   # 100 000 (pair by default) and 260 000 candidates
+    for n, seed, extra in ((1000, 5, {}), (4200, 6, {"topocentric": True})):   # 100 000 (latency forms by default) and 420 000 candidates
         batch = outfit_amd.ObsBatch.from_dict(synth.make_dataset(n, seed=seed, ephem=e, **extra))
         params = synth.bench_params(outfit_amd.IODParams())
         for k, v in kw.items():
