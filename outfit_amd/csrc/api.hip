@@ -289,6 +289,7 @@ struct outfit_hip_session {
   DevBuf<double> mjd, ra, dec, sra, sdec, helio, geo, obs_pos, cos_dec, unit[2], noise, coef;
   DevBuf<double> heap_w, sum, dirS, roots, state, psi0, sel_bound;
   DevBuf<unsigned long long> heap_id, triplets[2], queue, slow_list, slow_count;
+  DevBuf<unsigned> sel_list;  // K3 -> K3b: contender candidates per trajectory of the chunk (kernels.h)
   DevBuf<unsigned> n_triplets[2], flags, n_win;
   unsigned n_cu = 256;
   bool triplet_lds = false;  // K0 keeps its heap in LDS (small k_cap, <= 1024 reduced observations)
@@ -352,7 +353,7 @@ struct outfit_hip_session {
     traj_offset.release(); traj_key.release(); mjd.release(); ra.release(); dec.release(); sra.release(); sdec.release();
     helio.release(); geo.release(); obs_pos.release(); cos_dec.release(); unit[0].release(); unit[1].release(); noise.release(); coef.release();
     heap_w.release(); sum.release(); dirS.release(); roots.release(); state.release();
-    psi0.release(); slow_list.release(); slow_count.release(); sel_bound.release();
+    psi0.release(); slow_list.release(); slow_count.release(); sel_bound.release(); sel_list.release();
     heap_id.release(); triplets[0].release(); triplets[1].release(); queue.release(); wave_list.release();
     n_triplets[0].release(); n_triplets[1].release(); flags.release();
     n_win.release(); results.release(); error_flag.release();
@@ -624,6 +625,7 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
   HIP_TRY(s->slow_list.alloc(n_cand));
   HIP_TRY(s->slow_count.alloc(2));
   HIP_TRY(s->sel_bound.alloc(2 * chunk));
+  HIP_TRY(s->sel_list.alloc((size_t)chunk * (outfit::kContenderListCap + 1u)));
   g_trace.mark("  scratch alloc");
   int n_cu = 0;
   HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, s->device));
@@ -869,6 +871,7 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
     sa.out = d_out ? d_out : s->results.p;
     sa.math_mode = s->math_mode;
     sa.bound = refine ? s->sel_bound.p : nullptr;
+    sa.list = s->sel_list.p;
     sa.traj_offset = ci.traj_offset; sa.sra = ci.sra; sa.sdec = ci.sdec;
     {
       Stamp stamp(s, st, K_SELECT);

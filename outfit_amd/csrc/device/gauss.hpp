@@ -137,6 +137,7 @@ __device__ __forceinline__ int aberth_deg8(double c0, double c3, double c6, unsi
   }
   const double c6x6 = 6.0 * c6, c3x3 = 3.0 * c3;
   for (unsigned it = 1; it <= max_iter; ++it) {
+    K2ASTAT(1);
     double n_lo = 1.0, n_hi = 1.0;
     Cx sum[8];
 #pragma unroll

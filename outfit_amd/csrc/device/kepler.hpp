@@ -34,6 +34,20 @@ __device__ unsigned long long g_kstat[32];
 #define KSTAT(slot) do { } while (0)
 #endif
 
+#ifdef OUTFIT_K2A_STATS  // diagnostic build: (wave passes, active lanes) at a few program points of k_gauss_roots
+__device__ unsigned long long g_k2a_stat[16];
+#define K2ASTAT(slot)                                                               \
+  do {                                                                              \
+    const unsigned long long m__ = __ballot(true);                                  \
+    if (__lane_id() == (unsigned)__ffsll((long long)m__) - 1u) {                    \
+      atomicAdd(&g_k2a_stat[2 * (slot)], 1ull);                                     \
+      atomicAdd(&g_k2a_stat[2 * (slot) + 1], (unsigned long long)__popcll(m__));    \
+    }                                                                               \
+  } while (0)
+#else
+#define K2ASTAT(slot) do { } while (0)
+#endif
+
 constexpr double kPi = 3.14159265358979323846;
 constexpr double kTwoPi = 6.283185307179586476925286766559;  // constants.rs:31
 constexpr double kEps = 2.220446049250313e-16;                // f64::EPSILON
@@ -210,6 +224,7 @@ __device__ __forceinline__ double prelim_elliptic(const KeplerProblem& p) {
   // 20 copies of it made this the largest code of the library for no measurable gain
 #pragma unroll 1
   for (int i = 0; i < p.max_iter_prelim; ++i) {
+    K2ASTAT(4);
     double su, cu;
     sincos_mode(p.math_mode, u, su, cu);
     const double res = u - p.e0 * su - m;

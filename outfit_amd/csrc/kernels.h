@@ -157,9 +157,15 @@ struct SelectArgs {
   // trajectory of the chunk, the two numbers of its contender rule: bound[2 lt] = min_c (screened_c + slack_c),
   // bound[2 lt + 1] = 1 / sigma_min (kernels.hip, K3b)
   double* bound;
+  // ... and the trajectory's candidates that passed the contender test against the RUNNING bound of the fold, a
+  // superset of those that pass it against the final one: list[lt][0] = count (kContenderOverflow: more than fit, K3b
+  // scans the trajectory's candidates itself), list[lt][1..] = candidate indices within the trajectory
+  unsigned* list;
   const unsigned long long* traj_offset;
   const double *sra, *sdec;
 };
+constexpr unsigned kContenderListCap = 7;            // entries per trajectory (+ the count: 32 B per trajectory)
+constexpr unsigned kContenderOverflow = 0xFFFFFFFFu;
 
 // same layouts as outfit_lsq_result_t (480 B) / outfit_obs_fit_t (32 B)
 struct LsqResultRec {

@@ -305,6 +305,7 @@ k_gauss_roots(RootsArgs a) {
   const CandidateRef c = decode_candidate(a.I, cid);
   if (!c.live) { a.W.flags[cid] = kFlagEmpty; return; }
   const unsigned long long n = a.I.n_cand;
+  K2ASTAT(0);
 
   double ra[3], dec[3], t[3];
   Mat3 obs, Sinv;
@@ -352,6 +353,7 @@ k_gauss_roots(RootsArgs a) {
     }
   }
   if (nf == 0) { a.W.flags[cid] = (unsigned)kCauseNoRoots; return; }
+  K2ASTAT(2);
   // ---- K2a' fused: first accepted root and the cold-start values of its two universal-Kepler solves. The first
   // iteration of pos_and_vel_correction calls solve_kepuni_with_guess with psi_guess = None, i.e.
   // run_newton(prelim_kepuni(params)) (newton_solver.rs:151-161); prelim_kepuni(params) is what is stored.
@@ -374,6 +376,7 @@ k_gauss_roots(RootsArgs a) {
   if (!accepted) { a.W.flags[cid] = (unsigned)kCauseNoRoots; return; }  // no solution at all
   const double dt01 = g.t[0] - g.t[1], dt21 = g.t[2] - g.t[1];
   const bool slow = !vc.ok || fabs(dt01) <= kEps || fabs(dt21) <= kEps;
+  K2ASTAT(3);
   if (!slow) {
     a.W.psi0[cid] = prelim_kepuni(velocity_problem(vc, dt01, a.P.kepler_eps, a.P.math_mode));
     a.W.psi0[n + cid] = prelim_kepuni(velocity_problem(vc, dt21, a.P.kepler_eps, a.P.math_mode));
@@ -1041,9 +1044,14 @@ k_orbit_rms_wave(RmsArgs a) {
 // One wave = 64 trajectories; their candidates are contiguous in the scratch arrays, so the wave stages
 // them through LDS in tiles of kSelTile candidates per trajectory (two rows of 32 contiguous words per load
 // instruction) instead of 64 lanes each walking its own row (one cache line per lane and load).
+#ifndef OUTFIT_CONTENDER_WINDOW
+#define OUTFIT_CONTENDER_WINDOW 1.0e-4
+#endif
+constexpr double kContenderWindow = OUTFIT_CONTENDER_WINDOW;  // relative part of K3b's contender rule (see k_refine_best)
 constexpr unsigned kSelTile = 16;
 __global__ void __launch_bounds__(64)
 k_select_best(SelectArgs a) {
+  __shared__ unsigned s_list[64][kContenderListCap];  // K3b's contenders, collected against the running bound
   __shared__ double s_sum[64][kSelTile + 1];
   __shared__ unsigned s_flags[64][kSelTile + 1];
   __shared__ unsigned s_nwin[64][kSelTile + 1];
@@ -1067,6 +1075,7 @@ k_select_best(SelectArgs a) {
   const unsigned n_c = nt * a.n_real;
   // for K3b: the upper bound of the exact minimum, min_c (screened_c + slack_c), slack_c = screen_slack_rad / sigma_min
   double inv_sigma = 0.0, bound = INFINITY;
+  unsigned n_list = 0;  // kContenderOverflow once more than kContenderListCap candidates have passed
   if (a.bound && live) {
     double sig = INFINITY;
     for (unsigned long long o = a.traj_offset[a.traj0 + lt]; o < a.traj_offset[a.traj0 + lt + 1]; ++o)
@@ -1106,8 +1115,17 @@ k_select_best(SelectArgs a) {
           rms = (sm >= cutoff) ? best : sqrt(sm / denom);
         }
         if (!isfinite(rms)) { last_error = 4; continue; }  // NonFiniteScore
-        if (a.bound && !(f & kFlagRmsErr))
-          bound = fmin(bound, sqrt(s_sum[tl][cc] / denom) + screen_slack_rad((f & kFlagLevelMask) >> kFlagLevelShift) * inv_sigma);
+        if (a.bound && !(f & kFlagRmsErr)) {
+          // K3b's contender rule (see k_refine_best), applied with the bound as it stands: the final bound is no larger,
+          // so whatever passes the final test passes this one — the list is a superset of the contenders
+          const double screened = sqrt(s_sum[tl][cc] / denom);
+          const double slack = screen_slack_rad((f & kFlagLevelMask) >> kFlagLevelShift) * inv_sigma;
+          bound = fmin(bound, screened + slack);
+          if (screened <= bound * (1.0 + kContenderWindow) + slack) {
+            if (n_list < kContenderListCap) s_list[tl][n_list++] = c;
+            else n_list = kContenderOverflow;
+          }
+        }
         if (rms < best) { best = rms; best_c = (long long)c; }
       }
     }
@@ -1117,6 +1135,9 @@ k_select_best(SelectArgs a) {
   if (a.bound) {
     a.bound[2 * lt] = bound;
     a.bound[2 * lt + 1] = inv_sigma;
+    unsigned* row = a.list + lt * (kContenderListCap + 1u);
+    row[0] = n_list;
+    for (unsigned k = 0; k < kContenderListCap; ++k) row[1 + k] = k < n_list ? s_list[tl][k] : 0u;
   }
   if (nt == 0) {
     out.status = 1;  // NoFeasibleTriplets (trajectory.rs:439-451)
@@ -1172,10 +1193,6 @@ k_select_best(SelectArgs a) {
 // four lanes 0.6 ms), and the contenders of a wave's sixteen trajectories form one work list, so a trajectory with many
 // of them is spread over the wave.
 // ------------------------------------------------------------------------------
-#ifndef OUTFIT_CONTENDER_WINDOW
-#define OUTFIT_CONTENDER_WINDOW 1.0e-4
-#endif
-constexpr double kContenderWindow = OUTFIT_CONTENDER_WINDOW;
 // lanes per trajectory (kRefineGroup, a template parameter of the two functions below): 4 for throughput — a lane per
 // trajectory was a 45 k-instruction chain on 1.5 waves per SIMD: 1.6 ms; four lanes 0.6 ms —, 16 for small batches, where
 // the chain of the few waves there are is what the run waits for (1 000 trajectories: 0.22 -> see DESIGN.md §3).
@@ -1237,7 +1254,8 @@ constexpr unsigned kRefineList = 256;  // contenders a wave holds between two ev
 // what counts, so no spills)
 template <int kFn, unsigned kRefineGroup>  // kFnGlibc: the glibc-faithful mode; kFnPlatform: the correctly-rounded mode's RMS (platform functions)
 __global__ void __launch_bounds__(64, kRefineGroup == 16u ? 2 : 3)
-k_refine_best(RmsArgs r, GaussResultRec* out_all, const double* bound, unsigned long long n_traj, int inject_fail) {
+k_refine_best(RmsArgs r, GaussResultRec* out_all, const double* bound, const unsigned* list, unsigned long long n_traj,
+              int inject_fail) {
   constexpr unsigned kRefineTraj = 64 / kRefineGroup;       // trajectories per wave
   __shared__ unsigned s_item_c[kRefineList];      // candidate index within its trajectory
   __shared__ unsigned char s_item_t[kRefineList]; // trajectory of the wave (0..kRefineTraj-1)
@@ -1282,9 +1300,22 @@ k_refine_best(RmsArgs r, GaussResultRec* out_all, const double* bound, unsigned 
       const unsigned n_c = s_nc[t];
       if (sweep >= n_c) { ++t; sweep = 0; continue; }
       if (count + 64u > kRefineList) break;
-      const unsigned c = sweep + tl;
+      // Round 0 takes the trajectory's candidates from the list K3 collected against its running bound (a superset of
+      // the contenders, ~1 - 3 entries) instead of sweeping all of them; a trajectory whose list overflowed, and the
+      // exhaustive second round, sweep as before. Wave-uniform: t, round and the row's count are the same for all lanes.
+      unsigned c = sweep + tl;
+      bool from_list = false, mine = c < n_c;
+      if (round == 0 && list != nullptr) {
+        const unsigned* row = list + (blk0 + t) * (unsigned long long)(kContenderListCap + 1u);
+        const unsigned n_l = row[0];
+        if (n_l != kContenderOverflow) {
+          from_list = true;
+          mine = tl < n_l;
+          c = mine ? row[1u + tl] : 0u;
+        }
+      }
       bool is = false;
-      if (c < n_c) {
+      if (mine) {
         const unsigned long long cid = (blk0 + t) * r.I.cand_per_traj + c;
         const unsigned f = r.W.flags[cid];
         if ((f & kFlagOk) && !((f >> kFlagConvShift) & 0x7u) && !(f & kFlagRmsErr))
@@ -1298,7 +1329,8 @@ k_refine_best(RmsArgs r, GaussResultRec* out_all, const double* bound, unsigned 
         s_item_t[slot] = (unsigned char)t;
       }
       count += (unsigned)__popcll(mask);
-      sweep += 64u;
+      if (from_list) { ++t; sweep = 0; }
+      else sweep += 64u;
     }
     if (count == 0u) break;
     __syncthreads();
@@ -1388,12 +1420,13 @@ hipError_t launch_refine_best(const SelectArgs& a, const RmsArgs& r, hipStream_t
   const unsigned group = use_pair_form(a.n_cand) ? 16u : 4u;
   const dim3 grid((unsigned)((a.n_traj + 64 / group - 1) / (64 / group)));
   const bool glibc = a.math_mode == kMathGlibc;
+  static const bool use_list = std::getenv("OUTFIT_REFINE_SCAN_ALL") == nullptr;  // measurement / test aid: sweep every candidate
   if (group == 16u) {
-    if (glibc) hipLaunchKernelGGL((k_refine_best<kFnGlibc, 16>), grid, dim3(64), 0, s, r, a.out, a.bound, a.n_traj, inject_fail);
-    else hipLaunchKernelGGL((k_refine_best<kFnPlatform, 16>), grid, dim3(64), 0, s, r, a.out, a.bound, a.n_traj, inject_fail);
+    if (glibc) hipLaunchKernelGGL((k_refine_best<kFnGlibc, 16>), grid, dim3(64), 0, s, r, a.out, a.bound, use_list ? a.list : nullptr, a.n_traj, inject_fail);
+    else hipLaunchKernelGGL((k_refine_best<kFnPlatform, 16>), grid, dim3(64), 0, s, r, a.out, a.bound, use_list ? a.list : nullptr, a.n_traj, inject_fail);
   } else {
-    if (glibc) hipLaunchKernelGGL((k_refine_best<kFnGlibc, 4>), grid, dim3(64), 0, s, r, a.out, a.bound, a.n_traj, inject_fail);
-    else hipLaunchKernelGGL((k_refine_best<kFnPlatform, 4>), grid, dim3(64), 0, s, r, a.out, a.bound, a.n_traj, inject_fail);
+    if (glibc) hipLaunchKernelGGL((k_refine_best<kFnGlibc, 4>), grid, dim3(64), 0, s, r, a.out, a.bound, use_list ? a.list : nullptr, a.n_traj, inject_fail);
+    else hipLaunchKernelGGL((k_refine_best<kFnPlatform, 4>), grid, dim3(64), 0, s, r, a.out, a.bound, use_list ? a.list : nullptr, a.n_traj, inject_fail);
   }
 #ifdef OUTFIT_REFINE_STATS
   { unsigned long long h[4] = {}; (void)hipStreamSynchronize(s); (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_refine_stats), sizeof h);
@@ -1772,6 +1805,19 @@ hipError_t launch_gauss_correct_fast(const CorrectArgs& a, unsigned n_cu, hipStr
   const size_t lds = (size_t)27 * kFastBlock * sizeof(double);
   hipError_t e = hipMemsetAsync(a.queue, 0, sizeof(unsigned long long), s);
   if (e != hipSuccess) return e;
+#ifdef OUTFIT_K2A_STATS  // the K2a slices of this chunk have been enqueued before this launch: read and reset their counters
+  {
+    unsigned long long k[16] = {};
+    static const unsigned long long zero[16] = {};
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpyFromSymbol(k, HIP_SYMBOL(g_k2a_stat), sizeof k);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_k2a_stat), zero, sizeof zero);
+    const char* names[5] = {"kernel body (live candidates)", "Aberth sweep", "after the root filter", "cold-start section", "elliptic cold start: Newton iteration"};
+    for (int i = 0; i < 5; ++i)
+      fprintf(stderr, "[k2a stats]   %-40s wave passes %12llu (%.3f per wave)   lanes/pass %5.2f\n", names[i], k[2 * i],
+              k[0] ? (double)k[2 * i] / (double)k[0] : 0.0, k[2 * i] ? (double)k[2 * i + 1] / (double)k[2 * i] : 0.0);
+  }
+#endif
 #ifdef OUTFIT_K2B_STATS
   e = hipMemsetAsync(a.queue + 8, 0, 8 * sizeof(unsigned long long), s);
   if (e != hipSuccess) return e;
