@@ -198,6 +198,9 @@ def test_contender_refinement_equals_the_exhaustive_exact_evaluation(tmp_path, m
     refined = _digests({}, str(tmp_path / "screen"), mode)
     exhaustive = _digests({"OUTFIT_RMS_EXACT_ALL": "1"}, str(tmp_path / "exact"), mode)
     assert refined == exhaustive, (refined, exhaustive)
+    # round 4: K3b's first round reads the contender list K3 collected against its running bound; OUTFIT_REFINE_SCAN_ALL=1
+    # makes it sweep every candidate as before — the same records either way
+    assert _digests({"OUTFIT_REFINE_SCAN_ALL": "1"}, None, mode) == refined
     assert all(int(d.split(":")[1]) > 14000 for d in refined)
     report = []
     for i in range(3):
