@@ -61,7 +61,6 @@ k_diffcor(DiffCorArgs A) {
   // normal matrix (36), right-hand side (6) and weighted square sum (1) accumulate in LDS, [entry][slot]
   constexpr unsigned kSlots = 64 / kG;
   __shared__ double sN[43][kSlots];
-  __shared__ double sX[16][64];  // one observation per lane, published for the group's entry-parallel accumulation
   const unsigned lane = threadIdx.x / kG;   // LDS slot of this lane's group
   const unsigned sub = threadIdx.x % kG;
   const DiffCorConfig& C = A.cfg;
@@ -242,16 +241,10 @@ k_diffcor(DiffCorArgs A) {
             rc_[2 * A.n_obs + o] = have_accepted ? ra_[2 * A.n_obs + o] : 0.0;
           }
         }
-        // Ordered accumulation, entry-parallel (round 4). Every accumulator must sum the observations left to right
-        // (the reference's sequential loop), but the 43 accumulators are independent of each other: the group's lanes
-        // publish their observation's (ga, gd, wa, wd, rra, rdec) in LDS, then lane `sub` owns the entries
-        // e = sub, sub + kG, ... and adds the group's observations to each of them in observation order. Same products,
-        // same order per accumulator as one lane at a time adding all 43 of its observation (what this replaced: kG
-        // turns of 43 products with one lane of kG active — a quarter of the kernel's instructions at 1 / kG occupancy).
-        // No barrier: the groups of a wave run different trip counts (ragged trajectories); LDS operations of one wave
-        // complete in program order, the wavefront-scope fences only keep the compiler from reordering them.
-        if (kG == 1) {
-          if (eq_active) {
+        // ordered accumulation: observation i0 first, then i0 + 1, ... (one lane of the group at a time)
+#pragma unroll 1
+        for (unsigned turn = 0; turn < kG; ++turn) {
+          if (turn == sub && eq_active) {
             constexpr double wc = 0.0;
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
@@ -263,41 +256,6 @@ k_diffcor(DiffCorArgs A) {
             }
             lds_add(&sN[42][lane], wa * rra * rra + wd * rdec * rdec + 2.0 * wc * rra * rdec);
           }
-        } else {
-          const unsigned me = threadIdx.x, group_base = me - sub;
-#pragma unroll
-          for (int j = 0; j < 6; ++j) { sX[j][me] = ob.ga[j]; sX[6 + j][me] = ob.gd[j]; }
-          sX[12][me] = wa; sX[13][me] = wd; sX[14][me] = rra; sX[15][me] = rdec;
-          const unsigned act = (unsigned)(__ballot(eq_active) >> group_base) & ((1u << kG) - 1u);
-          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-          if (act) {
-            constexpr double wc = 0.0;
-#pragma unroll 1
-            for (unsigned e = sub; e < 43u; e += kG) {
-              double acc = sN[e][lane];
-              const unsigned j = e < 36u ? e / 6u : (e < 42u ? e - 36u : 0u), k = e < 36u ? e % 6u : 0u;
-#pragma unroll
-              for (unsigned turn = 0; turn < kG; ++turn) {
-                if (!((act >> turn) & 1u)) continue;
-                const unsigned src = group_base + turn;
-                const double o_wa = sX[12][src], o_wd = sX[13][src];
-                double term;
-                if (e < 36u) {
-                  const double gaj = sX[j][src], gak = sX[k][src], gdj = sX[6 + j][src], gdk = sX[6 + k][src];
-                  term = gaj * o_wa * gak + gdj * o_wd * gdk + wc * (gdj * gak + gaj * gdk);
-                } else if (e < 42u) {
-                  const double gaj = sX[j][src], gdj = sX[6 + j][src], o_rra = sX[14][src], o_rdec = sX[15][src];
-                  term = (gaj * o_wa + gdj * wc) * o_rra + (gaj * wc + gdj * o_wd) * o_rdec;
-                } else {
-                  const double o_rra = sX[14][src], o_rdec = sX[15][src];
-                  term = o_wa * o_rra * o_rra + o_wd * o_rdec * o_rdec + 2.0 * wc * o_rra * o_rdec;
-                }
-                acc = acc + term;
-              }
-              sN[e][lane] = acc;
-            }
-          }
-          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         }
       }
       active = group_sum<kG>(active);
