@@ -1538,6 +1538,9 @@ k_selftest_aberth(unsigned long long n_per_thread, unsigned long long seed, unsi
     const int er = (it & 3) == 3 ? 12 : 3;
     double c6 = random_double(s, er), c3 = random_double(s, er), c0 = random_double(s, er);
     if ((it & 1) == 0) { c6 = -fabs(c6); c0 = -fabs(c0); }  // physical case: c6 < 0, c0 < 0
+    if ((it & 31) == 5) c3 = 0.0;                            // even polynomial: roots in +- and conjugate quadruples
+    if ((it & 31) == 9) c6 = 0.0;
+    if ((it & 63) == 17) { c3 = 0.0; c6 = 0.0; }             // z^8 + c0: eight roots on a circle
     Cx za[8], zb[8];
     const int ra = aberth_deg8<true>(c0, c3, c6, 50u, 1e-6, za);
     const int rb = aberth_deg8<false>(c0, c3, c6, 50u, 1e-6, zb);
