@@ -88,22 +88,20 @@ __device__ __forceinline__ Cx cdiv_shared(Cx a, Cx b, double& lo, double& hi) {
   const double y = fdiv::refined_rcp(n);
   return {fdiv::div_with_rcp(a.re * b.re + a.im * b.im, n, y), fdiv::div_with_rcp(a.im * b.re - a.re * b.im, n, y)};
 }
-// 1 / b with the shared refined reciprocal, numerators simplified: num-complex evaluates (1 + 0i) / b as
-// ((1*b.re + 0*b.im) / n, (0*b.re - 1*b.im) / n); for FINITE, NON-ZERO b.re and b.im the two numerators are exactly b.re
-// and -b.im (0 * x = +-0, and y + (+-0) = y, (+-0) - y = -y for y != 0) — only the sign of a zero result can differ
-// when a component of b is exactly zero. `zmin` collects min(|b.re|, |b.im|): the caller verifies per sweep that it
-// stayed above 1e-100 — no zero (or NaN) component, and n = |b|^2 >= 2e-200 inside the shared reciprocal's window; the
-// upper end of the window follows from the iterates' own magnitudes (n <= 8 max|z|^2, checked per sweep as well).
-__device__ __forceinline__ Cx crecip_shared(Cx b, double& zmin) {
-  const double n = b.re * b.re + b.im * b.im;
-  zmin = fmin(zmin, fmin(fabs(b.re), fabs(b.im)));
-  const double y = fdiv::refined_rcp(n);
-  return {fdiv::div_with_rcp(b.re, n, y), fdiv::div_with_rcp(-b.im, n, y)};
-}
 // Complex::mul_add with a real addend: (a*b) + c, fused where num-complex fuses
 __device__ __forceinline__ Cx cmul_add_real(Cx a, Cx b, double c) {
   return {fma(a.re, b.re, c) - (a.im * b.im), fma(a.re, b.im, fma(a.im, b.re, 0.0))};
 }
+
+// The first Horner step of p and of p': (1 + 0i) z + 0 and (8 + 0i) z + 0 through Complex::mul_add, for a FINITE z
+// (every iterate is: a non-finite one ends the iteration in the sweep that produced it). Written out,
+//   re = fma(1, z.re, 0.0) - 0.0 * z.im,   im = fma(1, z.im, fma(0.0, z.re, 0.0)):
+// 0.0 * z.im is a zero, and A - (+-0) = A for every A that fma(1, z.re, 0.0) = z.re + 0.0 can be (a non-zero number, or
+// +0: never -0); fma(0.0, z.re, 0.0) = (+-0) + (+0) = +0. Hence exactly {z.re + 0.0, z.im + 0.0} — the additions stay:
+// they turn a -0 component into +0 as the crate's arithmetic does (a third of the polynomials end with an exactly zero
+// imaginary part) — and likewise {fma(8, z.re, 0.0), fma(8, z.im, 0.0)}. Two instructions each instead of five.
+__device__ __forceinline__ Cx horner_first_step_unit(Cx z) { return {z.re + 0.0, z.im + 0.0}; }
+__device__ __forceinline__ Cx horner_first_step_8(Cx z) { return {fma(8.0, z.re, 0.0), fma(8.0, z.im, 0.0)}; }
 
 // aberth::aberth::<9, f64>(&[c0,0,0,c3,0,0,c6,0,1], max_iter, eps): Aberth–Ehrlich
 // sweeps from Aberth's initial circle, every root updated from the previous sweep's
@@ -116,16 +114,10 @@ __device__ __forceinline__ Cx cmul_add_real(Cx a, Cx b, double c) {
 // crate's order (k ascending) so every partial sum is bit-identical.
 // Returns 0 converged / 1 max-iteration / 2 failed (NaN or Inf iterate).
 //
-// kSharedRcp: the 36 complex divisions of a sweep share one refined reciprocal each (cdiv_shared for the eight
-// updates, crecip_shared for the 28 pair terms: 11 instead of 22 division instructions), and — round 4 — what
-// num-complex spends on multiplying by the 1 and the 0 of (1 + 0i) is not spent: the numerators of 1 / (z_i - z_k) are
-// taken as (d.re, -d.im), the first Horner steps (1 + 0i) z + 0 and (8 + 0i) z + 0 as z and (8 z.re, 8 z.im) — exact for
-// finite, non-zero components (only the sign of an exact zero could differ). The preconditions are checked per sweep
-// on collected ranges: every component of every iterate and of every pair difference above 1e-100 in magnitude (no
-// zero, no NaN, |d|^2 >= 2e-200), every iterate component below 1e49 (|d|^2 <= 8e98), |denominator|^2 of the eight
-// updates in [1e-200, 1e200]. If any fails (not seen on any input) the function returns 3 and the caller restarts
-// with kSharedRcp = false: the crate's literal arithmetic with plain divisions. outfit_hip_selftest_aberth holds the
-// two variants against each other bit for bit (2^24 polynomials, incl. even and odd-free ones).
+// kSharedRcp: the 36 complex divisions of a sweep use cdiv_shared (11 instead of 22 division
+// instructions each). Its precondition is checked per sweep on the collected range of |denominator|^2;
+// if it ever fails (two iterates closer than 1e-100 or farther than 1e100 apart: not seen on any input)
+// the function returns 3 and the caller restarts with kSharedRcp = false, the plain divisions.
 template <bool kSharedRcp>
 __device__ __forceinline__ int aberth_deg8(double c0, double c3, double c6, unsigned max_iter, double eps,
                                            Cx (&z)[8]) {
@@ -156,7 +148,7 @@ __device__ __forceinline__ int aberth_deg8(double c0, double c3, double c6, unsi
   const double c6x6 = 6.0 * c6, c3x3 = 3.0 * c3;
   for (unsigned it = 1; it <= max_iter; ++it) {
     K2ASTAT(1);
-    double n_lo = 1.0, n_hi = 1.0, z_min = 1.0, z_max = 0.0;
+    double n_lo = 1.0, n_hi = 1.0;
     Cx sum[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) sum[i] = {0.0, 0.0};
@@ -164,7 +156,7 @@ __device__ __forceinline__ int aberth_deg8(double c0, double c3, double c6, unsi
     for (int i = 0; i < 8; ++i) {
 #pragma unroll
       for (int k = i + 1; k < 8; ++k) {
-        const Cx w = kSharedRcp ? crecip_shared(csub(z[i], z[k]), z_min)
+        const Cx w = kSharedRcp ? cdiv_shared({1.0, 0.0}, csub(z[i], z[k]), n_lo, n_hi)
                                 : cdiv({1.0, 0.0}, csub(z[i], z[k]));  // 1/(z_i - z_k)
         sum[i] = cadd(sum[i], w);
         sum[k] = cadd(sum[k], {-w.re, -w.im});             // 1/(z_k - z_i), exactly
@@ -175,16 +167,7 @@ __device__ __forceinline__ int aberth_deg8(double c0, double c3, double c6, unsi
     for (int i = 0; i < 8; ++i) {
       const Cx zi = z[i];
       // p(z): dense Horner over the 9 coefficients (zeros included, as the crate does)
-      // First Horner step of each: (1 + 0i) z + 0 and (8 + 0i) z + 0. With both components of z finite and non-zero
-      // these are exactly z and (8 z.re, 8 z.im) (same argument as crecip_shared; 8 x is exact); the shared-reciprocal
-      // variant takes them and verifies the precondition per sweep (z_min), the plain variant evaluates them literally.
-      Cx p = {1.0, 0.0};
-      if (kSharedRcp) {
-        p = zi;
-        z_min = fmin(z_min, fmin(fabs(zi.re), fabs(zi.im)));
-        z_max = fmax(z_max, fmax(fabs(zi.re), fabs(zi.im)));
-      }
-      else p = cmul_add_real(p, zi, 0.0);
+      Cx p = horner_first_step_unit(zi);  // == cmul_add_real({1.0, 0.0}, zi, 0.0)
       p = cmul_add_real(p, zi, c6);
       p = cmul_add_real(p, zi, 0.0);
       p = cmul_add_real(p, zi, 0.0);
@@ -193,9 +176,7 @@ __device__ __forceinline__ int aberth_deg8(double c0, double c3, double c6, unsi
       p = cmul_add_real(p, zi, 0.0);
       p = cmul_add_real(p, zi, c0);
       // p'(z): coefficients [0,0,3c3,0,0,6c6,0,8]
-      Cx dp = {8.0, 0.0};
-      if (kSharedRcp) dp = {8.0 * zi.re, 8.0 * zi.im};
-      else dp = cmul_add_real(dp, zi, 0.0);
+      Cx dp = horner_first_step_8(zi);   // == cmul_add_real({8.0, 0.0}, zi, 0.0)
       dp = cmul_add_real(dp, zi, c6x6);
       dp = cmul_add_real(dp, zi, 0.0);
       dp = cmul_add_real(dp, zi, 0.0);
@@ -213,7 +194,7 @@ __device__ __forceinline__ int aberth_deg8(double c0, double c3, double c6, unsi
     }
     // outside the window nothing of this sweep is trusted (coincident iterates, |d|^2 = 0, land here too and
     // are then reported as failed by the plain divisions)
-    if (kSharedRcp && !(n_lo > 1e-200 && n_hi < 1e200 && z_min > 1e-100 && z_max < 1e49)) return 3;
+    if (kSharedRcp && !(n_lo > 1e-200 && n_hi < 1e200)) return 3;
     if (failed) return 2;
     if (converged) return 0;
   }
@@ -262,8 +243,7 @@ __device__ __forceinline__ int aberth_deg8_lanes(double c0, double c3, double c6
       if (k != r) sum = added;
     }
     const Cx zi = z;
-    Cx p = {1.0, 0.0};
-    p = cmul_add_real(p, zi, 0.0);
+    Cx p = horner_first_step_unit(zi);
     p = cmul_add_real(p, zi, c6);
     p = cmul_add_real(p, zi, 0.0);
     p = cmul_add_real(p, zi, 0.0);
@@ -271,8 +251,7 @@ __device__ __forceinline__ int aberth_deg8_lanes(double c0, double c3, double c6
     p = cmul_add_real(p, zi, 0.0);
     p = cmul_add_real(p, zi, 0.0);
     p = cmul_add_real(p, zi, c0);
-    Cx dp = {8.0, 0.0};
-    dp = cmul_add_real(dp, zi, 0.0);
+    Cx dp = horner_first_step_8(zi);
     dp = cmul_add_real(dp, zi, c6x6);
     dp = cmul_add_real(dp, zi, 0.0);
     dp = cmul_add_real(dp, zi, 0.0);
