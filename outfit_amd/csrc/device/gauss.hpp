@@ -88,6 +88,21 @@ __device__ __forceinline__ Cx cdiv_shared(Cx a, Cx b, double& lo, double& hi) {
   const double y = fdiv::refined_rcp(n);
   return {fdiv::div_with_rcp(a.re * b.re + a.im * b.im, n, y), fdiv::div_with_rcp(a.im * b.re - a.re * b.im, n, y)};
 }
+// (1 + 0i) / b as num-complex evaluates it: numerators 1*b.re + 0*b.im and 0*b.re - 1*b.im. A product by 0.0 is exact
+// (+-0, or NaN for a non-finite factor), so fusing it into the addition changes nothing: fma(0.0, b.im, b.re) IS
+// (0.0 * b.im) + b.re, fma(0.0, b.re, -b.im) IS (0.0 * b.re) - b.im, for every input incl. zeros, infinities and NaN —
+// one instruction per numerator instead of two (the compiler may not do this itself: contraction is off).
+__device__ __forceinline__ Cx crecip(Cx b) {
+  const double n = b.re * b.re + b.im * b.im;
+  return {fma(0.0, b.im, b.re) / n, fma(0.0, b.re, -b.im) / n};
+}
+__device__ __forceinline__ Cx crecip_shared(Cx b, double& lo, double& hi) {
+  const double n = b.re * b.re + b.im * b.im;
+  lo = fmin(lo, n);
+  hi = fmax(hi, n);
+  const double y = fdiv::refined_rcp(n);
+  return {fdiv::div_with_rcp(fma(0.0, b.im, b.re), n, y), fdiv::div_with_rcp(fma(0.0, b.re, -b.im), n, y)};
+}
 // Complex::mul_add with a real addend: (a*b) + c, fused where num-complex fuses
 __device__ __forceinline__ Cx cmul_add_real(Cx a, Cx b, double c) {
   return {fma(a.re, b.re, c) - (a.im * b.im), fma(a.re, b.im, fma(a.im, b.re, 0.0))};
@@ -156,8 +171,8 @@ __device__ __forceinline__ int aberth_deg8(double c0, double c3, double c6, unsi
     for (int i = 0; i < 8; ++i) {
 #pragma unroll
       for (int k = i + 1; k < 8; ++k) {
-        const Cx w = kSharedRcp ? cdiv_shared({1.0, 0.0}, csub(z[i], z[k]), n_lo, n_hi)
-                                : cdiv({1.0, 0.0}, csub(z[i], z[k]));  // 1/(z_i - z_k)
+        const Cx w = kSharedRcp ? crecip_shared(csub(z[i], z[k]), n_lo, n_hi)
+                                : crecip(csub(z[i], z[k]));  // 1/(z_i - z_k)
         sum[i] = cadd(sum[i], w);
         sum[k] = cadd(sum[k], {-w.re, -w.im});             // 1/(z_k - z_i), exactly
       }
@@ -238,7 +253,7 @@ __device__ __forceinline__ int aberth_deg8_lanes(double c0, double c3, double c6
 #pragma unroll
     for (unsigned k = 0; k < 8; ++k) {
       const Cx zk = {__shfl(z.re, (int)(base + k)), __shfl(z.im, (int)(base + k))};
-      const Cx w = cdiv({1.0, 0.0}, csub(z, zk));  // 1/(z_i - z_k); for k == i a division by zero, discarded
+      const Cx w = crecip(csub(z, zk));  // 1/(z_i - z_k); for k == i a division by zero, discarded
       const Cx added = cadd(sum, w);
       if (k != r) sum = added;
     }
