@@ -1,0 +1,122 @@
+// Host build of the device's arithmetic (tests/test_device_math_host.py): the headers under outfit_amd/csrc/device/ compiled
+// with g++ against the stand-in hip_runtime.h, plain C entry points over arrays. What runs here is the code the kernels
+// inline — restated glibc functions, correctly-rounded functions, Stumpff series, universal-Kepler Newton solver, cold
+// starts, Lagrange velocity correction, the Aberth iteration in its three forms of arithmetic — so that it can be held
+// against the CPU oracle bit for bit WITHOUT a GPU. (Lane-cooperative code — wave form of K0, pair / root-per-lane forms —
+// needs the device: the -m gpu suite.) v_rcp_f64 is emulated by the correctly rounded reciprocal (seed error 0).
+#include "hip/hip_runtime.h"
+#include "device/gauss.hpp"
+#include "device/orbit.hpp"
+extern "C" {
+double g_seed_rel_error = 0.0;
+using namespace outfit;
+// fn: 0 sin1 1 cos1 2 sincos->sin 3 sincos->cos 4 tan 5 atan2(a,b) 6 hypot(a,b) 7 acos 8 log 9 sinh 10 cosh
+void glm_eval(int fn, unsigned long long n, const double* a, const double* b, double* out) {
+  for (unsigned long long i = 0; i < n; ++i) {
+    double s, c;
+    switch (fn) {
+      case 0: out[i] = glm::sin1(a[i]); break;
+      case 1: out[i] = glm::cos1(a[i]); break;
+      case 2: glm::sincos(a[i], s, c); out[i] = s; break;
+      case 3: glm::sincos(a[i], s, c); out[i] = c; break;
+      case 4: out[i] = glm::tan(a[i]); break;
+      case 5: out[i] = glm::atan2(a[i], b[i]); break;
+      case 6: out[i] = glm::hypot(a[i], b[i]); break;
+      case 7: out[i] = glm::acos(a[i]); break;
+      case 8: out[i] = glm::log(a[i]); break;
+      case 9: glm::sinhcosh(a[i], s, c); out[i] = s; break;
+      default: glm::sinhcosh(a[i], s, c); out[i] = c; break;
+    }
+  }
+}
+// fn: 0 sin 1 cos 2 acos 3 log 4 sinh 5 cosh 6 atan2(a,b) 7 tan 8 hypot(a,b)   (correctly rounded, crmath.hpp)
+void crm_eval(int fn, unsigned long long n, const double* a, const double* b, double* out) {
+  for (unsigned long long i = 0; i < n; ++i) {
+    double s, c;
+    switch (fn) {
+      case 0: crm::sincos(a[i], s, c); out[i] = s; break;
+      case 1: crm::sincos(a[i], s, c); out[i] = c; break;
+      case 2: out[i] = crm::acos(a[i]); break;
+      case 3: out[i] = crm::log(a[i]); break;
+      case 4: crm::sinhcosh(a[i], s, c); out[i] = s; break;
+      case 5: crm::sinhcosh(a[i], s, c); out[i] = c; break;
+      case 6: out[i] = crm::atan2(a[i], b[i]); break;
+      case 7: out[i] = crm::tan(a[i]); break;
+      default: out[i] = crm::hypot(a[i], b[i]); break;
+    }
+  }
+}
+void s_funct_array(unsigned long long n, const double* psi, const double* alpha, double* out /* 4 n */) {
+  for (unsigned long long i = 0; i < n; ++i) {
+    const Stumpff s = s_funct(psi[i], alpha[i]);
+    out[4 * i] = s.s0; out[4 * i + 1] = s.s1; out[4 * i + 2] = s.s2; out[4 * i + 3] = s.s3;
+  }
+}
+// problems: (dt, r0, sig0, alpha, e0, convergency) x n; out: prelim_kepuni value; then the Newton solve from it:
+// sol[6 i ..] = ok, psi, s0, s1, s2, s3
+void kepler_array(unsigned long long n, const double* prob, int math_mode, double* prelim, double* sol) {
+  for (unsigned long long i = 0; i < n; ++i) {
+    KeplerProblem p;
+    p.dt = prob[6 * i]; p.r0 = prob[6 * i + 1]; p.sig0 = prob[6 * i + 2]; p.alpha = prob[6 * i + 3];
+    p.e0 = prob[6 * i + 4]; p.convergency = prob[6 * i + 5]; p.math_mode = math_mode;
+    prelim[i] = prelim_kepuni(p);
+    const KeplerSolution s = solve_kepuni(p, false, 0.0);
+    sol[6 * i] = s.ok ? 1.0 : 0.0; sol[6 * i + 1] = s.psi;
+    sol[6 * i + 2] = s.s.s0; sol[6 * i + 3] = s.s.s1; sol[6 * i + 4] = s.s.s2; sol[6 * i + 5] = s.s.s3;
+  }
+}
+// in: x1[3] x2[3] v2[3] dt has_guess chi (12 per case); out: ok v[3] f g chi (7 per case)
+void velocity_correction_array(unsigned long long n, const double* in, double peri_max, double ecc_max, double eps,
+                               int math_mode, double* out) {
+  for (unsigned long long i = 0; i < n; ++i) {
+    const double* q = in + 12 * i;
+    const VelCorr v = velocity_correction({q[0], q[1], q[2]}, {q[3], q[4], q[5]}, {q[6], q[7], q[8]}, q[9], peri_max,
+                                          ecc_max, q[10] != 0.0, q[11], eps, math_mode);
+    double* o = out + 7 * i;
+    o[0] = v.ok ? 1.0 : 0.0;
+    o[1] = v.ok ? v.v.x : 0.0; o[2] = v.ok ? v.v.y : 0.0; o[3] = v.ok ? v.v.z : 0.0;
+    o[4] = v.ok ? v.f : 0.0; o[5] = v.ok ? v.g : 0.0; o[6] = v.ok ? v.chi : 0.0;
+  }
+}
+// coef: (c0, c3, c6) x n; variant 0 = plain divisions, 1 = shared reciprocal (restart with the plain form on 3, as K2a does)
+void aberth_array(unsigned long long n, const double* coef, unsigned max_iter, double eps, int variant, int* code,
+                  double* roots /* 16 n: re, im x 8 */) {
+  for (unsigned long long i = 0; i < n; ++i) {
+    Cx z[8];
+    int rc = variant ? aberth_deg8<true>(coef[3 * i], coef[3 * i + 1], coef[3 * i + 2], max_iter, eps, z)
+                     : aberth_deg8<false>(coef[3 * i], coef[3 * i + 1], coef[3 * i + 2], max_iter, eps, z);
+    if (rc == 3) rc = aberth_deg8<false>(coef[3 * i], coef[3 * i + 1], coef[3 * i + 2], max_iter, eps, z);
+    code[i] = rc;
+    for (int k = 0; k < 8; ++k) { roots[16 * i + 2 * k] = z[k].re; roots[16 * i + 2 * k + 1] = z[k].im; }
+  }
+}
+// The RMS chain of one candidate in the glibc-faithful mode (what K3b evaluates exactly): state (equatorial r, v, epoch)
+// -> ccek1 -> to_equinoctial -> for every observation ephemeris_error. in: r[3] v[3] epoch (7); obs: mjd ra dec sra sdec
+// obs_pos[3] (8 per observation, n_obs per candidate); out per candidate: kind, conv, elem[6], eq (a h k p q lambda),
+// then n_obs x (ok, term).
+void rms_chain_glibc(unsigned long long n, unsigned n_obs, const double* state, const double* obs, double* out) {
+  const unsigned stride = 2 + 6 + 6 + 2 * n_obs;
+  for (unsigned long long i = 0; i < n; ++i) {
+    const double* q = state + 7 * i;
+    double* o = out + stride * i;
+    const Elements el = ccek1<kFnGlibc>(equ_to_ecl({q[0], q[1], q[2]}), equ_to_ecl({q[3], q[4], q[5]}), q[6]);
+    Equinoctial eq{};
+    const int conv = to_equinoctial<kFnGlibc>(el, eq);
+    o[0] = el.kind; o[1] = conv;
+    for (int k = 0; k < 6; ++k) o[2 + k] = el.e[k];
+    o[8] = eq.a; o[9] = eq.h; o[10] = eq.k; o[11] = eq.p; o[12] = eq.q; o[13] = eq.lambda;
+    if (conv != 0 || !(sqrt(eq.h * eq.h + eq.k * eq.k) < 1.0)) {
+      for (unsigned j = 0; j < 2 * n_obs; ++j) o[14 + j] = -1.0;
+      continue;
+    }
+    const TwoBodyFrame F = twobody_frame<kFnGlibc>(eq);
+    for (unsigned j = 0; j < n_obs; ++j) {
+      const double* b = obs + 8 * ((unsigned long long)n_obs * i + j);
+      double term = 0.0;
+      const bool ok = ephemeris_error<kFnGlibc>(eq, F, b[0], b[1], b[2], glm::cos1(b[2]), b[3], b[4], {b[5], b[6], b[7]}, term);
+      o[14 + 2 * j] = ok ? 1.0 : 0.0;
+      o[15 + 2 * j] = ok ? term : 0.0;
+    }
+  }
+}
+}

@@ -5,13 +5,6 @@
 #include <cstdint>
 #include <vector>
 #include "hip/hip_runtime.h"
-using std::isfinite;
-// names the header's wave form mentions; never called from here
-static unsigned long long __ballot(bool) { return 0; }
-static int __ffsll(long long) { return 0; }
-template <class T> static T __shfl(T v, int) { return v; }
-static void __syncthreads() {}
-static struct { unsigned x; } threadIdx;
 #include "device/triplets.hpp"
 extern "C" int k0_lane_form(const double* mjd, unsigned long long n_obs, double dt_min, double dt_max, double dtw,
                             unsigned long long max_keep, unsigned k_cap, unsigned long long* out) {

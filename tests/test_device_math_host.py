@@ -1,0 +1,270 @@
+"""The device's arithmetic against the CPU oracle, bit for bit, WITHOUT a GPU.
+
+tests/host_harness/device_math_host.cpp compiles the headers the kernels inline (outfit_amd/csrc/device/*.hpp) with g++:
+the restated glibc functions, the correctly-rounded functions, the Stumpff series, the universal-Kepler cold starts and
+Newton solver, the Lagrange velocity correction and the Aberth iteration in both of its arithmetic forms. The -m gpu
+suite compares whole records through the C ABI on the device; this one holds the same code against the oracle function
+by function on this machine (a host compiler may schedule differently, but every operation is IEEE and the translation
+unit is built with contraction off, exactly as hipcc builds it: same bits)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HARNESS = os.path.join(ROOT, "tests", "host_harness")
+BUILD = os.path.join(ROOT, "oracle", "_build")
+_dp = C.POINTER(C.c_double)
+EPS = 2.220446049250313e-16
+
+
+@pytest.fixture(scope="module")
+def D():
+    os.makedirs(BUILD, exist_ok=True)
+    so = os.path.join(BUILD, "libdevice_math_host.so")
+    src = os.path.join(HARNESS, "device_math_host.cpp")
+    deps = [src, os.path.join(HARNESS, "hip", "hip_runtime.h")] + \
+        [os.path.join(ROOT, "outfit_amd", "csrc", "device", f) for f in os.listdir(os.path.join(ROOT, "outfit_amd", "csrc", "device"))]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in deps):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-D_GNU_SOURCE", "-shared", "-fPIC", "-I" + HARNESS,
+                        "-I" + os.path.join(ROOT, "outfit_amd", "csrc"), src, "-o", so], check=True)
+    return C.CDLL(so)
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def same_bits(a, b):
+    return a.view(np.uint64) == b.view(np.uint64)
+
+
+def scalar(L, name, n_args=1):
+    f = getattr(L, name)
+    f.restype = C.c_double
+    f.argtypes = [C.c_double] * n_args
+    return f
+
+
+def test_restated_glibc_functions_device_equals_oracle(D):
+    """glibcmath{,2,3}.hpp == oracle/glibcmath{,2,3}.c on the ranges the path uses (and beyond): every bit."""
+    L = O.lib()
+    rng = np.random.default_rng(11)
+    n = 60000
+    ang = np.concatenate([rng.uniform(-40, 40, n // 2), rng.uniform(-7, 7, n // 2)])
+    one = [("orc_glibc_sin1", 0, ang), ("orc_glibc_cos1", 1, ang), ("orc_glibc_sin", 2, ang), ("orc_glibc_cos", 3, ang),
+           ("orc_glibc_tan", 4, rng.uniform(-1.6, 1.6, n)), ("orc_glibc_acos", 7, rng.uniform(-1, 1, n)),
+           ("orc_glibc_log", 8, 10.0 ** rng.uniform(-3, 3, n)), ("orc_glibc_sinh", 9, rng.uniform(-15, 15, n)),
+           ("orc_glibc_cosh", 10, rng.uniform(-15, 15, n))]
+    for name, fn, x in one:
+        x = np.ascontiguousarray(x)
+        out = np.empty_like(x)
+        D.glm_eval(C.c_int(fn), C.c_uint64(x.size), _p(x), _p(x), _p(out))
+        f = scalar(L, name)
+        ref = np.array([f(float(v)) for v in x])
+        assert same_bits(out, ref).all(), (name, int((~same_bits(out, ref)).sum()))
+    y, x = np.ascontiguousarray(rng.normal(size=n) * 10.0 ** rng.uniform(-3, 3, n)), np.ascontiguousarray(rng.normal(size=n) * 10.0 ** rng.uniform(-3, 3, n))
+    for name, fn in (("orc_glibc_atan2", 5), ("orc_glibc_hypot", 6)):
+        out = np.empty_like(x)
+        D.glm_eval(C.c_int(fn), C.c_uint64(n), _p(y), _p(x), _p(out))
+        f = scalar(L, name, 2)
+        ref = np.array([f(float(a), float(b)) for a, b in zip(y, x)])
+        assert same_bits(out, ref).all(), name
+
+
+def test_correctly_rounded_functions_device_equals_oracle(D):
+    """crmath.hpp (double-double fast paths + full evaluations) == the oracle's correctly-rounded mode (its own
+    double-double sin / cos / acos, binary128 for the rest)."""
+    L = O.lib()
+    rng = np.random.default_rng(12)
+    n = 30000
+    with O.math_flags(libm=0, glibc=0):
+        for name, fn, x in (("orc_sin", 0, rng.uniform(-40, 40, n)), ("orc_cos", 1, rng.uniform(-40, 40, n)),
+                            ("orc_acos", 2, rng.uniform(-1, 1, n)), ("orc_log", 3, 1.0 + 10.0 ** rng.uniform(-6, 3, n)),   # log: y > 1 is the call site's domain (hyperbolic cold start)
+                            ("orc_sinh", 4, rng.uniform(-15, 15, n)), ("orc_cosh", 5, rng.uniform(-15, 15, n))):
+            x = np.ascontiguousarray(x)
+            out = np.empty_like(x)
+            D.crm_eval(C.c_int(fn), C.c_uint64(x.size), _p(x), _p(x), _p(out))
+            f = scalar(L, name)
+            ref = np.array([f(float(v)) for v in x])
+            assert same_bits(out, ref).all(), (name, int((~same_bits(out, ref)).sum()))
+
+
+def _kepler_problems(rng, n):
+    a = np.where(rng.uniform(size=n) < 0.85, 10.0 ** rng.uniform(-0.3, 1.7, n), -10.0 ** rng.uniform(-0.3, 1.5, n))   # a < 0: hyperbolic
+    alpha = -1.0 / a
+    e0 = np.where(a > 0, rng.uniform(0, 0.98, n), 1.0 + 10.0 ** rng.uniform(-3, 0.5, n))
+    r0 = np.abs(a) * np.abs(1.0 - e0 * rng.uniform(-1, 1, n)) + 1e-3
+    sig0 = rng.normal(size=n) * 0.7
+    dt = rng.choice([-1.0, 1.0], n) * 10.0 ** rng.uniform(-2, 1.6, n)
+    return np.ascontiguousarray(np.stack([dt, r0, sig0, alpha, e0, np.full(n, 1e3 * EPS)], axis=1))
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["correctly_rounded", "glibc"])
+def test_stumpff_cold_starts_and_newton_device_equals_oracle(D, mode):
+    """s_funct (series with the exact constant divisions, halving + duplication), prelim_kepuni (elliptic / hyperbolic
+    cold starts with the mode's functions) and the Newton solve from it (quirks incl.): device headers == oracle."""
+    L = O.lib()
+    rng = np.random.default_rng(13 + mode)
+    n = 20000
+    psi = np.ascontiguousarray(rng.normal(size=n) * 10.0 ** rng.uniform(-3, 1.5, n))
+    alpha = np.ascontiguousarray(rng.normal(size=n) * 10.0 ** rng.uniform(-2, 1, n))
+    alpha[:50] = 0.0
+    out = np.empty(4 * n)
+    D.s_funct_array(C.c_uint64(n), _p(psi), _p(alpha), _p(out))
+    s4 = O.D4()
+    ref = np.empty(4 * n)
+    for i in range(n):
+        L.orc_s_funct(float(psi[i]), float(alpha[i]), s4)
+        ref[4 * i:4 * i + 4] = list(s4)
+    assert same_bits(out, ref).all()
+    m = 6000
+    prob = _kepler_problems(rng, m)
+    prelim, sol = np.empty(m), np.empty(6 * m)
+    D.kepler_array(C.c_uint64(m), _p(prob), C.c_int(mode), _p(prelim), _p(sol))
+    sol = sol.reshape(m, 6)
+    with O.math_flags(libm=0, glibc=mode):
+        for i in range(m):
+            kp = O.KeplerParams(dt=prob[i, 0], r0=prob[i, 1], sig0=prob[i, 2], mu=0.01720209895 ** 2, alpha=prob[i, 3],
+                                e0=prob[i, 4], convergency=prob[i, 5], has_guess=0, psi_guess=0.0,
+                                max_iter_prelim_kepuni=20, kind=0, parabolic_method=0)
+            want = L.orc_prelim_kepuni(C.byref(kp))
+            assert np.float64(want).view(np.uint64) == prelim[i:i + 1].view(np.uint64)[0], (i, prob[i], want, prelim[i])
+            ks = O.KeplerSolution()
+            rc = L.orc_kepler_solve(C.byref(kp), C.byref(ks))
+            assert (rc == 1) == (sol[i, 0] == 1.0), (i, prob[i])      # 1 = Some(solution)
+            if rc == 1:
+                got = sol[i, 1:]
+                exp = np.array([ks.psi, ks.s0, ks.s1, ks.s2, ks.s3])
+                assert same_bits(np.ascontiguousarray(got), exp).all(), (i, prob[i], got, exp)
+
+
+def test_velocity_correction_device_equals_oracle(D):
+    L = O.lib()
+    rng = np.random.default_rng(15)
+    n = 6000
+    x2 = rng.normal(size=(n, 3)) * 2.0
+    v2 = rng.normal(size=(n, 3)) * 0.012
+    dt = rng.choice([-1.0, 1.0], n) * 10.0 ** rng.uniform(-2, 1.4, n)
+    x1 = x2 + v2 * dt[:, None] + rng.normal(size=(n, 3)) * 1e-4
+    has = (rng.uniform(size=n) < 0.6).astype(float)
+    chi = rng.normal(size=n) * 0.3
+    inp = np.ascontiguousarray(np.concatenate([x1, x2, v2, dt[:, None], has[:, None], chi[:, None]], axis=1))
+    out = np.empty(7 * n)
+    D.velocity_correction_array(C.c_uint64(n), _p(inp), C.c_double(1e3), C.c_double(5.0), C.c_double(1e3 * EPS), C.c_int(1), _p(out))
+    out = out.reshape(n, 7)
+    ok_count = 0
+    with O.math_flags(libm=0, glibc=1):
+        for i in range(n):
+            v = O.D3()
+            f, g, c = C.c_double(), C.c_double(), C.c_double()
+            rc = L.orc_velocity_correction_with_guess(O.D3(*x1[i]), O.D3(*x2[i]), O.D3(*v2[i]), float(dt[i]), 1e3, 5.0,
+                                                      int(has[i]), float(chi[i]), 1e3 * EPS, v, C.byref(f), C.byref(g), C.byref(c))
+            assert (rc == 0) == (out[i, 0] == 1.0), i
+            if rc == 0:
+                ok_count += 1
+                exp = np.array([v[0], v[1], v[2], f.value, g.value, c.value])
+                assert same_bits(np.ascontiguousarray(out[i, 1:]), exp).all(), (i, out[i, 1:], exp)
+    assert ok_count > 0.5 * n
+
+
+def test_aberth_forms_device_equals_oracle(D):
+    """aberth_deg8<false> (plain divisions) and <true> (shared reciprocals; restart on the guard) == the oracle's
+    restatement of the crate: return code, all eight iterates, their order — incl. the families whose roots reach
+    exactly zero imaginary parts, even polynomials and z^8 + c0."""
+    L = O.lib()
+    rng = np.random.default_rng(16)
+    n = 4000
+    c = rng.normal(size=(n, 3)) * 10.0 ** rng.uniform(-2, 2, (n, 3))
+    c[: n // 2, 0] = -np.abs(c[: n // 2, 0])      # the physical signs: c0 < 0, c6 < 0
+    c[: n // 2, 2] = -np.abs(c[: n // 2, 2])
+    c[n // 2: n // 2 + 200, 1] = 0.0
+    c[n // 2 + 200: n // 2 + 300, 2] = 0.0
+    c[n // 2 + 300: n // 2 + 350, 1:] = 0.0
+    coef = np.ascontiguousarray(c)
+    got = {}
+    for variant in (0, 1):
+        code = np.empty(n, dtype=np.int32)
+        roots = np.empty(16 * n)
+        D.aberth_array(C.c_uint64(n), _p(coef), C.c_uint(50), C.c_double(1e-6), C.c_int(variant),
+                       code.ctypes.data_as(C.POINTER(C.c_int)), _p(roots))
+        got[variant] = (code, roots.reshape(n, 16))
+    assert np.array_equal(got[0][0], got[1][0])
+    live = got[0][0] != 2
+    assert same_bits(np.ascontiguousarray(got[0][1][live]), np.ascontiguousarray(got[1][1][live])).all()
+    re, im = O.D8(), O.D8()
+    it = C.c_uint32()
+    for i in range(n):
+        rc = L.orc_aberth9(O.D9(coef[i, 0], 0, 0, coef[i, 1], 0, 0, coef[i, 2], 0, 1.0), 50, 1e-6, re, im, C.byref(it))
+        assert rc == got[0][0][i], (i, coef[i])
+        if rc != 2:
+            exp = np.array([v for k in range(8) for v in (re[k], im[k])])
+            assert same_bits(np.ascontiguousarray(got[0][1][i]), exp).all(), (i, coef[i])
+
+
+def test_rms_chain_device_equals_oracle_in_the_glibc_mode(D):
+    """State -> ccek1 -> to_equinoctial -> ephemeris_error per observation with the restated glibc functions (orbit.hpp
+    kFnGlibc: what K3b evaluates for the contenders) == the oracle in its restated-glibc mode: elements, equinoctial
+    elements, every residual term — the bits of the `rms` field's ingredients."""
+    import outfit_amd  # noqa: F401
+    from outfit_amd import synth
+    L = O.lib()
+    ds = synth.make_dataset(300, seed=41)
+    n, n_obs = 300, 20
+    truth = ds["truth"]
+    rng = np.random.default_rng(17)
+    # states: the truth orbit's position / velocity at the middle epoch, perturbed (what a Gauss candidate looks like)
+    state = np.empty((n, 7))
+    for i in range(n):
+        a, e, inc, node, argp, m0 = truth[i]
+        el = O.Elements(kind=0, epoch=60000.0, e=(C.c_double * 6)(a, e, inc, node, argp, m0))
+        eq = O.Equinoctial()
+        with O.math_flags(libm=0, glibc=1):
+            assert L.orc_to_equinoctial(C.byref(el), C.byref(eq)) == 0
+            r, v = O.D3(), O.D3()
+            t_mid = float(ds["mjd_tt"][n_obs * i + n_obs // 2])
+            assert L.orc_propagate_twobody(C.byref(eq), 60000.0, t_mid, r, v) == 0
+        # ecliptic -> equatorial (orbit.hpp ecl_to_equ), small perturbation
+        c, s_ = 9.174820620691818e-1, 3.977771559319137e-1
+        rq = np.array([r[0], c * r[1] - s_ * r[2], s_ * r[1] + c * r[2]]) * (1 + 1e-4 * rng.normal(size=3))
+        vq = np.array([v[0], c * v[1] - s_ * v[2], s_ * v[1] + c * v[2]]) * (1 + 1e-4 * rng.normal(size=3))
+        state[i] = [*rq, *vq, t_mid]
+    obs = np.empty((n, n_obs, 8))
+    for i in range(n):
+        sl = slice(n_obs * i, n_obs * (i + 1))
+        obs[i, :, 0] = ds["mjd_tt"][sl]; obs[i, :, 1] = ds["ra"][sl]; obs[i, :, 2] = ds["dec"][sl]
+        obs[i, :, 3] = ds["sigma_ra"][sl]; obs[i, :, 4] = ds["sigma_dec"][sl]
+        obs[i, :, 5:] = ds["obs_helio_equ"].reshape(-1, 3)[sl]
+    state, obs = np.ascontiguousarray(state), np.ascontiguousarray(obs)
+    stride = 14 + 2 * n_obs
+    out = np.empty(n * stride)
+    D.rms_chain_glibc(C.c_uint64(n), C.c_uint(n_obs), _p(state), _p(obs), _p(out))
+    out = out.reshape(n, stride)
+    checked = 0
+    with O.math_flags(libm=0, glibc=1):
+        for i in range(n):
+            c, s_ = 9.174820620691818e-1, 3.977771559319137e-1
+            def to_ecl(x):   # orbit.hpp equ_to_ecl: the reference's rotation matrix, row by row
+                return O.D3((1.0 * x[0] + 0.0 * x[1]) + 0.0 * x[2], (0.0 * x[0] + c * x[1]) + s_ * x[2], (0.0 * x[0] + (-s_) * x[1]) + c * x[2])
+            el = O.Elements()
+            L.orc_ccek1(to_ecl(state[i, :3]), to_ecl(state[i, 3:6]), float(state[i, 6]), C.byref(el))
+            assert el.kind == int(out[i, 0])
+            assert same_bits(np.ascontiguousarray(out[i, 2:8]), np.array(list(el.e))).all(), (i, out[i, 2:8], list(el.e))
+            eq = O.Equinoctial()
+            conv = L.orc_to_equinoctial(C.byref(el), C.byref(eq))
+            assert conv == int(out[i, 1])
+            if conv != 0:
+                continue
+            assert same_bits(np.ascontiguousarray(out[i, 8:14]), np.array([eq.a, eq.h, eq.k, eq.p, eq.q, eq.lam])).all(), i
+            for j in range(n_obs):
+                term = C.c_double()
+                rc = L.orc_ephemeris_error(C.byref(eq), *[float(x) for x in obs[i, j, :5]], O.D3(*obs[i, j, 5:]), C.byref(term))
+                assert (rc == 0) == (out[i, 14 + 2 * j] == 1.0), (i, j)
+                if rc == 0:
+                    assert np.float64(term.value).view(np.uint64) == out[i, 15 + 2 * j:16 + 2 * j].view(np.uint64)[0], (i, j, term.value, out[i, 15 + 2 * j])
+                    checked += 1
+    assert checked > 0.9 * n * n_obs
