@@ -7,6 +7,7 @@
 #include "hip/hip_runtime.h"
 #include "device/gauss.hpp"
 #include "device/orbit.hpp"
+#include "device/diffcor.hpp"
 extern "C" {
 double g_seed_rel_error = 0.0;
 using namespace outfit;
@@ -119,4 +120,21 @@ void rms_chain_glibc(unsigned long long n, unsigned n_obs, const double* state, 
     }
   }
 }
+// compute_obs_and_partials_2body of the corrector in the glibc-faithful mode (diffcor.hpp kFnGlibc): eq = epoch a h k p q
+// lambda (7 per case), obs = mjd obs_pos[3] (4 per case); out per case: ok, ra, dec, ga[6], gd[6] (15)
+void obs_partials_glibc(unsigned long long n, const double* eqs, const double* obs, double* out) {
+  for (unsigned long long i = 0; i < n; ++i) {
+    const double* e = eqs + 7 * i;
+    Equinoctial q{};
+    q.epoch = e[0]; q.a = e[1]; q.h = e[2]; q.k = e[3]; q.p = e[4]; q.q = e[5]; q.lambda = e[6];
+    const PartialsFrame P = partials_frame<kFnGlibc>(q);
+    ObsPartials ob;
+    const bool ok = obs_and_partials<kFnGlibc>(q, P, obs[4 * i], {obs[4 * i + 1], obs[4 * i + 2], obs[4 * i + 3]}, ob);
+    double* o = out + 15 * i;
+    o[0] = ok ? 1.0 : 0.0;
+    o[1] = ok ? ob.ra : 0.0; o[2] = ok ? ob.dec : 0.0;
+    for (int j = 0; j < 6; ++j) { o[3 + j] = ok ? ob.ga[j] : 0.0; o[9 + j] = ok ? ob.gd[j] : 0.0; }
+  }
+}
+double angular_diff_host(double a, double b) { return angular_diff(a, b); }
 }

@@ -268,3 +268,50 @@ def test_rms_chain_device_equals_oracle_in_the_glibc_mode(D):
                     assert np.float64(term.value).view(np.uint64) == out[i, 15 + 2 * j:16 + 2 * j].view(np.uint64)[0], (i, j, term.value, out[i, 15 + 2 * j])
                     checked += 1
     assert checked > 0.9 * n * n_obs
+
+
+def test_corrector_partials_device_equals_oracle_in_the_glibc_mode(D):
+    """compute_obs_and_partials_2body (observation_ephemeris.rs:418-450 -> equinoctial_element.rs:442-582): computed (ra, dec)
+    and their twelve element partials, device header (diffcor.hpp, kFnGlibc) == oracle in its restated-glibc mode; and
+    angular_diff on wrapped and unwrapped pairs."""
+    import outfit_amd  # noqa: F401
+    from outfit_amd import synth
+    L = O.lib()
+    ds = synth.make_dataset(200, seed=43)
+    n_obs = 20
+    rng = np.random.default_rng(19)
+    eqs, obs = [], []
+    with O.math_flags(libm=0, glibc=1):
+        for i in range(200):
+            a, e, inc, node, argp, m0 = ds["truth"][i]
+            el = O.Elements(kind=0, epoch=60000.0, e=(C.c_double * 6)(a, e, inc, node, argp, m0))
+            eq = O.Equinoctial()
+            assert L.orc_to_equinoctial(C.byref(el), C.byref(eq)) == 0
+            for j in range(n_obs):
+                o = n_obs * i + j
+                pert = 1e-5 * rng.normal(size=6)
+                eqs.append([60000.0, eq.a * (1 + pert[0]), eq.h + pert[1], eq.k + pert[2], eq.p + pert[3], eq.q + pert[4], eq.lam + pert[5]])
+                obs.append([ds["mjd_tt"][o], *ds["obs_helio_equ"][3 * o:3 * o + 3]])
+    eqs, obs = np.ascontiguousarray(eqs), np.ascontiguousarray(obs)
+    n = len(eqs)
+    out = np.empty(15 * n)
+    D.obs_partials_glibc(C.c_uint64(n), _p(eqs), _p(obs), _p(out))
+    out = out.reshape(n, 15)
+    checked = 0
+    with O.math_flags(libm=0, glibc=1):
+        for i in range(n):
+            eq = O.Equinoctial(*eqs[i])
+            ra, dec = C.c_double(), C.c_double()
+            ga, gd = O.D6(), O.D6()
+            rc = L.orc_obs_and_partials_2body(C.byref(eq), float(obs[i, 0]), O.D3(*obs[i, 1:]), C.byref(ra), C.byref(dec), ga, gd)
+            assert (rc == 0) == (out[i, 0] == 1.0), i
+            if rc == 0:
+                exp = np.array([ra.value, dec.value, *ga, *gd])
+                assert same_bits(np.ascontiguousarray(out[i, 1:]), exp).all(), (i, out[i, 1:], exp)
+                checked += 1
+    assert checked > 0.95 * n
+    D.angular_diff_host.restype = C.c_double
+    D.angular_diff_host.argtypes = [C.c_double, C.c_double]
+    for a, b in [(0.1, 6.2), (6.2, 0.1), (3.0, -3.0), (1.0, 1.0 + 1e-9), (100.0, -3.0), (-50.0, 7.0)] + \
+            [tuple(rng.uniform(-20, 20, 2)) for _ in range(2000)]:
+        assert np.float64(D.angular_diff_host(a, b)).view(np.uint64) == np.float64(L.orc_angular_diff(a, b)).view(np.uint64), (a, b)
