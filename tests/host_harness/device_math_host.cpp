@@ -137,4 +137,38 @@ void obs_partials_glibc(unsigned long long n, const double* eqs, const double* o
   }
 }
 double angular_diff_host(double a, double b) { return angular_diff(a, b); }
+// One root of one candidate through the device's accept_root and correction loop (gauss.hpp), as the general kernel runs
+// it: correction_iteration<false, false> until it ends — WITH the early exits of the device (fixed point of the
+// (pos, vel, chi01, chi21) tuple, carried eccentricity_control) that the reference's 50-iteration loop does not have.
+// in per case: obs[9] (m[r][k] row-major), S[9], t[3], root (22); out: accepted, outcome (1 Some / 0 None), pos column 1 [3],
+// vel[3], epoch, iterations consumed (10)
+void correction_loop_array(unsigned long long n, const double* in, double max_ecc, double max_peri, double min_rho2,
+                           double kepler_eps, double newton_eps, unsigned newton_max_it, int math_mode, double* out) {
+  GaussParams P{};
+  P.max_ecc = max_ecc; P.max_perihelion_au = max_peri; P.min_rho2_au = min_rho2; P.kepler_eps = kepler_eps;
+  P.newton_eps = newton_eps; P.newton_max_it = newton_max_it; P.math_mode = math_mode;
+  for (unsigned long long i = 0; i < n; ++i) {
+    const double* q = in + 22 * i;
+    double* o = out + 10 * i;
+    Mat3 obs, S, Sinv;
+    for (int r = 0; r < 3; ++r)
+      for (int k = 0; k < 3; ++k) { obs.m[r][k] = q[3 * r + k]; S.m[r][k] = q[9 + 3 * r + k]; }
+    const double t[3] = {q[18], q[19], q[20]};
+    for (int k = 0; k < 10; ++k) o[k] = 0.0;
+    if (!try_inverse(S, Sinv)) { o[0] = -1.0; continue; }
+    const GaussGeometry g = gauss_times(t);
+    CorrectionState st{};
+    double e_pre;
+    if (!accept_root(obs, S, Sinv, t[1], g, P, q[21], st.pos, st.vel, e_pre, st.vc)) continue;
+    o[0] = 1.0;
+    const double dt01 = t[0] - t[1], dt21 = t[2] - t[1];
+    if (fabs(dt01) <= kEps || fabs(dt21) <= kEps) continue;  // gauss.rs:1311-1313: None
+    st.epoch = 0.0; st.has01 = false; st.has21 = false; st.chi01 = st.chi21 = 0.0; st.it = 0;
+    CorrStep step = kCorrContinue;
+    while (step == kCorrContinue) step = correction_iteration<false, false>(obs, S, Sinv, t[1], dt01, dt21, P, st);
+    o[1] = step == kCorrSome ? 1.0 : 0.0;
+    o[2] = st.pos.m[0][1]; o[3] = st.pos.m[1][1]; o[4] = st.pos.m[2][1];
+    o[5] = st.vel.x; o[6] = st.vel.y; o[7] = st.vel.z; o[8] = st.epoch; o[9] = st.it;
+  }
+}
 }

@@ -315,3 +315,72 @@ def test_corrector_partials_device_equals_oracle_in_the_glibc_mode(D):
     for a, b in [(0.1, 6.2), (6.2, 0.1), (3.0, -3.0), (1.0, 1.0 + 1e-9), (100.0, -3.0), (-50.0, 7.0)] + \
             [tuple(rng.uniform(-20, 20, 2)) for _ in range(2000)]:
         assert np.float64(D.angular_diff_host(a, b)).view(np.uint64) == np.float64(L.orc_angular_diff(a, b)).view(np.uint64), (a, b)
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["correctly_rounded", "glibc"])
+def test_correction_loop_with_its_early_exits_equals_the_literal_loop(D, mode):
+    """gauss.rs:1284-1418 through the DEVICE's code — accept_root, then correction_iteration until it ends, with the exits
+    the device adds (an iteration that ends in `continue` and leaves (pos, vel, chi01, chi21) bit for bit unchanged is a
+    fixed point: the loop's result is known; eccentricity_control carried from one iteration to the next) — against the
+    oracle's literal loop over all newton_max_it iterations: same Some / None, same position, velocity and epoch bits,
+    for every root of ~600 triplets of the bench population, several parameter sets."""
+    import outfit_amd  # noqa: F401
+    from outfit_amd import synth
+    from outfit_amd.api import IODParams
+    L = O.lib()
+    L.orc_accept_root.argtypes = [C.POINTER(O.GaussObs), C.POINTER(O.IODParamsC), C.c_double, C.POINTER(O.GaussPrelim),
+                                  O.M33, O.D3, _dp]
+    ds = synth.make_dataset(150, seed=47)
+    rng = np.random.default_rng(21)
+    total = some = none_ = early = 0
+    for kw in (dict(), dict(max_ecc=0.35, max_perihelion_au=3.5), dict(newton_max_it=7), dict(min_rho2_au=0.5)):
+        ip = IODParams(n_noise_realizations=0, **kw).as_c()
+        with O.math_flags(libm=0, glibc=mode):
+            cases, refs = [], []
+            for i in range(150):
+                idx = sorted(rng.choice(20, 3, replace=False).tolist())
+                o = [20 * i + k for k in idx]
+                g = O.gauss_obs(idx, [ds["ra"][k] for k in o], [ds["dec"][k] for k in o], [ds["mjd_tt"][k] for k in o],
+                                [ds["obs_helio_equ"][3 * k:3 * k + 3] for k in o])
+                pre = O.GaussPrelim()
+                if L.orc_gauss_prelim_fn(C.byref(g), C.byref(pre)) != 0:
+                    continue
+                c6, c3, c0 = C.c_double(), C.c_double(), C.c_double()
+                L.orc_coeff_eight_poly(C.byref(g), C.byref(pre), C.byref(c6), C.byref(c3), C.byref(c0))
+                roots, nr = O.D8(), C.c_int()
+                if L.orc_solve_8poly(O.D9(c0.value, 0, 0, c3.value, 0, 0, c6.value, 0, 1.0), 50, 1e-6, 1e-6, roots, C.byref(nr)) != 0:
+                    continue
+                for r in range(nr.value):
+                    root = roots[r]
+                    if not (ip.r2_min_au <= root <= ip.r2_max_au):
+                        continue
+                    pos, vel, ep = O.M33(), O.D3(), C.c_double()
+                    acc = L.orc_accept_root(C.byref(g), C.byref(ip), float(root), C.byref(pre), pos, vel, C.byref(ep))
+                    ref = {"accepted": acc}
+                    if acc:
+                        pos2, vel2, ep2 = O.M33(), O.D3(), C.c_double()
+                        rc = L.orc_pos_and_vel_correction(C.byref(g), C.byref(ip), pos, vel, pre.S, pre.Sinv, ip.max_perihelion_au,
+                                                          ip.max_ecc, ip.newton_eps, ip.newton_max_it, pos2, vel2, C.byref(ep2))
+                        ref.update(outcome=rc, state=[pos2[0][1], pos2[1][1], pos2[2][1], vel2[0], vel2[1], vel2[2], ep2.value])
+                    refs.append(ref)
+                    cases.append([*[g.obs[a][b] for a in range(3) for b in range(3)], *[pre.S[a][b] for a in range(3) for b in range(3)],
+                                  g.t[0], g.t[1], g.t[2], root])
+        inp = np.ascontiguousarray(cases)
+        out = np.empty(10 * len(cases))
+        D.correction_loop_array(C.c_uint64(len(cases)), _p(inp), C.c_double(ip.max_ecc), C.c_double(ip.max_perihelion_au),
+                                C.c_double(ip.min_rho2_au), C.c_double(ip.kepler_eps), C.c_double(ip.newton_eps),
+                                C.c_uint(ip.newton_max_it), C.c_int(mode), _p(out))
+        out = out.reshape(-1, 10)
+        for k, ref in enumerate(refs):
+            assert (ref["accepted"] != 0) == (out[k, 0] == 1.0), (kw, k)
+            if not ref["accepted"]:
+                continue
+            total += 1
+            assert ref["outcome"] == int(out[k, 1]), (kw, k, ref, out[k])
+            if ref["outcome"] == 1:
+                some += 1
+                assert same_bits(np.ascontiguousarray(out[k, 2:9]), np.array(ref["state"])).all(), (kw, k, out[k, 2:9], ref["state"])
+                early += out[k, 9] < ip.newton_max_it
+            else:
+                none_ += 1
+    assert total > 600 and some > 500 and none_ > 5 and early > 200, (total, some, none_, early)
