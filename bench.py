@@ -161,6 +161,14 @@ def noise_point(label, ds, ephem, params, device, stream, steps, seed, workload)
     kt = s.kernel_times()
     s.set_profiling(False)
     rec = s.results()
+    # K0 and K1 run on side streams under the previous run's kernels: in back-to-back runs their event times include
+    # waiting for issue slots. One ISOLATED run (device idle before it) gives what they cost by themselves.
+    torch.cuda.synchronize()
+    s.set_profiling(True)
+    s.run(stream=stream)
+    torch.cuda.synchronize()
+    kt_iso = s.kernel_times()
+    s.set_profiling(False)
     s.close()
     cand = n_obj * params.max_triplets * (1 + params.n_noise_realizations)
     n_obs = int(batch.traj_offset[-1])
@@ -172,6 +180,7 @@ def noise_point(label, ds, ephem, params, device, stream, steps, seed, workload)
             "obs_per_object": n_obs / n_obj,
             "steps": steps, "ms_per_step": 1e3 * dt, "objects_per_s": n_obj / dt, "candidates_per_s": cand / dt,
             "kernel_avg_ms_per_step": {k: v[0] / steps for k, v in kt.items()},
+            "isolated_run_kernel_ms": {k: v[0] for k, v in kt_iso.items()},
             "orbits_found": int((rec["status"] == 0).sum()),
             "noisy_winners": int(((rec["status"] == 0) & (rec["best_realization"] > 0)).sum()),
             "session_build_and_first_run_s": setup}
@@ -198,6 +207,9 @@ def long_arc_points(outfit_amd, synth, device, stream, steps, which=(100, 300), 
                             20261100 + n_obs, f"long_arcs_{n_obs}_{tag}")
             k0 = r["kernel_avg_ms_per_step"].get("k_triplet_select", 0.0)
             r["k_triplet_select_share_of_step"] = k0 / r["ms_per_step"] if r["ms_per_step"] > 0 else None
+            # (event time back to back, i.e. incl. waiting under the previous run's kernels, over the step time; the
+            # kernel's own time is isolated_run_kernel_ms.k_triplet_select)
+            r["k_triplet_select_isolated_ms"] = r["isolated_run_kernel_ms"].get("k_triplet_select")
             out[f"{n_obs}_obs_{tag}"] = r
     return out
 
