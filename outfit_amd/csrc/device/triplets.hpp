@@ -253,8 +253,7 @@ __device__ __forceinline__ unsigned select_triplets(const double* mjd /* this tr
 // (rank = #{w_j < w_i} + #{j < i : w_j == w_i}), which is what a stable insertion sort produces.
 // LDS: the reduced epochs [n] and the heap [k_cap] x (weight, 64-bit id); the launcher checks that it fits.
 // Returns the number of triplets (wave-uniform) and writes them, sorted, to `out` (global).
-struct WaveHeap {   // heap of one trajectory in LDS; same interface as HeapView (stride 1); lane 0 operates it
-  static constexpr bool kAllLanes = false;
+struct WaveHeap {   // heap of one trajectory in LDS; same interface as HeapView (stride 1)
   double* w;
   unsigned long long* id;
   __device__ __forceinline__ double W(unsigned s) const { return w[s]; }
@@ -264,51 +263,11 @@ struct WaveHeap {   // heap of one trajectory in LDS; same interface as HeapView
   __device__ __forceinline__ Raw raw(unsigned s) const { return id[s]; }
   __device__ __forceinline__ Raw encode(unsigned long long ii) const { return ii; }
   __device__ __forceinline__ void set_raw(unsigned s, double ww, Raw r) const { w[s] = ww; id[s] = r; }
-  // this lane's view of slot lane + 64 * half (the rank computation at the end)
-  __device__ __forceinline__ double own_w(unsigned lane, unsigned half) const { return w[lane + 64u * half]; }
-  __device__ __forceinline__ unsigned long long own_id(unsigned lane, unsigned half) const { return id[lane + 64u * half]; }
 };
 
-// The same heap held in REGISTERS across the wave, for k_cap <= 128: slot s lives in lane s & 63, register s >> 6. The
-// sift code above runs on it unchanged, executed by ALL lanes with wave-uniform indices: a read is a v_readlane (a few
-// cycles) instead of an LDS round trip (~100 cycles in a chain that is nothing but dependent reads), a write a
-// v_writelane. With K = 100 a long trajectory makes thousands of heap operations (the generator's order improves the
-// weights steadily, so most candidates of a good row replace the top): they are what K0 spends its time on.
-__device__ __forceinline__ double wave_read(double v, unsigned lane) {
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), (int)lane),
-                          __builtin_amdgcn_readlane(__double2loint(v), (int)lane));
-}
-// (a v_writelane in effect: `val` and `lane` are wave-uniform; written as a select on the lane id)
-__device__ __forceinline__ double wave_write(double old, double val, unsigned lane) {
-  return __lane_id() == lane ? val : old;
-}
-struct WaveRegHeap {
-  static constexpr bool kAllLanes = true;
-  mutable double w0 = 0.0, w1 = 0.0;   // this lane's two slots
-  mutable double i0 = 0.0, i1 = 0.0;   // their ids, bit-cast (moved as 64-bit patterns only)
-  typedef unsigned long long Raw;
-  __device__ __forceinline__ double W(unsigned s) const { return s < 64u ? wave_read(w0, s) : wave_read(w1, s - 64u); }
-  __device__ __forceinline__ Raw raw(unsigned s) const {
-    return (Raw)__double_as_longlong(s < 64u ? wave_read(i0, s) : wave_read(i1, s - 64u));
-  }
-  __device__ __forceinline__ unsigned long long I(unsigned s) const { return raw(s); }
-  __device__ __forceinline__ Raw encode(unsigned long long ii) const { return ii; }
-  __device__ __forceinline__ void set_raw(unsigned s, double ww, Raw r) const {
-    const double rd = __longlong_as_double((long long)r);
-    if (s < 64u) { w0 = wave_write(w0, ww, s); i0 = wave_write(i0, rd, s); }
-    else { w1 = wave_write(w1, ww, s - 64u); i1 = wave_write(i1, rd, s - 64u); }
-  }
-  __device__ __forceinline__ void move(unsigned dst, unsigned src) const { set_raw(dst, W(src), raw(src)); }
-  __device__ __forceinline__ double own_w(unsigned, unsigned half) const { return half ? w1 : w0; }
-  __device__ __forceinline__ unsigned long long own_id(unsigned, unsigned half) const {
-    return (unsigned long long)__double_as_longlong(half ? i1 : i0);
-  }
-};
-
-template <class Heap>
 __device__ __forceinline__ unsigned select_triplets_wave(const double* mjd /* this trajectory */, unsigned long long n_obs64,
                                                          const TripletParams& P, double* ep /* LDS [n] */,
-                                                         const Heap& h, unsigned long long* out) {
+                                                         const WaveHeap& h, unsigned long long* out) {
   if (P.k_cap == 0 || n_obs64 < 3) return 0;
   const unsigned lane = threadIdx.x & 63u;
   const unsigned n_obs = (unsigned)n_obs64;
@@ -322,15 +281,13 @@ __device__ __forceinline__ unsigned select_triplets_wave(const double* mjd /* th
     while (mask) {
       const int l = __ffsll((long long)mask) - 1;
       mask &= mask - 1ull;
-      // the survivor's weight and id, wave-uniform (l is: it comes from the ballot)
-      const double wl = wave_read(w, (unsigned)l);
-      const unsigned long long il =
-          (unsigned long long)__double_as_longlong(wave_read(__longlong_as_double((long long)id), (unsigned)l));
+      const double wl = __shfl(w, l);
+      const unsigned long long il = __shfl(id, l);
       if (len < P.k_cap) {
-        if (Heap::kAllLanes || lane == 0) heap_sift_up(h, 0, len, wl, il);
+        if (lane == 0) heap_sift_up(h, 0, len, wl, il);
         ++len;
       } else if (wl < root_w) {
-        if (Heap::kAllLanes || lane == 0) {
+        if (lane == 0) {
           unsigned ll = len;
           heap_pop(h, ll);
           heap_sift_up(h, 0, ll, wl, il);
@@ -338,7 +295,7 @@ __device__ __forceinline__ unsigned select_triplets_wave(const double* mjd /* th
       } else {
         continue;  // the top has dropped below this candidate since the ballot
       }
-      if (!Heap::kAllLanes) __syncthreads();
+      __syncthreads();
       root_w = h.W(0);
     }
   };
@@ -391,16 +348,14 @@ __device__ __forceinline__ unsigned select_triplets_wave(const double* mjd /* th
   }
   __syncthreads();
   // sort_unstable_by(weight) as the stable order of the heap's vector (see select_triplets): rank of every slot
-  for (unsigned half = 0; 64u * half < len; ++half) {
-    const unsigned i = lane + 64u * half;
-    const bool mine = i < len;
-    const double wi = mine ? h.own_w(lane, half) : 0.0;
+  for (unsigned i = lane; i < len; i += 64u) {
+    const double wi = h.W(i);
     unsigned rank = 0;
     for (unsigned j = 0; j < len; ++j) {
       const double wj = h.W(j);
       rank += (wj < wi || (wj == wi && j < i)) ? 1u : 0u;
     }
-    if (mine) out[rank] = h.own_id(lane, half);
+    out[rank] = h.I(i);
   }
   return len;
 }

@@ -84,14 +84,8 @@ k_triplet_select_wave(TripletArgs a) {
   const unsigned long long n_obs = a.traj_offset[traj + 1] - base;
   const unsigned n = (unsigned)reduced_len(n_obs, a.P.max_keep);
   double* ep = lds_wave;
-  unsigned len;
-  if (a.P.k_cap <= 128u) {  // the heap fits the wave's registers (two slots per lane): no LDS round trips in the sifts
-    WaveRegHeap h;
-    len = select_triplets_wave(a.mjd + base, n_obs, a.P, ep, h, a.triplets + lt * a.P.k_cap);
-  } else {
-    WaveHeap h{lds_wave + n, reinterpret_cast<unsigned long long*>(lds_wave + n + a.P.k_cap)};
-    len = select_triplets_wave(a.mjd + base, n_obs, a.P, ep, h, a.triplets + lt * a.P.k_cap);
-  }
+  WaveHeap h{lds_wave + n, reinterpret_cast<unsigned long long*>(lds_wave + n + a.P.k_cap)};
+  const unsigned len = select_triplets_wave(a.mjd + base, n_obs, a.P, ep, h, a.triplets + lt * a.P.k_cap);
   if (threadIdx.x == 0) a.n_triplets[lt] = len;
 }
 

@@ -38,7 +38,6 @@ static inline int __popc(unsigned x) { return __builtin_popcount(x); }
 template <class T> static inline T __shfl(T v, int) { return v; }
 template <class T> static inline T __shfl_xor(T v, int) { return v; }
 static inline int __builtin_amdgcn_mov_dpp(int x, int, int, int, bool) { return x; }
-static inline int __builtin_amdgcn_readlane(int x, int) { return x; }
 static inline void __syncthreads() {}
 static struct { unsigned x; } threadIdx;
 extern "C" double g_seed_rel_error;  // +-2^-23 (or 0)
