@@ -529,6 +529,18 @@ const char *outfit_hip_last_error(void); /* thread-local, never NULL */
 int         outfit_hip_abi_version(void);
 int         outfit_hip_device_count(void);
 
+/* ---- environment switches (none is needed in production; all are read by the host layer only) ------------------
+ * Behaviour:    OUTFIT_MATH_MODE (glibc / cr: initial process default), OUTFIT_CACHE_LIMIT_MB, OUTFIT_NO_CACHE,
+ *               OUTFIT_IOD_CHUNK (trajectories per chunk), OUTFIT_SHARD_DEVICES (logical shards, e.g. "0,0"),
+ *               OUTFIT_TRACE (phase trace of the blocking call on stderr).
+ * Forms of a kernel that must give the same bytes (testing / measurement aids; tests hold them against each other):
+ *               OUTFIT_K0_WAVE_MIN (reduced epochs from which a trajectory takes the wave form of K0; 0 never, 3 all),
+ *               OUTFIT_PAIR_MODE (0 / 1: throughput / latency forms of K2a, K2b, K3b whatever the batch size),
+ *               OUTFIT_REFINE_SCAN_ALL (K3b sweeps every candidate instead of reading K3's contender list),
+ *               OUTFIT_RMS_EXACT_ALL, OUTFIT_RMS_NO_SCREEN (K2c exact for every candidate), OUTFIT_RMS_WAVE,
+ *               OUTFIT_K0_SLICES, OUTFIT_GENERAL_SERIAL, OUTFIT_NO_STREAMED_UPLOAD, OUTFIT_DIFFCOR_GROUP.
+ * Fault injection for tests: OUTFIT_CACHE_POISON (NaN-fill device blocks), OUTFIT_TEST_EXACT_RMS_FAILS. */
+
 #ifdef __cplusplus
 }
 #endif
