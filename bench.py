@@ -34,6 +34,11 @@ FP64_PEAK_TFLOPS = 78.6        # MI355X_MICROARCH.md: fp64 vector, 256 CU x 4 SI
 # the ONE fp64 issue peak used everywhere: a 64-lane fp64 VALU instruction occupies a SIMD's 16 lanes for 4 cycles,
 # 1024 SIMDs at the 2.4 GHz peak engine clock -> wave-instructions per second
 VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4.0
+# measured issue costs on gfx950 (tools/issue_cost.hip -> profiles/round04_issue_cost_gfx950.json): fp64 add / mul / fma,
+# compares, v_div_*, v_ldexp, conversions 4.0 shader cycles per 64-lane instruction per SIMD; v_rcp / v_rsq / v_sqrt_f64
+# (the counters' TRANS class) 16.0; plain 32-bit moves / integer adds 2 - 4 (priced at 4 here: a lower bound on the fraction)
+ISSUE_CYCLES_PLAIN, ISSUE_CYCLES_TRANS_F64 = 4.0, 16.0
+N_SIMDS, NOMINAL_CLOCK_HZ = 1024, 2.4e9
 BYTES_PER_OBS_IN = 64          # t, ra, dec, sigma_ra, sigma_dec, obs_helio_equ[3]   
 BYTES_PER_OBS_GEO = 24         # obs_geo_ecl[3] when the Earth is evaluated on device
 BYTES_PER_RESULT = 96          # outfit_gauss_result_t
@@ -289,7 +294,8 @@ def roofline_block(ktimes, n_obj, steps, step_s, bytes_per_obj, workload, object
     alg_step = n_obj * bytes_per_obj
     if w is not None:
         sc = n_obj / w["objects_per_step"]
-        tot_instr = tot_f64i = tot_ops = tot_bytes = 0.0
+        tot_instr = tot_f64i = tot_ops = tot_bytes = tot_cyc = tot_cyc_s = 0.0
+        clocks_known = True
         for k in sorted(pick, key=lambda k: -ktimes[k][0]):
             rows = _pmc_rows(w, k)
             if not rows:
@@ -301,11 +307,24 @@ def roofline_block(ktimes, n_obj, steps, step_s, bytes_per_obj, workload, object
             thr = sum(r.get("thread_cycles_valu", 0.0) for r in rows)
             act = sum(r.get("active_inst_valu", 0.0) for r in rows)
             ms = ktimes[k][0] / steps
-            tot_instr += instr; tot_f64i += f64i; tot_ops += ops; tot_bytes += byt
+            trans = sum(r.get("fp64_trans_wave_instr", 0.0) for r in rows) * sc
+            cyc = (instr - trans) * ISSUE_CYCLES_PLAIN + trans * ISSUE_CYCLES_TRANS_F64   # SIMD-cycles of pure issue
+            ghz = [r["engine_clock_ghz"] for r in rows if r.get("engine_clock_ghz")]
+            # (short kernels that overlap others read above the 2.4 GHz maximum: capped)
+            clock_hz = min(1e9 * sum(ghz) / len(ghz), NOMINAL_CLOCK_HZ) if ghz and k in MAIN_STREAM_KERNELS else None
+            tot_instr += instr; tot_f64i += f64i; tot_ops += ops; tot_bytes += byt; tot_cyc += cyc
+            if clock_hz:
+                tot_cyc_s += cyc / N_SIMDS / clock_hz
+            elif k in MAIN_STREAM_KERNELS:
+                clocks_known = False
             per_kernel.append({
                 "kernel": k, "stream": "main" if k in MAIN_STREAM_KERNELS else "side (overlapped; its time includes waiting for CUs)",
                 "ms_per_step": ms, "valu_wave_instr_per_step": instr,
                 "issue_frac": instr / VALU_ISSUE_PEAK / (ms * 1e-3) if ms > 0 else None,
+                # the same with the measured cost of each instruction class, at the nominal and at the measured clock
+                "issue_cycle_frac": cyc / N_SIMDS / NOMINAL_CLOCK_HZ / (ms * 1e-3) if ms > 0 and trans > 0 else None,
+                "clock_ghz_under_load": clock_hz / 1e9 if clock_hz else None,
+                "issue_cycle_frac_at_measured_clock": cyc / N_SIMDS / clock_hz / (ms * 1e-3) if ms > 0 and trans > 0 and clock_hz else None,
                 "lanes_per_instruction": thr / act if act > 0 else None,
                 "non_fp64_share": 1.0 - f64i / instr if instr > 0 and f64i > 0 else None,
                 "counter_bytes_per_step": byt, "counter_over_algorithmic_bytes": byt / alg_step})
@@ -313,7 +332,15 @@ def roofline_block(ktimes, n_obj, steps, step_s, bytes_per_obj, workload, object
                 traffic = byt * steps / launches
         issue = {"step_wave_instr": tot_instr, "step_issue_frac": tot_instr / VALU_ISSUE_PEAK / step_s,
                  "peak_wave_instr_per_s": VALU_ISSUE_PEAK,
-                 "peak_is": "1024 SIMDs x 2.4 GHz / 4 cycles per 64-lane fp64 instruction"}
+                 "peak_is": "1024 SIMDs x 2.4 GHz / 4 cycles per 64-lane fp64 instruction",
+                 # every instruction at its MEASURED issue cost (profiles/round04_issue_cost_gfx950.json): 4 cycles, the
+                 # TRANS class (v_rcp / v_rsq / v_sqrt_f64: every division and square root holds one) 16
+                 "step_issue_cycle_frac": tot_cyc / N_SIMDS / NOMINAL_CLOCK_HZ / step_s if tot_cyc > tot_instr * ISSUE_CYCLES_PLAIN else None,
+                 # ... and each main-stream kernel at the shader clock measured under this load (GRBM_GUI_ACTIVE /
+                 # duration, 2.1 - 2.3 GHz, not the 2.4 GHz of the peak): the share of the step in which a SIMD issues
+                 "step_issue_cycle_frac_at_measured_clock": tot_cyc_s / step_s if clocks_known and tot_cyc_s > 0 else None,
+                 "cycles_per_instruction": {"fp64_add_mul_fma_and_others": ISSUE_CYCLES_PLAIN, "fp64_trans": ISSUE_CYCLES_TRANS_F64,
+                                            "source": "profiles/round04_issue_cost_gfx950.json"}}
         if tot_ops > 0:
             tf = tot_ops / step_s / 1e12
             executed = {"fp64_lane_ops_per_object_upper": tot_ops / n_obj, "achieved_tflops": tf,

@@ -354,6 +354,90 @@ __device__ __forceinline__ double prelim_kepuni(const KeplerProblem& p) {
   return prelim_parabolic(p);
 }
 
+// prelim_kepuni for the TWO solves of one correction iteration's cold start (t1 <- t2 and t3 <- t2): the problems differ
+// in dt only, and everything of the elliptic / hyperbolic cold start that does not depend on dt — acos(c) or ln(c + ..),
+// the sine / hyperbolic pair at the start value, the reference mean anomaly — is the same value in both calls of the
+// reference (prelim_elliptic.rs:72-134, prelim_hyperbolic.rs:45-141); it is evaluated once here. Same bits as two calls
+// of prelim_kepuni.
+__device__ __forceinline__ void prelim_kepuni_pair(const KeplerProblem& p, double dt_a, double dt_b, double& out_a,
+                                                   double& out_b) {
+  if (p.alpha < 0.0) {
+    const double contr = p.convergency;
+    const double a0 = -1.0 / p.alpha;
+    const double n = sqrt(kMu) * sqrt(-(p.alpha * p.alpha * p.alpha));
+    if (p.e0 < contr) {
+      out_a = n * dt_a / sqrt(-p.alpha);
+      out_b = n * dt_b / sqrt(-p.alpha);
+      return;
+    }
+    const double c = (1.0 - p.r0 / a0) / p.e0;
+    double u0;
+    if (fabs(c) <= 1.0) u0 = p.math_mode == kMathGlibc ? glm::acos(c) : crm::acos(c);
+    else if (c >= 1.0) u0 = 0.0;
+    else u0 = kPi;
+    if (p.sig0 < 0.0) u0 = -u0;
+    u0 = principal_angle(u0);
+    double su0, cu0;
+    if (p.math_mode == kMathGlibc) su0 = glm::sin1(u0); else crm::sincos(u0, su0, cu0);
+    const double m0 = principal_angle(u0 - p.e0 * su0);
+#pragma unroll 1
+    for (int side = 0; side < 2; ++side) {
+      const double m = m0 + n * (side ? dt_b : dt_a);
+      double u = m;
+#pragma unroll 1
+      for (int i = 0; i < p.max_iter_prelim; ++i) {
+        K2ASTAT(4);
+        double su, cu;
+        sincos_mode(p.math_mode, u, su, cu);
+        const double res = u - p.e0 * su - m;
+        const double der = 1.0 - p.e0 * cu;
+        const double step = -res / der;
+        u += step;
+        if (fabs(step) < contr * 1e3) break;
+      }
+      const double r = (u - u0) / sqrt(-p.alpha);
+      if (side) out_b = r; else out_a = r;
+    }
+    return;
+  }
+  if (p.alpha > 0.0) {
+    const double a0 = -1.0 / p.alpha;
+    const double n = sqrt(kMu) * sqrt(p.alpha * p.alpha * p.alpha);
+    const double c = (1.0 - p.r0 / a0) / p.e0;
+    double f0 = (c > 1.0) ? (p.math_mode == kMathGlibc ? glm::log(c + sqrt(c * c - 1.0)) : crm::log(c + sqrt(c * c - 1.0))) : 0.0;
+    if (p.sig0 < 0.0) f0 = -f0;
+    double sh0, ch0;
+    sinhcosh_mode(p.math_mode, f0, sh0, ch0);
+    const double m_base = p.e0 * sh0 - f0;
+#pragma unroll 1
+    for (int side = 0; side < 2; ++side) {
+      const double m = m_base + n * (side ? dt_b : dt_a);
+      double f = 0.0, sh, ch;
+#pragma unroll 1
+      for (int i = 0; i < p.max_iter_prelim; ++i) {
+        if (fabs(f) < 15.0) {
+          sinhcosh_mode(p.math_mode, f, sh, ch);
+          const double res = p.e0 * sh - f - m;
+          const double der = p.e0 * ch - 1.0;
+          const double cand = f + (-res / der);
+          f = (f * cand < 0.0) ? f / 2.0 : cand;
+        } else {
+          f /= 2.0;
+        }
+        if (fabs(f) < p.convergency * 1e3) break;
+      }
+      const double r = (f - f0) / sqrt(p.alpha);
+      if (side) out_b = r; else out_a = r;
+    }
+    return;
+  }
+  KeplerProblem q = p;
+  q.dt = dt_a;
+  out_a = prelim_parabolic(q);
+  q.dt = dt_b;
+  out_b = prelim_parabolic(q);
+}
+
 struct KeplerSolution {
   double psi;
   Stumpff s;

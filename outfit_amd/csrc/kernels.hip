@@ -378,8 +378,10 @@ k_gauss_roots(RootsArgs a) {
   const bool slow = !vc.ok || fabs(dt01) <= kEps || fabs(dt21) <= kEps;
   K2ASTAT(3);
   if (!slow) {
-    a.W.psi0[cid] = prelim_kepuni(velocity_problem(vc, dt01, a.P.kepler_eps, a.P.math_mode));
-    a.W.psi0[n + cid] = prelim_kepuni(velocity_problem(vc, dt21, a.P.kepler_eps, a.P.math_mode));
+    double psi01, psi21;  // the two cold starts share everything but dt (kepler.hpp prelim_kepuni_pair)
+    prelim_kepuni_pair(velocity_problem(vc, dt01, a.P.kepler_eps, a.P.math_mode), dt01, dt21, psi01, psi21);
+    a.W.psi0[cid] = psi01;
+    a.W.psi0[n + cid] = psi21;
   }
   a.W.flags[cid] = kFlagOk | (nf << kFlagRootsShift) | (slot << kFlagFirstShift) | (slow ? kFlagSlow : 0u);
   if (slow) append_slow(a.W, cid);
@@ -791,8 +793,7 @@ k_gauss_correct(CorrectArgs a) {
               st.chi01 = odd ? other : mine;
               st.chi21 = odd ? mine : other;
             } else {
-              st.chi01 = prelim_kepuni(velocity_problem(st.vc, dt01, a.P.kepler_eps, a.P.math_mode));
-              st.chi21 = prelim_kepuni(velocity_problem(st.vc, dt21, a.P.kepler_eps, a.P.math_mode));
+              prelim_kepuni_pair(velocity_problem(st.vc, dt01, a.P.kepler_eps, a.P.math_mode), dt01, dt21, st.chi01, st.chi21);
             }
           }
           break;

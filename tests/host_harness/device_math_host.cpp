@@ -66,6 +66,19 @@ void kepler_array(unsigned long long n, const double* prob, int math_mode, doubl
     sol[6 * i + 2] = s.s.s0; sol[6 * i + 3] = s.s.s1; sol[6 * i + 4] = s.s.s2; sol[6 * i + 5] = s.s.s3;
   }
 }
+// the shared cold start of an iteration's two solves: out[4 i ..] = pair(dt, -0.6 dt), prelim_kepuni(dt), prelim_kepuni(-0.6 dt)
+void kepler_pair_array(unsigned long long n, const double* prob, int math_mode, double* out) {
+  for (unsigned long long i = 0; i < n; ++i) {
+    KeplerProblem p;
+    p.dt = prob[6 * i]; p.r0 = prob[6 * i + 1]; p.sig0 = prob[6 * i + 2]; p.alpha = prob[6 * i + 3];
+    p.e0 = prob[6 * i + 4]; p.convergency = prob[6 * i + 5]; p.math_mode = math_mode;
+    const double dt_b = -0.6 * p.dt;
+    prelim_kepuni_pair(p, p.dt, dt_b, out[4 * i], out[4 * i + 1]);
+    out[4 * i + 2] = prelim_kepuni(p);
+    p.dt = dt_b;
+    out[4 * i + 3] = prelim_kepuni(p);
+  }
+}
 // in: x1[3] x2[3] v2[3] dt has_guess chi (12 per case); out: ok v[3] f g chi (7 per case)
 void velocity_correction_array(unsigned long long n, const double* in, double peri_max, double ecc_max, double eps,
                                int math_mode, double* out) {

@@ -33,11 +33,16 @@ def test_counter_fields_follow_the_source_hash(monkeypatch):
     if matches:   # the committed profile was taken from this build: the line says what limits the path
         assert r["counters"]["source_hash"] == bench.source_hash() and r["traffic"] > 0
         assert 0.3 < r["issue"]["step_issue_frac"] < 1.0
+        # measured issue costs (4 cycles, TRANS 16) and the measured clock raise the fraction, never above 1
+        assert r["issue"]["step_issue_frac"] < r["issue"]["step_issue_cycle_frac"] < 1.0
+        assert r["issue"]["step_issue_cycle_frac"] < r["issue"]["step_issue_cycle_frac_at_measured_clock"] < 1.0
         assert 0.1 < r["fp64_executed"]["frac"] < 1.0
         assert r["step_traffic"]["ratio"] > 1.0
         rows = {row["kernel"]: row for row in r["per_kernel"]}
         for k in ("k_gauss_roots", "k_gauss_correct_fast", "k_orbit_rms"):
             assert 30.0 < rows[k]["lanes_per_instruction"] <= 64.0 and 0.0 < rows[k]["issue_frac"] < 1.2
+            assert rows[k]["issue_frac"] < rows[k]["issue_cycle_frac"] < rows[k]["issue_cycle_frac_at_measured_clock"] < 1.2
+            assert 1.8 < rows[k]["clock_ghz_under_load"] <= 2.4
         for w in ("noise_default", "noise_8d", "lsq_default", "lsq_ratio10", "lsq_no_divergence_check"):
             assert w in pmc["workloads"], w
     else:

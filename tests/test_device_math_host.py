@@ -143,6 +143,23 @@ def test_stumpff_cold_starts_and_newton_device_equals_oracle(D, mode):
                 assert same_bits(np.ascontiguousarray(got), exp).all(), (i, prob[i], got, exp)
 
 
+@pytest.mark.parametrize("mode", [0, 1], ids=["correctly_rounded", "glibc"])
+def test_shared_cold_start_of_the_two_solves_equals_two_cold_starts(D, mode):
+    """K2a's fused cold start evaluates the dt-independent part of prelim_kepuni once for the iteration's two solves
+    (kepler.hpp prelim_kepuni_pair): same bits as the two separate calls, which the test above holds against the oracle."""
+    rng = np.random.default_rng(113 + mode)
+    m = 20000
+    prob = _kepler_problems(rng, m)
+    prob[:40, 3] = 0.0                       # parabolic branch
+    prob[40:80, 4] = 1e-20                   # e0 below the convergence threshold
+    out = np.empty(4 * m)
+    D.kepler_pair_array(C.c_uint64(m), _p(prob), C.c_int(mode), _p(out))
+    out = out.reshape(m, 4)
+    assert same_bits(np.ascontiguousarray(out[:, 0]), np.ascontiguousarray(out[:, 2])).all()
+    assert same_bits(np.ascontiguousarray(out[:, 1]), np.ascontiguousarray(out[:, 3])).all()
+    assert (prob[:, 3] > 0).sum() > 100 and (prob[:, 3] < 0).sum() > 100
+
+
 def test_velocity_correction_device_equals_oracle(D):
     L = O.lib()
     rng = np.random.default_rng(15)

@@ -85,6 +85,7 @@ if ccw.get(k_cal) and cal_w.get((k_cal, "WRITE_SIZE")):
     write_factor = CAL_BYTES / (cal_w[(k_cal, "WRITE_SIZE")] * 1024 / ccw[k_cal])
 # engine clock under load: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / kernel duration, from the same pass's kernel trace
 clk_lines = []
+clock_ghz = {}   # kernel -> shader clock under the bench load (headline workload)
 try:
     cyc, dur = collections.defaultdict(float), {}
     for f in glob.glob(os.path.join(src, "pmc_clk", "**", "*counter_collection.csv"), recursive=True):
@@ -101,6 +102,7 @@ try:
             agg[k][1] += dur[d]
     for k, (c, t) in sorted(agg.items()):
         clk_lines.append("%-24s GRBM_GUI_ACTIVE %.3e cycles over %.3e ns -> %.2f GHz per XCD (sum / 8)" % (k, c, t, c / t / 8.0))
+        clock_ghz[k] = c / t / 8.0
 except (OSError, KeyError, ValueError):
     pass
 source_hash = None
@@ -182,6 +184,7 @@ def kernel_rows(kernel_names, sq_, cs_, fetch_, cf_, write_, cw_, f64_, c64_, la
         rows[k] = {"hbm_bytes_per_step": fb + wb, "fetch_bytes": fb, "write_bytes": wb,
                    "fp64_wave_instr": g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64") + g("SQ_INSTS_VALU_FMA_F64")
                                       + g("SQ_INSTS_VALU_TRANS_F64"),
+                   "fp64_trans_wave_instr": g("SQ_INSTS_VALU_TRANS_F64"),   # v_rcp / v_rsq / v_sqrt_f64: 16 issue cycles each
                    "fp64_lane_ops_upper": 64.0 * (g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64")
                                                   + 2.0 * g("SQ_INSTS_VALU_FMA_F64") + g("SQ_INSTS_VALU_TRANS_F64")),
                    "valu_wave_instr": per(sq_, cs_, "SQ_INSTS_VALU"),
@@ -196,6 +199,9 @@ pmc = {"source": f"profiles/{name}_rocprof_summary.md (rocprofv3 --pmc FETCH_SIZ
        "source_hash": source_hash, "fetch_factor": fetch_factor, "write_factor": write_factor,
        "objects_per_step": n_obj,
        "kernels": kernel_rows(kernels, sq, cs, fetch, cf, write, cw, f64, c64, lanes, cl), "workloads": {}}
+for k_, ghz in clock_ghz.items():
+    if k_ in pmc["kernels"]:
+        pmc["kernels"][k_]["engine_clock_ghz"] = ghz
 pmc["workloads"]["headline"] = {"objects_per_step": n_obj, "kernels": pmc["kernels"]}
 # the extra workloads of tools/profile_gpu.sh (bench.py --workload W: only that region ran in the process)
 WORKLOAD_OBJECTS = {"long_arcs_100": 10000, "long_arcs_300": 10000}
