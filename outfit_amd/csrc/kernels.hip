@@ -1050,16 +1050,21 @@ k_orbit_rms_wave(RmsArgs a) {
 #endif
 constexpr double kContenderWindow = OUTFIT_CONTENDER_WINDOW;  // relative part of K3b's contender rule (see k_refine_best)
 constexpr unsigned kSelTile = 16;
-__global__ void __launch_bounds__(64)
+// Launched with 256 threads per 64 trajectories for throughput, with 1024 for small batches: the staging phase of a tile
+// — loads, one division and one square root per candidate — runs on 4 / 16 waves instead of one (a lone wave issues an
+// instruction every ~5 cycles: with 16 workgroups on the whole device K3 was 0.11 ms of a 1.05 ms step at 1 000
+// trajectories, now 0.05; 0.19 -> 0.16 ms at 100 000); the fold itself stays with the first wave, one lane per trajectory.
+__global__ void __launch_bounds__(1024)
 k_select_best(SelectArgs a) {
   __shared__ unsigned s_list[64][kContenderListCap];  // K3b's contenders, collected against the running bound
   __shared__ double s_sum[64][kSelTile + 1];
+  __shared__ double s_den[64][kSelTile + 1];   // 2 n_win
+  __shared__ double s_rms[64][kSelTile + 1];   // sqrt(sum / (2 n_win)): evaluated by the staging lanes, see below
   __shared__ unsigned s_flags[64][kSelTile + 1];
-  __shared__ unsigned s_nwin[64][kSelTile + 1];
   const unsigned tl = threadIdx.x;
   const unsigned long long blk0 = (unsigned long long)blockIdx.x * 64;
-  const unsigned long long lt = blk0 + tl;
-  const bool live = lt < a.n_traj;
+  const unsigned long long lt = blk0 + (tl & 63u);
+  const bool live = tl < 64u && lt < a.n_traj;   // threads beyond the first wave only stage
   GaussResultRec out;
   out.status = 0; out.cause = 0; out.stage = 0; out.kind = 0;
   out.attempts = 0; out.best_triplet = 0; out.best_realization = 0;
@@ -1079,21 +1084,38 @@ k_select_best(SelectArgs a) {
   unsigned n_list = 0;  // kContenderOverflow once more than kContenderListCap candidates have passed
   if (a.bound && live) {
     double sig = INFINITY;
-    for (unsigned long long o = a.traj_offset[a.traj0 + lt]; o < a.traj_offset[a.traj0 + lt + 1]; ++o)
-      sig = fmin(sig, fmin(fabs(a.sra[o]), fabs(a.sdec[o])));
+    // four observations per pass (indices clamped to the last one: a repeated element does not change a minimum), so
+    // that the eight loads of a pass are in flight together instead of one dependent load per observation
+    const unsigned long long o0 = a.traj_offset[a.traj0 + lt], o1 = a.traj_offset[a.traj0 + lt + 1];
+    for (unsigned long long o = o0; o < o1; o += 4) {
+      double m[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned long long ok = o + k < o1 ? o + k : o1 - 1;
+        m[k] = fmin(fabs(a.sra[ok]), fabs(a.sdec[ok]));
+      }
+      sig = fmin(sig, fmin(fmin(m[0], m[1]), fmin(m[2], m[3])));
+    }
     inv_sigma = 1.0 / sig;
   }
   for (unsigned cb = 0; cb < a.cand_per_traj; cb += kSelTile) {
     // does any trajectory of this wave still need candidates from this tile on?
     const bool want = live && !aborted && cb < n_c;
-    if (__ballot(want) == 0ull) break;
-    for (unsigned idx = tl; idx < 64u * kSelTile; idx += 64u) {
+    if (!__syncthreads_or(want)) break;   // (also the barrier between the previous tile's fold and this tile's staging)
+    for (unsigned idx = tl; idx < 64u * kSelTile; idx += blockDim.x) {
       const unsigned row = idx / kSelTile, cc = idx % kSelTile;
       const unsigned long long g = (blk0 + row) * a.cand_per_traj + cb + cc;
       const bool in = (blk0 + row) < a.n_traj && cb + cc < a.cand_per_traj;
       s_flags[row][cc] = in ? a.W.flags[g] : kFlagEmpty;
-      s_nwin[row][cc] = in ? a.W.n_win[g] : 0u;
-      s_sum[row][cc] = in ? a.W.sum[g] : 0.0;
+      // the candidate's RMS — the division and the square root of the fold below — is evaluated HERE, by the 64 lanes
+      // on independent candidates, instead of inside the fold's dependent chain (one lane, ~100 candidates in a row,
+      // each waiting for the previous `best`): the operations and operands are the fold's, so are the bits; a value the
+      // fold does not use (candidate without a sum, pruned, trajectory aborted) is simply not read
+      const double den = 2.0 * (double)(in ? a.W.n_win[g] : 0u);
+      const double sm = in ? a.W.sum[g] : 0.0;
+      s_sum[row][cc] = sm;
+      s_den[row][cc] = den;
+      s_rms[row][cc] = sqrt(sm / den);
     }
     __syncthreads();
     if (want) {
@@ -1107,19 +1129,16 @@ k_select_best(SelectArgs a) {
         if (conv) { out.status = (int)conv; aborted = true; break; }      // to_equinoctial()? (quirk Q2)
         // rms_orbit_error with prune_if_rms_ge = Some(best): the partial sums are
         // non-decreasing, so "some partial sum >= cutoff" == "final sum >= cutoff".
-        const double denom = 2.0 * (double)s_nwin[tl][cc];
+        const double denom = s_den[tl][cc];
         const double cutoff = isfinite(best) ? best * best * denom : INFINITY;
         double rms;
         if (f & kFlagRmsErr) rms = best;
-        else {
-          const double sm = s_sum[tl][cc];
-          rms = (sm >= cutoff) ? best : sqrt(sm / denom);
-        }
+        else rms = (s_sum[tl][cc] >= cutoff) ? best : s_rms[tl][cc];  // == sqrt(sum / denom)
         if (!isfinite(rms)) { last_error = 4; continue; }  // NonFiniteScore
         if (a.bound && !(f & kFlagRmsErr)) {
           // K3b's contender rule (see k_refine_best), applied with the bound as it stands: the final bound is no larger,
           // so whatever passes the final test passes this one — the list is a superset of the contenders
-          const double screened = sqrt(s_sum[tl][cc] / denom);
+          const double screened = s_rms[tl][cc];
           const double slack = screen_slack_rad((f & kFlagLevelMask) >> kFlagLevelShift) * inv_sigma;
           bound = fmin(bound, screened + slack);
           if (screened <= bound * (1.0 + kContenderWindow) + slack) {
@@ -1130,7 +1149,6 @@ k_select_best(SelectArgs a) {
         if (rms < best) { best = rms; best_c = (long long)c; }
       }
     }
-    __syncthreads();
   }
   if (!live) return;
   if (a.bound) {
@@ -1418,7 +1436,11 @@ hipError_t launch_refine_best(const SelectArgs& a, const RmsArgs& r, hipStream_t
 #endif
   static const int inject_fail = std::getenv("OUTFIT_TEST_EXACT_RMS_FAILS") != nullptr;  // test aid, see the kernel
   // small batch (the chunk's candidates, as for the correction kernels' forms): 16 lanes per trajectory
-  const unsigned group = use_pair_form(a.n_cand) ? 16u : 4u;
+  static const char* forced_group = std::getenv("OUTFIT_REFINE_GROUP");  // measurement aid: 4 or 16 lanes per evaluation
+  // 16 lanes up to 16 384 trajectories (measured, ms at 4 / 16 lanes: 10 000 trajectories 0.23 / 0.16, 20 000 0.24 / 0.22,
+  // 40 000 0.32 / 0.41, 100 000 0.64 / 0.93)
+  const unsigned group = forced_group ? (std::atoi(forced_group) == 16 ? 16u : 4u)
+                                      : (use_pair_form(a.n_cand) || a.n_traj <= 16384) ? 16u : 4u;
   const dim3 grid((unsigned)((a.n_traj + 64 / group - 1) / (64 / group)));
   const bool glibc = a.math_mode == kMathGlibc;
   static const bool use_list = std::getenv("OUTFIT_REFINE_SCAN_ALL") == nullptr;  // measurement / test aid: sweep every candidate
@@ -1896,7 +1918,16 @@ hipError_t launch_orbit_rms(const RmsArgs& a, bool slow_list, hipStream_t s) {
 hipError_t launch_select_best(const SelectArgs& a, hipStream_t s) {
   if (a.n_traj == 0) return hipSuccess;
   const unsigned grid = (unsigned)((a.n_traj + 63) / 64);
-  hipLaunchKernelGGL(k_select_best, dim3(grid), dim3(64), 0, s, a);
+  // small batches: 16 waves stage each tile (see the kernel); OUTFIT_K3_THREADS = 64 .. 1024 forces a shape (measurement aid)
+  static const char* forced_once = std::getenv("OUTFIT_K3_THREADS");
+  const char* forced = forced_once ? forced_once : std::getenv("OUTFIT_K3_THREADS_TEST");  // (_TEST: re-read per launch)
+  // (100 000 trajectories: 64 threads 0.31 ms, 128 0.22, 256 0.16, 1024 0.36; 10 000: 0.11 / 0.06 at 64 / 256)
+  unsigned threads = a.n_traj <= 4096 ? 1024u : 256u;
+  if (forced) {
+    const long v = std::strtol(forced, nullptr, 10);
+    if (v >= 64 && v <= 1024 && v % 64 == 0) threads = (unsigned)v;
+  }
+  hipLaunchKernelGGL(k_select_best, dim3(grid), dim3(threads), 0, s, a);
   return hipGetLastError();
 }
 hipError_t launch_propagate_universal(unsigned long long n, const double* rv, const double* t0,

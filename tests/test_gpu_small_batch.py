@@ -75,3 +75,23 @@ def test_lane_pair_form_with_noisy_realisations(monkeypatch):
     ds["noise_z"] = synth.SplitMix64(9).normal(500 * params.max_triplets * params.n_noise_realizations * 6)
     batch, ephem = outfit_amd.ObsBatch.from_dict(ds), outfit_amd.Ephemeris.from_dict(e)
     _same(_run(batch, ephem, params, monkeypatch, False), _run(batch, ephem, params, monkeypatch, True))
+
+
+def test_fold_kernel_launch_shapes_agree(monkeypatch):
+    """K3 (k_select_best) stages each tile of candidates with 1 024 threads per 64 trajectories for small batches and with
+    256 for throughput (64: the single-wave form); the fold itself is the first wave's either way: same records, same contender lists (read through
+    K3b's result), on a noisy batch (210 candidates per trajectory: 14 tiles) and a bench batch."""
+    e = synth.make_ephemeris()
+    ephem = outfit_amd.Ephemeris.from_dict(e)
+    ds = synth.make_dataset(700, seed=31, ephem=e)
+    p_noise = outfit_amd.IODParams()
+    ds_noise = dict(ds)
+    ds_noise["noise_z"] = synth.SplitMix64(10).normal(700 * p_noise.max_triplets * p_noise.n_noise_realizations * 6)
+    for data, params in ((ds, synth.bench_params(outfit_amd.IODParams())), (ds_noise, p_noise)):
+        batch = outfit_amd.ObsBatch.from_dict(data)
+        got = {}
+        for threads in ("64", "256", "1024"):
+            monkeypatch.setenv("OUTFIT_K3_THREADS_TEST", threads)
+            got[threads] = _run(batch, ephem, params, monkeypatch, None)
+        _same(got["64"], got["256"])
+        _same(got["64"], got["1024"])
