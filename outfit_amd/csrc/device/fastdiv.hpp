@@ -63,6 +63,51 @@ __device__ __forceinline__ void div2_shared(double a1, double a2, double b, doub
   q2 = div_with_rcp(a2, b, y);
 }
 
+// ---- guarded divisions: the fast forms WITHOUT their per-division window test --------------------------------------
+// The window test above is a divergent branch per division (two compares, exec bookkeeping, the plain sequence as the
+// other arm): measured, it costs what the short sequence saves (K2b 6.45 -> 6.58 ms). A Guard instead RECORDS the
+// magnitude of every operand that goes through a fast division — smallest one, and the sum (an upper bound of the
+// largest that also turns NaN / Inf when an operand is) — two instructions per operand, and the caller tests it ONCE
+// for a whole stretch of work: if any operand was zero, outside [2^-300, 2^300] or not finite, nothing computed in that
+// stretch is used and the work is redone with plain divisions (K2b: the candidate is handed to the general kernel,
+// which is built without a guard). Inside the window the fast forms return the bits of `/` (selftest on 2^27 operands,
+// tests/test_gpu_parity.py::test_fast_division_is_exact), so results never depend on which path ran.
+// A null guard = plain divisions: every other caller of the functions that take one.
+struct Guard {
+  double lo, sum;
+  __device__ __forceinline__ void reset() { lo = 1.0; sum = 0.0; }
+  __device__ __forceinline__ void see(double a) {
+    const double ax = fabs(a);
+    sum += ax;
+    lo = fmin(lo, ax);
+  }
+  __device__ __forceinline__ bool ok() const { return lo >= 4.909093465297727e-91 && sum <= 2.037035976334486e+90; }
+};
+// a / c, c a compile-time constant of moderate magnitude, rc == RN(1 / c)
+__device__ __forceinline__ double div_const(double a, double c, double rc, Guard* g) {
+  if (!g) return a / c;
+  g->see(a);
+  const double q0 = a * rc;
+  return fma(fma(-q0, c, a), rc, q0);
+}
+// (a[0] / b, .., a[N-1] / b): velocity.rs:155-157 divides the three components of the corrected velocity by the same g,
+// eccentricity_control 1 and mu by the same |r|
+template <int N>
+__device__ __forceinline__ void divn_shared(const double (&a)[N], double b, double (&q)[N], Guard* g) {
+  if (!g) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) q[k] = a[k] / b;
+    return;
+  }
+  g->see(b);
+  const double y = refined_rcp(b);
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    g->see(a[k]);
+    q[k] = div_with_rcp(a[k], b, y);
+  }
+}
+
 // Stumpff-series denominators and their correctly-rounded reciprocals, term j = 1..70:
 //   s2 series: (2j+1)(2j+2)      s3 series: (2j+2)(2j+3)
 struct SeriesTable {

@@ -359,7 +359,7 @@ __device__ __forceinline__ unsigned descartes_upper_bound(double c0, double c3, 
 // gauss.rs:702-724 ; false = SpuriousRootDetected
 __device__ __forceinline__ bool position_and_epoch(const Mat3& obs, const Mat3& S, const Mat3& Sinv,
                                                    double t_mid, const Vec3& c, double min_rho2, Mat3& pos,
-                                                   double& epoch) {
+                                                   double& epoch, fdiv::Guard* guard = nullptr) {
   const Vec3 gcap = gemv(obs, c);
   const Vec3 crhom = gemv(Sinv, gcap);
   const double rho0 = -(crhom.x / c.x), rho1 = -(crhom.y / c.y), rho2 = -(crhom.z / c.z);
@@ -370,7 +370,7 @@ __device__ __forceinline__ bool position_and_epoch(const Mat3& obs, const Mat3& 
     pos.m[r][1] = obs.m[r][1] + rho1 * S.m[r][1];
     pos.m[r][2] = obs.m[r][2] + rho2 * S.m[r][2];
   }
-  epoch = t_mid - rho1 / kVlightAU;
+  epoch = t_mid - div_by_vlight(rho1, guard);
   return true;
 }
 
@@ -421,7 +421,10 @@ struct CorrectionState {
   VelCommon vc;          // velocity.rs:105-129 evaluated on (pos[:,1], vel): shared by both sides
 };
 
-enum CorrStep { kCorrContinue = 0, kCorrSome = 1, kCorrNone = 2, kCorrSlow = 3 };
+// kCorrRedo (fast kernel only): an operand of one of the iteration's guarded divisions (fastdiv.hpp Guard) was zero,
+// outside the window or not finite — nothing of this iteration is used, the general kernel (plain divisions) replays the
+// candidate from its first root
+enum CorrStep { kCorrContinue = 0, kCorrSome = 1, kCorrNone = 2, kCorrSlow = 3, kCorrRedo = 4 };
 
 // ONE iteration of the loop at gauss.rs:1316-1415. `continue` in the reference = return
 // kCorrContinue here (the iteration is consumed, the state is kept).
@@ -454,9 +457,9 @@ __device__ __forceinline__ double pair_swap(double x) {  // the partner lane's x
   return __hiloint2double(hi, lo);
 }
 template <bool kFast, bool kWarmOnly = kFast, class Params = GaussParams, bool kPair = false>
-__device__ __forceinline__ CorrStep correction_iteration(const Mat3& obs, const Mat3& S, const Mat3& Sinv,
-                                                         double t_mid, double dt01, double dt21,
-                                                         const Params& P, CorrectionState& st) {
+__device__ __forceinline__ CorrStep correction_iteration_impl(const Mat3& obs, const Mat3& S, const Mat3& Sinv,
+                                                              double t_mid, double dt01, double dt21,
+                                                              const Params& P, CorrectionState& st, fdiv::Guard* G) {
   KSTAT(3);
   st.it += 1;
   const bool last = st.it >= P.newton_max_it;
@@ -494,11 +497,11 @@ __device__ __forceinline__ CorrStep correction_iteration(const Mat3& obs, const 
     const double dt = side ? dt21 : dt01;
     const double chi = side ? st.chi21 : st.chi01;
     const KeplerProblem p = velocity_problem(st.vc, dt, P.kepler_eps, P.math_mode);
-    const KeplerSolution sol = kWarmOnly ? run_newton(p, chi) : solve_kepuni(p, side ? st.has21 : st.has01, chi);
+    const KeplerSolution sol = kWarmOnly ? run_newton(p, chi, G) : solve_kepuni(p, side ? st.has21 : st.has01, chi, G);
 #ifdef OUTFIT_K2B_STATS  // histogram of Newton rounds per solve: first iteration of a candidate (cold start) / later ones
     atomicAdd(&g_kstat[(st.it == 1 ? 24 : 16) + (sol.rounds < 7 ? sol.rounds : 7)], 1ull);
 #endif
-    const VelCorr vc = velocity_finish(sol, side ? r3 : r1, r2, st.vc.r2, dt);
+    const VelCorr vc = velocity_finish(sol, side ? r3 : r1, r2, st.vc.r2, dt, G);
     if (side) b = vc; else a = vc;
   }
   }
@@ -518,10 +521,10 @@ __device__ __forceinline__ CorrStep correction_iteration(const Mat3& obs, const 
   Mat3 np;
   double ne;
   KSTAT(5);
-  if (!position_and_epoch(obs, S, Sinv, t_mid, c, P.min_rho2_au, np, ne)) return skip;  // common
+  if (!position_and_epoch(obs, S, Sinv, t_mid, c, P.min_rho2_au, np, ne, G)) return skip;  // common
   KSTAT(6);
   const Vec3 nr2 = column(np, 1);
-  const EccControl ec = eccentricity_control(nr2, nv, P.max_perihelion_au, P.max_ecc);
+  const EccControl ec = eccentricity_control(nr2, nv, P.max_perihelion_au, P.max_ecc, G);
   if (!ec.some || !ec.accepted) return kFast ? kCorrSlow : kCorrNone;
   const double denom = frob(np);
   if (!isfinite(denom) || denom <= kEps) return skip;
@@ -534,9 +537,28 @@ __device__ __forceinline__ CorrStep correction_iteration(const Mat3& obs, const 
   st.pos = np;
   st.vel = nv;
   st.epoch = ne;
-  st.vc = velocity_common_from(ec, nr2, nv);
+  st.vc = velocity_common_from(ec, nr2, nv, G);
   if (rel <= P.newton_eps) return kCorrSome;
   return last ? kCorrSome : kCorrContinue;
+}
+// The throughput form of the fast kernel runs the iteration's divisions by constants and by shared denominators in their
+// short forms under a guard (fastdiv.hpp) and asks for a replay with plain divisions if the guard saw an operand outside
+// the window in which the short forms are the bits of `/`; every other caller gets the plain divisions.
+#ifndef OUTFIT_GUARDED_DIVISIONS
+#define OUTFIT_GUARDED_DIVISIONS 1
+#endif
+template <bool kFast, bool kWarmOnly = kFast, class Params = GaussParams, bool kPair = false>
+__device__ __forceinline__ CorrStep correction_iteration(const Mat3& obs, const Mat3& S, const Mat3& Sinv,
+                                                         double t_mid, double dt01, double dt21,
+                                                         const Params& P, CorrectionState& st) {
+  if constexpr (kFast && !kPair && OUTFIT_GUARDED_DIVISIONS) {
+    fdiv::Guard guard;
+    guard.reset();
+    const CorrStep step = correction_iteration_impl<kFast, kWarmOnly, Params, kPair>(obs, S, Sinv, t_mid, dt01, dt21, P, st, &guard);
+    return guard.ok() ? step : kCorrRedo;
+  } else {
+    return correction_iteration_impl<kFast, kWarmOnly, Params, kPair>(obs, S, Sinv, t_mid, dt01, dt21, P, st, nullptr);
+  }
 }
 
 }  // namespace outfit

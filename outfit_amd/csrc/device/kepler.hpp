@@ -56,6 +56,18 @@ constexpr double kMu = kGaussGrav * kGaussGrav;               // constants.rs:73
 constexpr double kAU = 149597870.7;                           // constants.rs:37
 constexpr double kVlightAU = 2.99792458e5 / kAU * 86400.0;    // constants.rs:79
 
+// a / c for the reference's physical constants through a guard (fastdiv.hpp: 3 operations + 2 of bookkeeping instead of
+// the 11-instruction, 58-cycle division sequence, profiles/round04_issue_cost_gfx950.json); plain `/` without one.
+// sqrt(kMu) is folded by the compiler (correctly rounded: the value the device's own square root returns).
+__device__ __forceinline__ double div_by_sqrt_mu(double a, fdiv::Guard* g) {
+  const double c = sqrt(kMu);
+  return fdiv::div_const(a, c, 1.0 / c, g);
+}
+__device__ __forceinline__ double div_by_mu(double a, fdiv::Guard* g) { return fdiv::div_const(a, kMu, 1.0 / kMu, g); }
+__device__ __forceinline__ double div_by_vlight(double a, fdiv::Guard* g) {
+  return fdiv::div_const(a, kVlightAU, 1.0 / kVlightAU, g);
+}
+
 struct Vec3 {
   double x, y, z;
 };
@@ -84,14 +96,14 @@ struct Stumpff {
 
 // kepler/stumpff.rs:78-297. Power series while |alpha psi^2| < 100, otherwise
 // halve psi, expand s0/s1 and apply the duplication formulas.
-__device__ __forceinline__ Stumpff s_funct(double psi, double alpha) {
+__device__ __forceinline__ Stumpff s_funct(double psi, double alpha, fdiv::Guard* guard = nullptr) {
   constexpr double tol = 100.0 * kEps, ovf = 1.0 / kEps;
   if (psi == 0.0) return {1.0, 0.0, 0.0, 0.0};
   const double psi2 = psi * psi;
   const double beta = alpha * psi2;
   if (fabs(beta) < 100.0) {
     double s2 = 0.5 * psi2, t2 = s2;
-    double s3 = (s2 * psi) / 3.0, t3 = s3;
+    double s3 = fdiv::div_const(s2 * psi, 3.0, 1.0 / 3.0, guard), t3 = s3;  // (s2 psi) / 3
     // term j divides by the integer constants (2j+1)(2j+2) and (2j+2)(2j+3): exact quotient
     // from the tabulated correctly-rounded reciprocal (fastdiv.hpp), same bits as `/`
     const bool fast = fdiv::in_window(beta);
@@ -449,7 +461,7 @@ struct KeplerSolution {
 
 // kepler/newton_solver.rs:151-161,240-352 (SolverKind::NewtonRaphson)
 // run_newton (newton_solver.rs:240-352) from a given start value
-__device__ __forceinline__ KeplerSolution run_newton(const KeplerProblem& p, double psi) {
+__device__ __forceinline__ KeplerSolution run_newton(const KeplerProblem& p, double psi, fdiv::Guard* guard = nullptr) {
   const double sqrt_mu = sqrt(kMu);
   const double res_tol = 10.0 * kEps * (1.0 + fabs(sqrt_mu * p.dt));
   KeplerSolution out;
@@ -462,7 +474,7 @@ __device__ __forceinline__ KeplerSolution run_newton(const KeplerProblem& p, dou
     out.rounds = it + 1;
 #endif
     if (!isfinite(psi)) { psi = 0.5; continue; }
-    const Stumpff s = s_funct(psi, p.alpha);
+    const Stumpff s = s_funct(psi, p.alpha, guard);
     const double residual = p.r0 * s.s1 + p.sig0 * s.s2 + s.s3 - sqrt_mu * p.dt;
     const double derivative = p.r0 * s.s0 + p.sig0 * s.s1 + s.s2;
     if (fabs(residual) <= res_tol) { out.psi = psi; out.s = s; out.ok = true; break; }
@@ -477,15 +489,16 @@ __device__ __forceinline__ KeplerSolution run_newton(const KeplerProblem& p, dou
     }
     if (sa <= p.convergency * (1.0 + fabs(psi))) {
       KSTAT(2);
-      out.psi = psi; out.s = s_funct(psi, p.alpha); out.ok = true; break;
+      out.psi = psi; out.s = s_funct(psi, p.alpha, guard); out.ok = true; break;
     }
   }
   return out;
 }
 
 // solve_kepuni_with_guess (newton_solver.rs:151-161): psi_guess or the cold-start value
-__device__ __forceinline__ KeplerSolution solve_kepuni(const KeplerProblem& p, bool has_guess, double guess) {
-  return run_newton(p, has_guess ? guess : prelim_kepuni(p));
+__device__ __forceinline__ KeplerSolution solve_kepuni(const KeplerProblem& p, bool has_guess, double guess,
+                                                       fdiv::Guard* guard = nullptr) {
+  return run_newton(p, has_guess ? guess : prelim_kepuni(p), guard);
 }
 
 // kepler/brent_dekker_solver.rs:59-62
@@ -568,7 +581,7 @@ struct EccControl {
 
 // orb_elem.rs:257-301
 __device__ __forceinline__ EccControl eccentricity_control(const Vec3& r, const Vec3& v, double peri_max,
-                                                  double ecc_max) {
+                                                  double ecc_max, fdiv::Guard* guard = nullptr) {
   EccControl o;
   const double v2 = dot(v, v);
   const double dist = norm(r);
@@ -578,12 +591,17 @@ __device__ __forceinline__ EccControl eccentricity_control(const Vec3& r, const 
   o.h_norm = sqrt(h2);
   o.some = !(o.h_norm == 0.0);
   const Vec3 vxh = cross(v, h);
-  const double inv_mu = 1.0 / kMu, inv_d = 1.0 / dist;
+  // 1 / |r| and mu / |r| (the energy, below) share their denominator
+  const double inv_mu = 1.0 / kMu;
+  const double one_mu[2] = {1.0, kMu};
+  double over_d[2];
+  fdiv::divn_shared<2>(one_mu, dist, over_d, guard);
+  const double inv_d = over_d[0];
   const Vec3 lenz = {vxh.x * inv_mu - r.x * inv_d, vxh.y * inv_mu - r.y * inv_d,
                      vxh.z * inv_mu - r.z * inv_d};
   o.ecc = norm(lenz);
   o.peri = h2 / (kMu * (1.0 + o.ecc));
-  o.energy = v2 / 2.0 - kMu / dist;
+  o.energy = v2 / 2.0 - over_d[1];
   o.accepted = (o.ecc < ecc_max) && (o.peri < peri_max);
   return o;
 }
@@ -620,11 +638,12 @@ __device__ __forceinline__ VelCommon velocity_common(const Vec3& x2, const Vec3&
 }
 // the same, from an eccentricity_control already evaluated on (x2, v2): norm(x2) and
 // norm(x2 x v2) are the very values eccentricity_control computed (same operation order)
-__device__ __forceinline__ VelCommon velocity_common_from(const EccControl& ec, const Vec3& x2, const Vec3& v2) {
+__device__ __forceinline__ VelCommon velocity_common_from(const EccControl& ec, const Vec3& x2, const Vec3& v2,
+                                                          fdiv::Guard* guard = nullptr) {
   VelCommon c;
   c.r2 = ec.dist;
-  c.sig0 = dot(x2, v2) / sqrt(kMu);
-  c.alpha = 2.0 * ec.energy / kMu;
+  c.sig0 = div_by_sqrt_mu(dot(x2, v2), guard);
+  c.alpha = div_by_mu(2.0 * ec.energy, guard);
   c.e0 = ec.ecc;
   c.ok = isfinite(ec.h_norm) && !(ec.h_norm <= 1e6 * kEps) && ec.some;
   return c;
@@ -637,15 +656,18 @@ __device__ __forceinline__ KeplerProblem velocity_problem(const VelCommon& c, do
 }
 // Lagrange f, g and the corrected velocity from a Kepler solution (velocity.rs:144-161)
 __device__ __forceinline__ VelCorr velocity_finish(const KeplerSolution& sol, const Vec3& x1, const Vec3& x2,
-                                                   double r2, double dt) {
+                                                   double r2, double dt, fdiv::Guard* guard = nullptr) {
   VelCorr o;
   o.ok = false;
   if (!sol.ok) return o;
   const double f = 1.0 - sol.s.s2 / r2;
-  const double g = dt - sol.s.s3 / sqrt(kMu);
+  const double g = dt - div_by_sqrt_mu(sol.s.s3, guard);
   const double ga = fabs(g);
   if (!isfinite(ga) || ga < 100.0 * kEps * (1.0 + fabs(dt))) return o;
-  o.v = {((-f) * x2.x + x1.x) / g, ((-f) * x2.y + x1.y) / g, ((-f) * x2.z + x1.z) / g};
+  const double num[3] = {(-f) * x2.x + x1.x, (-f) * x2.y + x1.y, (-f) * x2.z + x1.z};
+  double q[3];
+  fdiv::divn_shared<3>(num, g, q, guard);  // three components over the same g
+  o.v = {q[0], q[1], q[2]};
   o.f = f; o.g = g; o.chi = sol.psi;
   o.ok = true;
   return o;

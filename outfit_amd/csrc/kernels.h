@@ -132,6 +132,8 @@ struct CorrectArgs {
   CandidateScratch W;
   GaussParams P;
   unsigned long long* queue;  // work-queue head (zeroed before every launch)
+  unsigned test_redo_mod;     // test aid (OUTFIT_TEST_GUARD_REDO=m): the fast kernel reports kCorrRedo — "a guarded division
+                              // saw an operand outside its window" — for every (candidate + iteration) divisible by m
 };
 
 struct RmsArgs {

@@ -646,10 +646,11 @@ k_gauss_correct_fast(CorrectArgs a) {
 #else
     const GaussParams& P = a.P;
 #endif
-    const CorrStep step = correction_iteration<true, true, std::remove_cv_t<std::remove_reference_t<decltype(P)>>, kPair>(
+    CorrStep step = correction_iteration<true, true, std::remove_cv_t<std::remove_reference_t<decltype(P)>>, kPair>(
         obs, S, Sinv, t_mid, dt01, dt21, P, st);
     const unsigned long long ucand = (unsigned long long)cand;
-    if (step == kCorrSome || step == kCorrSlow) {
+    if (a.test_redo_mod && (ucand + st.it) % a.test_redo_mod == 0) step = kCorrRedo;  // test aid, see CorrectArgs
+    if (step == kCorrSome || step == kCorrSlow || step == kCorrRedo) {
 #if OUTFIT_KERNARG_LAZY_PARAMS
       const CandidateScratch W = kernarg_field<CandidateScratch>((unsigned)offsetof(CorrectArgs, W));
 #else
@@ -666,10 +667,15 @@ k_gauss_correct_fast(CorrectArgs a) {
         W.state[5 * n + ucand] = st.vel.z;
         W.state[6 * n + ucand] = st.epoch;
         W.flags[ucand] = kFlagOk | kFlagCorrected;
-      } else {
+      } else if (step == kCorrSlow) {
         // None inside the loop (eccentricity_control rejected an iterate): the root walk continues in the general
         // kernel, which does not replay this root's loop; kFlagSlow also selects the second RMS pass
         W.flags[ucand] |= kFlagSlow | kFlagFirstNone;
+        append_slow(W, ucand);
+      } else {
+        // kCorrRedo: a guarded division met an operand outside its window (gauss.hpp): the general kernel replays the
+        // candidate from its first root with plain divisions
+        W.flags[ucand] |= kFlagSlow;
         append_slow(W, ucand);
       }
       cand = -1;
@@ -1513,6 +1519,45 @@ k_selftest_division(unsigned long long n_per_thread, unsigned long long seed, un
     const double c3 = fdiv::div_const(beta, d3, fdiv::kSeries.r3[j]);
     bad += (__double_as_longlong(c2) != __double_as_longlong(beta / d2));
     bad += (__double_as_longlong(c3) != __double_as_longlong(beta / d3));
+    // the guarded forms of the correction loop (kepler.hpp div_by_*, s_funct's / 3, velocity_finish's three quotients
+    // over one g, eccentricity_control's pair): inside the guard's window they are the bits of `/`, and the guard
+    // reports every operand outside it (zero, tiny, huge, Inf, NaN)
+    {
+      fdiv::Guard g;
+      g.reset();
+      const double sqrt_mu = sqrt(kMu);
+      const double v1 = div_by_sqrt_mu(beta, &g), v2 = div_by_mu(beta, &g), v3 = div_by_vlight(beta, &g);
+      const double v4 = fdiv::div_const(beta, 3.0, 1.0 / 3.0, &g);
+      double num[3], q[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) num[k] = random_double(s, er);
+      if ((it & 63) == 9) num[2] = INFINITY;
+      if ((it & 63) == 10) num[1] = nan("");
+      if ((it & 63) == 11) num[0] = 0.0;
+      if ((it & 63) == 12) num[0] = -0.0;
+      fdiv::divn_shared<3>(num, b, q, &g);
+      const double one_mu[2] = {1.0, kMu};
+      double over[2];
+      fdiv::divn_shared<2>(one_mu, b, over, &g);
+      bool in = fdiv::in_window(beta) && fdiv::in_window(b);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) in = in && fdiv::in_window(num[k]);
+      if (g.ok()) {
+        bad += !in;  // the guard may only pass when every operand is inside the window
+        bad += (__double_as_longlong(v1) != __double_as_longlong(beta / sqrt_mu));
+        bad += (__double_as_longlong(v2) != __double_as_longlong(beta / kMu));
+        bad += (__double_as_longlong(v3) != __double_as_longlong(beta / kVlightAU));
+        bad += (__double_as_longlong(v4) != __double_as_longlong(beta / 3.0));
+#pragma unroll
+        for (int k = 0; k < 3; ++k) bad += (__double_as_longlong(q[k]) != __double_as_longlong(num[k] / b));
+        bad += (__double_as_longlong(over[0]) != __double_as_longlong(1.0 / b));
+        bad += (__double_as_longlong(over[1]) != __double_as_longlong(kMu / b));
+      }
+      // (the converse is not required: the guard tests the SUM of the magnitudes against the upper limit, which is
+      //  conservative; with operands of ordinary size it passes — the bench run hands no candidate over for it)
+      // without a guard: the plain divisions
+      bad += (__double_as_longlong(div_by_sqrt_mu(beta, nullptr)) != __double_as_longlong(beta / sqrt_mu));
+    }
   }
   if (bad) atomicAdd(mismatches, bad);
 }
@@ -1853,8 +1898,11 @@ hipError_t launch_gauss_correct_fast(const CorrectArgs& a, unsigned n_cu, hipStr
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_kstat), zero, sizeof zero);
   }
 #endif
-  if (pair) hipLaunchKernelGGL(k_gauss_correct_fast<true>, dim3(grid), dim3(kFastBlock), lds, s, a);
-  else hipLaunchKernelGGL(k_gauss_correct_fast<false>, dim3(grid), dim3(kFastBlock), lds, s, a);
+  const char* redo = std::getenv("OUTFIT_TEST_GUARD_REDO");  // test aid (CorrectArgs::test_redo_mod), read per launch
+  CorrectArgs b = a;
+  b.test_redo_mod = redo ? (unsigned)std::strtoul(redo, nullptr, 10) : 0u;
+  if (pair) hipLaunchKernelGGL(k_gauss_correct_fast<true>, dim3(grid), dim3(kFastBlock), lds, s, b);
+  else hipLaunchKernelGGL(k_gauss_correct_fast<false>, dim3(grid), dim3(kFastBlock), lds, s, b);
 #ifdef OUTFIT_K2B_STATS
   {
     unsigned long long h[8] = {};

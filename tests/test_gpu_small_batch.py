@@ -31,11 +31,11 @@ def _run(batch, ephem, params, monkeypatch, pair):
     return rec, total, n_win, flags
 
 
-def _same(a, b):
+def _same(a, b, ignore_flags=0):
     rec_a, sum_a, win_a, fl_a = a
     rec_b, sum_b, win_b, fl_b = b
     assert rec_a.tobytes() == rec_b.tobytes()
-    assert np.array_equal(fl_a, fl_b)
+    assert np.array_equal(fl_a & ~np.uint32(ignore_flags), fl_b & ~np.uint32(ignore_flags))
     scored = ((fl_a & 0x10) != 0) & ((fl_a >> 8 & 0x7) == 0) & ((fl_a & 0x80) == 0) & ((fl_a & 0x80000000) == 0)
     assert np.array_equal(win_a[scored], win_b[scored]) and sum_a[scored].tobytes() == sum_b[scored].tobytes()
 
@@ -95,3 +95,28 @@ def test_fold_kernel_launch_shapes_agree(monkeypatch):
             got[threads] = _run(batch, ephem, params, monkeypatch, None)
         _same(got["64"], got["256"])
         _same(got["64"], got["1024"])
+
+
+def test_guarded_divisions_hand_over_equals_plain_divisions(monkeypatch):
+    """The throughput form of the fast correction kernel runs the iteration's divisions by constants and by shared
+    denominators in their short forms under a range guard (device/fastdiv.hpp) and hands a candidate to the general
+    kernel — plain divisions, replay from the first root — when the guard saw an operand outside its window (kCorrRedo).
+    With OUTFIT_TEST_GUARD_REDO=m the kernel reports that for every (candidate + iteration) divisible by m, so that a
+    third / a seventh of all iterations end in a hand-over: every byte must be what the undisturbed run returns, in the
+    one-lane form (guarded) and in the lane-pair form (plain divisions, same hand-over)."""
+    e = synth.make_ephemeris()
+    ephem = outfit_amd.Ephemeris.from_dict(e)
+    batch = outfit_amd.ObsBatch.from_dict(synth.make_dataset(2500, seed=41, ephem=e, topocentric=True))
+    for kw in ({}, dict(max_ecc=0.35, max_perihelion_au=3.5)):
+        params = synth.bench_params(outfit_amd.IODParams())
+        for k, v in kw.items():
+            setattr(params, k, v)
+        monkeypatch.delenv("OUTFIT_TEST_GUARD_REDO", raising=False)
+        plain = _run(batch, ephem, params, monkeypatch, False)
+        assert (plain[0]["status"] == 0).sum() > 1500
+        for mod in ("3", "7"):
+            monkeypatch.setenv("OUTFIT_TEST_GUARD_REDO", mod)
+            # (a handed-over candidate carries kFlagSlow: which kernel finished it — nothing else may differ)
+            _same(plain, _run(batch, ephem, params, monkeypatch, False), ignore_flags=0x100000)
+            _same(plain, _run(batch, ephem, params, monkeypatch, True), ignore_flags=0x100000)
+        monkeypatch.delenv("OUTFIT_TEST_GUARD_REDO", raising=False)
