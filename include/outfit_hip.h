@@ -538,8 +538,12 @@ int         outfit_hip_device_count(void);
  *               OUTFIT_PAIR_MODE (0 / 1: throughput / latency forms of K2a, K2b, K3b whatever the batch size),
  *               OUTFIT_REFINE_SCAN_ALL (K3b sweeps every candidate instead of reading K3's contender list),
  *               OUTFIT_RMS_EXACT_ALL, OUTFIT_RMS_NO_SCREEN (K2c exact for every candidate), OUTFIT_RMS_WAVE,
- *               OUTFIT_K0_SLICES, OUTFIT_GENERAL_SERIAL, OUTFIT_NO_STREAMED_UPLOAD, OUTFIT_DIFFCOR_GROUP.
- * Fault injection for tests: OUTFIT_CACHE_POISON (NaN-fill device blocks), OUTFIT_TEST_EXACT_RMS_FAILS. */
+ *               OUTFIT_K0_SLICES, OUTFIT_GENERAL_SERIAL, OUTFIT_NO_STREAMED_UPLOAD, OUTFIT_DIFFCOR_GROUP,
+ *               OUTFIT_K3_THREADS (64 .. 1024 threads staging a tile of K3), OUTFIT_REFINE_GROUP (4 / 16 lanes per
+ *               exact evaluation in K3b).
+ * Fault injection for tests: OUTFIT_CACHE_POISON (NaN-fill device blocks), OUTFIT_TEST_EXACT_RMS_FAILS,
+ *               OUTFIT_TEST_GUARD_REDO (m: every (candidate + iteration) divisible by m is reported as a guarded-division
+ *               hit in the fast correction kernel and replayed by the general one). */
 
 #ifdef __cplusplus
 }
