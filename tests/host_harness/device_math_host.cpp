@@ -155,8 +155,12 @@ double angular_diff_host(double a, double b) { return angular_diff(a, b); }
 // (pos, vel, chi01, chi21) tuple, carried eccentricity_control) that the reference's 50-iteration loop does not have.
 // in per case: obs[9] (m[r][k] row-major), S[9], t[3], root (22); out: accepted, outcome (1 Some / 0 None), pos column 1 [3],
 // vel[3], epoch, iterations consumed (10)
+// `guarded` != 0: the iterations in the fast kernel's form (correction_iteration<true, false>: divisions by constants
+// and by shared denominators in their short forms under fdiv::Guard); out[9] = -1 when an iteration reported kCorrRedo
+// (a guard hit: the device would replay the candidate with plain divisions), kCorrSlow counts as None.
 void correction_loop_array(unsigned long long n, const double* in, double max_ecc, double max_peri, double min_rho2,
-                           double kepler_eps, double newton_eps, unsigned newton_max_it, int math_mode, double* out) {
+                           double kepler_eps, double newton_eps, unsigned newton_max_it, int math_mode, int guarded,
+                           double* out) {
   GaussParams P{};
   P.max_ecc = max_ecc; P.max_perihelion_au = max_peri; P.min_rho2_au = min_rho2; P.kepler_eps = kepler_eps;
   P.newton_eps = newton_eps; P.newton_max_it = newton_max_it; P.math_mode = math_mode;
@@ -178,10 +182,12 @@ void correction_loop_array(unsigned long long n, const double* in, double max_ec
     if (fabs(dt01) <= kEps || fabs(dt21) <= kEps) continue;  // gauss.rs:1311-1313: None
     st.epoch = 0.0; st.has01 = false; st.has21 = false; st.chi01 = st.chi21 = 0.0; st.it = 0;
     CorrStep step = kCorrContinue;
-    while (step == kCorrContinue) step = correction_iteration<false, false>(obs, S, Sinv, t[1], dt01, dt21, P, st);
+    while (step == kCorrContinue)
+      step = guarded ? correction_iteration<true, false>(obs, S, Sinv, t[1], dt01, dt21, P, st)
+                     : correction_iteration<false, false>(obs, S, Sinv, t[1], dt01, dt21, P, st);
     o[1] = step == kCorrSome ? 1.0 : 0.0;
     o[2] = st.pos.m[0][1]; o[3] = st.pos.m[1][1]; o[4] = st.pos.m[2][1];
-    o[5] = st.vel.x; o[6] = st.vel.y; o[7] = st.vel.z; o[8] = st.epoch; o[9] = st.it;
+    o[5] = st.vel.x; o[6] = st.vel.y; o[7] = st.vel.z; o[8] = st.epoch; o[9] = step == kCorrRedo ? -1.0 : st.it;
   }
 }
 }

@@ -349,7 +349,7 @@ def test_correction_loop_with_its_early_exits_equals_the_literal_loop(D, mode):
                                   O.M33, O.D3, _dp]
     ds = synth.make_dataset(150, seed=47)
     rng = np.random.default_rng(21)
-    total = some = none_ = early = 0
+    total = some = none_ = early = guarded_cases = 0
     for kw in (dict(), dict(max_ecc=0.35, max_perihelion_au=3.5), dict(newton_max_it=7), dict(min_rho2_au=0.5)):
         ip = IODParams(n_noise_realizations=0, **kw).as_c()
         with O.math_flags(libm=0, glibc=mode):
@@ -386,8 +386,17 @@ def test_correction_loop_with_its_early_exits_equals_the_literal_loop(D, mode):
         out = np.empty(10 * len(cases))
         D.correction_loop_array(C.c_uint64(len(cases)), _p(inp), C.c_double(ip.max_ecc), C.c_double(ip.max_perihelion_au),
                                 C.c_double(ip.min_rho2_au), C.c_double(ip.kepler_eps), C.c_double(ip.newton_eps),
-                                C.c_uint(ip.newton_max_it), C.c_int(mode), _p(out))
+                                C.c_uint(ip.newton_max_it), C.c_int(mode), C.c_int(0), _p(out))
         out = out.reshape(-1, 10)
+        # the fast kernel's form of the iteration: short divisions under the range guard — the same bytes, no guard hit
+        fast = np.empty(10 * len(cases))
+        D.correction_loop_array(C.c_uint64(len(cases)), _p(inp), C.c_double(ip.max_ecc), C.c_double(ip.max_perihelion_au),
+                                C.c_double(ip.min_rho2_au), C.c_double(ip.kepler_eps), C.c_double(ip.newton_eps),
+                                C.c_uint(ip.newton_max_it), C.c_int(mode), C.c_int(1), _p(fast))
+        fast = fast.reshape(-1, 10)
+        assert (fast[:, 9] >= 0).all(), "a guarded division reported an operand outside its window on ordinary data"
+        assert same_bits(np.ascontiguousarray(fast), np.ascontiguousarray(out)).all()
+        guarded_cases += len(cases)
         for k, ref in enumerate(refs):
             assert (ref["accepted"] != 0) == (out[k, 0] == 1.0), (kw, k)
             if not ref["accepted"]:
@@ -400,4 +409,4 @@ def test_correction_loop_with_its_early_exits_equals_the_literal_loop(D, mode):
                 early += out[k, 9] < ip.newton_max_it
             else:
                 none_ += 1
-    assert total > 600 and some > 500 and none_ > 5 and early > 200, (total, some, none_, early)
+    assert total > 600 and some > 500 and none_ > 5 and early > 200 and guarded_cases > 600, (total, some, none_, early)
