@@ -435,10 +435,28 @@ void sort_permutation(const outfit_obs_batch_t* b, std::vector<uint64_t>& perm) 
   perm.clear();
   if (!b->n_traj || !b->mjd_tt) return;
   const uint64_t o0 = b->traj_offset[0];
+  // the check reads every epoch once (16 MB for 2 x 10^6 observations: ~1 ms on one core, in front of the first
+  // kernel of a blocking call): large batches are checked by up to four threads, a range of trajectories each
+  auto range_sorted = [b](uint64_t t0, uint64_t t1) {
+    for (uint64_t t = t0; t < t1; ++t)
+      for (uint64_t i = b->traj_offset[t] + 1; i < b->traj_offset[t + 1]; ++i)
+        if (total_order_key(b->mjd_tt[i - 1]) > total_order_key(b->mjd_tt[i])) return false;
+    return true;
+  };
   bool sorted = true;
-  for (uint64_t t = 0; t < b->n_traj && sorted; ++t)
-    for (uint64_t i = b->traj_offset[t] + 1; i < b->traj_offset[t + 1]; ++i)
-      if (total_order_key(b->mjd_tt[i - 1]) > total_order_key(b->mjd_tt[i])) { sorted = false; break; }
+  const uint64_t n_all = b->traj_offset[b->n_traj] - o0;
+  const unsigned n_thr = n_all >= (1u << 18) && b->n_traj >= 4 ? 4u : 1u;
+  if (n_thr == 1) {
+    sorted = range_sorted(0, b->n_traj);
+  } else {
+    bool ok[4] = {true, true, true, true};
+    std::thread th[3];
+    for (unsigned k = 1; k < n_thr; ++k)
+      th[k - 1] = std::thread([&, k] { ok[k] = range_sorted(b->n_traj * k / n_thr, b->n_traj * (k + 1) / n_thr); });
+    ok[0] = range_sorted(0, b->n_traj / n_thr);
+    for (unsigned k = 1; k < n_thr; ++k) th[k - 1].join();
+    sorted = ok[0] && ok[1] && ok[2] && ok[3];
+  }
   if (sorted) return;
   const uint64_t n = b->traj_offset[b->n_traj] - o0;
   perm.resize(n);
