@@ -1180,12 +1180,12 @@ k_select_best(SelectArgs a) {
       out.best_realization = (unsigned)best_c % a.n_real;
       // build_result -> compute_orbit_from_state -> ccek1 (gauss.rs:906-923,1063-1076) for the winner, with the
       // correctly-rounded functions: these are the elements the caller gets
-      const unsigned long long nc = a.n_cand;
-      const Vec3 r2 = {a.W.state[0 * nc + cid], a.W.state[1 * nc + cid], a.W.state[2 * nc + cid]};
-      const Vec3 v2 = {a.W.state[3 * nc + cid], a.W.state[4 * nc + cid], a.W.state[5 * nc + cid]};
-      out.epoch = a.W.state[6 * nc + cid];
       out.rms = best;
-      if (!a.bound) {  // (with K3b behind it the winner and its elements are K3b's to write)
+      if (!a.bound) {  // (with K3b behind it the winner, its epoch, rms and elements are K3b's to write: no gather here)
+        const unsigned long long nc = a.n_cand;
+        const Vec3 r2 = {a.W.state[0 * nc + cid], a.W.state[1 * nc + cid], a.W.state[2 * nc + cid]};
+        const Vec3 v2 = {a.W.state[3 * nc + cid], a.W.state[4 * nc + cid], a.W.state[5 * nc + cid]};
+        out.epoch = a.W.state[6 * nc + cid];
         // correctly rounded, or glibc's bits (atan2 included) in the glibc-faithful mode
         const Elements el = a.math_mode == kMathGlibc ? ccek1<kFnGlibc>(equ_to_ecl(r2), equ_to_ecl(v2), out.epoch)
                                                       : ccek1<kFnCr>(equ_to_ecl(r2), equ_to_ecl(v2), out.epoch, kMathCr);
@@ -1278,7 +1278,10 @@ constexpr unsigned kRefineList = 256;  // contenders a wave holds between two ev
 // (the small-batch form, 16 lanes per trajectory, is compiled for 2 waves per SIMD: there are few waves and their chain is
 // what counts, so no spills)
 template <int kFn, unsigned kRefineGroup>  // kFnGlibc: the glibc-faithful mode; kFnPlatform: the correctly-rounded mode's RMS (platform functions)
-__global__ void __launch_bounds__(64, kRefineGroup == 16u ? 2 : 3)
+#ifndef OUTFIT_REFINE_WAVES
+#define OUTFIT_REFINE_WAVES 2
+#endif
+__global__ void __launch_bounds__(64, kRefineGroup == 16u ? 2 : OUTFIT_REFINE_WAVES)
 k_refine_best(RmsArgs r, GaussResultRec* out_all, const double* bound, const unsigned* list, unsigned long long n_traj,
               int inject_fail) {
   constexpr unsigned kRefineTraj = 64 / kRefineGroup;       // trajectories per wave
