@@ -150,6 +150,31 @@ void obs_partials_glibc(unsigned long long n, const double* eqs, const double* o
   }
 }
 double angular_diff_host(double a, double b) { return angular_diff(a, b); }
+// The guarded divisions of the fast correction kernel (fastdiv.hpp): per case a, b, n1, n2, n3 (5 doubles);
+// out per case: guard passed (1 / 0), then a / sqrt(mu), a / mu, a / c, a / 3, n1 / b, n2 / b, n3 / b, 1 / b, mu / b in
+// the short forms (9), then the same nine with `/` (9)
+void guarded_division_array(unsigned long long n, const double* in, double* out) {
+  const double sqrt_mu = sqrt(kMu);
+  for (unsigned long long i = 0; i < n; ++i) {
+    const double* q = in + 5 * i;
+    double* o = out + 19 * i;
+    fdiv::Guard g;
+    g.reset();
+    o[1] = div_by_sqrt_mu(q[0], &g); o[2] = div_by_mu(q[0], &g); o[3] = div_by_vlight(q[0], &g);
+    o[4] = fdiv::div_const(q[0], 3.0, 1.0 / 3.0, &g);
+    const double num[3] = {q[2], q[3], q[4]};
+    double r[3];
+    fdiv::divn_shared<3>(num, q[1], r, &g);
+    o[5] = r[0]; o[6] = r[1]; o[7] = r[2];
+    const double one_mu[2] = {1.0, kMu};
+    double w[2];
+    fdiv::divn_shared<2>(one_mu, q[1], w, &g);
+    o[8] = w[0]; o[9] = w[1];
+    o[0] = g.ok() ? 1.0 : 0.0;
+    o[10] = q[0] / sqrt_mu; o[11] = q[0] / kMu; o[12] = q[0] / kVlightAU; o[13] = q[0] / 3.0;
+    o[14] = q[2] / q[1]; o[15] = q[3] / q[1]; o[16] = q[4] / q[1]; o[17] = 1.0 / q[1]; o[18] = kMu / q[1];
+  }
+}
 // One root of one candidate through the device's accept_root and correction loop (gauss.hpp), as the general kernel runs
 // it: correction_iteration<false, false> until it ends — WITH the early exits of the device (fixed point of the
 // (pos, vel, chi01, chi21) tuple, carried eccentricity_control) that the reference's 50-iteration loop does not have.

@@ -410,3 +410,28 @@ def test_correction_loop_with_its_early_exits_equals_the_literal_loop(D, mode):
             else:
                 none_ += 1
     assert total > 600 and some > 500 and none_ > 5 and early > 200 and guarded_cases > 600, (total, some, none_, early)
+
+
+def test_guarded_divisions_equal_plain_divisions_inside_the_guard(D):
+    """fastdiv.hpp: the short forms of a division by a constant (Markstein's correction step from the correctly-rounded
+    reciprocal) and of several divisions by one denominator (one refined reciprocal), as the fast correction kernel runs
+    them under fdiv::Guard — whenever the guard passes, every quotient is the bits of `/`; operands that are zero, tiny,
+    huge or not finite never pass. (Here with an exact reciprocal seed; the device's own seed: outfit_hip_selftest_division.)"""
+    rng = np.random.default_rng(2026)
+    n = 400000
+    ordinary = rng.normal(size=(n, 5)) * 10.0 ** rng.uniform(-6, 6, (n, 5))
+    wide = rng.normal(size=(n // 4, 5)) * 10.0 ** rng.uniform(-200, 200, (n // 4, 5))
+    special = ordinary[:4000].copy()
+    for k, v in enumerate((0.0, -0.0, np.inf, -np.inf, np.nan, 1e-310, 1e-95, 1e95)):
+        special[k::8, k % 5] = v
+    cases = np.ascontiguousarray(np.concatenate([ordinary, wide, special]))
+    out = np.empty(19 * len(cases))
+    D.guarded_division_array(C.c_uint64(len(cases)), _p(cases), _p(out))
+    out = out.reshape(-1, 19)
+    passed = out[:, 0] == 1.0
+    assert passed[:n].all()                                             # ordinary operands: the guard never fires
+    bad = ~np.isfinite(cases).all(1) | (cases == 0).any(1) | (np.abs(cases) < 4.9e-91).any(1) | (np.abs(cases) > 2.04e90).any(1)
+    assert not (passed & bad).any()                                     # an operand outside the window never passes
+    assert (~passed[n:]).sum() > 1000 and passed[n:].sum() > 1000
+    fast, plain = np.ascontiguousarray(out[passed, 1:10]), np.ascontiguousarray(out[passed, 10:19])
+    assert same_bits(fast, plain).all()
