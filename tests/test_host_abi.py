@@ -269,3 +269,17 @@ def test_call_options_abi_v6_without_a_gpu(L):
     o.math_mode, o.struct_size = 1, 4
     h = C.c_void_p()
     assert L.outfit_hip_session_create_ex(C.byref(pc), C.byref(bc), C.byref(ec), 0, C.byref(o), C.byref(h)) == -1
+
+
+def test_issue_cost_microbenchmark_compiles(tmp_path):
+    """tools/issue_cost.hip (the measured cycles per instruction behind bench.py's cycle-weighted issue fractions,
+    profiles/round04_issue_cost_gfx950.json) is a stand-alone gfx950 program: it has to keep compiling."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "issue_cost.hip")
+    r = subprocess.run([hipcc, "-O2", "--offload-arch=gfx950", "-c", src, "-o", str(tmp_path / "issue_cost.o")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
