@@ -19,6 +19,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -451,10 +452,20 @@ void sort_permutation(const outfit_obs_batch_t* b, std::vector<uint64_t>& perm) 
   } else {
     bool ok[4] = {true, true, true, true};
     std::thread th[3];
-    for (unsigned k = 1; k < n_thr; ++k)
-      th[k - 1] = std::thread([&, k] { ok[k] = range_sorted(b->n_traj * k / n_thr, b->n_traj * (k + 1) / n_thr); });
+    unsigned started = 0;  // a thread that cannot be created (resource limits) leaves its range to this one: no exception
+    for (unsigned k = 1; k < n_thr; ++k) {  //                                                  may cross the C ABI
+      try {
+        th[k - 1] = std::thread([&ok, &range_sorted, b, k, n_thr] {
+          ok[k] = range_sorted(b->n_traj * k / n_thr, b->n_traj * (k + 1) / n_thr);
+        });
+        started = k;
+      } catch (const std::system_error&) {
+        break;
+      }
+    }
     ok[0] = range_sorted(0, b->n_traj / n_thr);
-    for (unsigned k = 1; k < n_thr; ++k) th[k - 1].join();
+    for (unsigned k = started + 1; k < n_thr; ++k) ok[k] = range_sorted(b->n_traj * k / n_thr, b->n_traj * (k + 1) / n_thr);
+    for (unsigned k = 1; k <= started; ++k) th[k - 1].join();
     sorted = ok[0] && ok[1] && ok[2] && ok[3];
   }
   if (sorted) return;
