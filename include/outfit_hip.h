@@ -45,6 +45,8 @@ extern "C" {
 #define OUTFIT_ERR_HIP           -4 /* a HIP runtime call failed                                                  */
 #define OUTFIT_ERR_EPHEM_RANGE   -5 /* an epoch lies outside the table (reference panics: horizon_data.rs:722-724)*/
 #define OUTFIT_ERR_BAD_HANDLE    -6
+#define OUTFIT_ERR_NO_MEMORY     -8 /* a host allocation (or any other C++ exception) failed inside the library: entry
+                                       points never let an exception cross the C ABI (-7: OUTFIT_ERR_EPHEM_FILE, below) */
 
 /* ---- per-trajectory status (outfit_gauss_result_t.status) ------------------
  * mirrors the Err variants `estimate_best_orbit` can return
@@ -487,6 +489,10 @@ int outfit_hip_device_normals(uint64_t noise_seed, const uint64_t *traj_key, uin
  * compares them with `/` on n_pairs pseudo-random operand pairs and returns the number
  * of differing results (must be 0). No counterpart in the reference. */
 int outfit_hip_selftest_division(uint64_t n_pairs, uint64_t seed, uint64_t *mismatches);
+/* Host self-test of the rule "no C++ exception crosses this ABI": raises std::bad_alloc (kind 0), std::runtime_error (1)
+ * or a non-standard exception (2) inside an entry point; must return OUTFIT_ERR_NO_MEMORY with outfit_hip_last_error()
+ * set. Needs no device. */
+int outfit_hip_selftest_abi_guard(int kind);
 /* Device self-test of the Aberth sweep that shares one refined reciprocal between the two components of
  * every complex division (outfit_amd/csrc/device/gauss.hpp) against the plain divisions, on n_polys random
  * sparse octics: counts[0] = polynomials whose return code or iterates differ in any bit (must be 0),

@@ -17,6 +17,7 @@ OUTFIT_ERR_HIP = -4
 OUTFIT_ERR_EPHEM_RANGE = -5
 OUTFIT_ERR_BAD_HANDLE = -6
 OUTFIT_ERR_EPHEM_FILE = -7
+OUTFIT_ERR_NO_MEMORY = -8
 
 TRAJ_OK = 0
 TRAJ_NO_FEASIBLE_TRIPLETS = 1

@@ -136,7 +136,7 @@ EXPORTED_SYMBOLS = [
     "outfit_hip_fit_lsq", "outfit_hip_session_run_lsq", "outfit_hip_session_lsq_results",
     "outfit_hip_solver_type_default", "outfit_hip_propagate_universal_ex", "outfit_hip_trim_cache", "outfit_hip_calibration_stream", "outfit_hip_glibc_eval", "outfit_hip_prelim_kepuni", "outfit_hip_set_math_mode", "outfit_hip_get_math_mode",
     "outfit_hip_call_options_default", "outfit_hip_fit_full_iod_ex", "outfit_hip_session_create_ex", "outfit_hip_fit_lsq_ex",
-    "outfit_hip_ephem_open", "outfit_hip_ephem_header", "outfit_hip_ephem_view", "outfit_hip_ephem_close", "outfit_hip_ephem_body_record",
+    "outfit_hip_selftest_abi_guard", "outfit_hip_ephem_open", "outfit_hip_ephem_header", "outfit_hip_ephem_view", "outfit_hip_ephem_close", "outfit_hip_ephem_body_record",
 ]
 
 

@@ -19,6 +19,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <stdexcept>
 #include <system_error>
 #include <thread>
 #include <vector>
@@ -73,6 +74,13 @@ int fail(int code, const std::string& msg) {
   g_last_error = msg;
   return code;
 }
+
+// Nothing may unwind through the C ABI (the caller is Rust, C or ctypes): every entry point that can allocate or start a
+// thread is a function-try-block ending in this handler.
+#define OUTFIT_ABI_CATCH                                                                               \
+  catch (const std::bad_alloc&) { return fail(OUTFIT_ERR_NO_MEMORY, "host allocation failed"); }       \
+  catch (const std::exception& e) { return fail(OUTFIT_ERR_NO_MEMORY, std::string("internal error: ") + e.what()); } \
+  catch (...) { return fail(OUTFIT_ERR_NO_MEMORY, "internal error: unknown exception"); }
 
 }  // namespace
 namespace outfit {
@@ -1099,28 +1107,28 @@ void outfit_hip_iod_params_default(outfit_iod_params_t* p) {
   p->newton_eps = 1.0e-10; p->newton_max_it = 50; p->root_imag_eps = 1.0e-6;
 }
 
-int outfit_hip_iod_params_validate(const outfit_iod_params_t* p) {
+int outfit_hip_iod_params_validate(const outfit_iod_params_t* p) try {
   if (!p) return fail(OUTFIT_ERR_INVALID_PARAM, "params is NULL");
   if (const char* m = validate_params(p)) return fail(OUTFIT_ERR_INVALID_PARAM, m);
   return OUTFIT_OK;
-}
+} OUTFIT_ABI_CATCH
 
 const char* outfit_hip_last_error(void) { return g_last_error.c_str(); }
 
-int outfit_hip_set_math_mode(int mode) {
+int outfit_hip_set_math_mode(int mode) try {
   if (mode != OUTFIT_MATH_CORRECTLY_ROUNDED && mode != OUTFIT_MATH_GLIBC)
     return fail(OUTFIT_ERR_INVALID_PARAM, "math mode must be OUTFIT_MATH_CORRECTLY_ROUNDED or OUTFIT_MATH_GLIBC");
   g_math_mode.store(mode);
   return OUTFIT_OK;
-}
+} OUTFIT_ABI_CATCH
 int outfit_hip_get_math_mode(void) { return current_math_mode(); }
 int outfit_hip_abi_version(void) { return OUTFIT_HIP_ABI_VERSION; }
 
-int outfit_hip_device_count(void) {
+int outfit_hip_device_count(void) try {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
-}
+} OUTFIT_ABI_CATCH
 
 }  // extern "C"
 namespace {
@@ -1136,15 +1144,15 @@ void outfit_hip_call_options_default(outfit_hip_call_options_t* o) {
 }
 int outfit_hip_session_create_ex(const outfit_iod_params_t* params, const outfit_obs_batch_t* batch,
                                  const outfit_ephem_t* ephem, int device, const outfit_hip_call_options_t* options,
-                                 outfit_hip_session_t** out) {
+                                 outfit_hip_session_t** out) try {
   int mode = 0;
   TRY_RC(resolve_math_mode(options, &mode));
   return session_create(params, batch, ephem, device, /*streaming=*/false, mode, out);
-}
+} OUTFIT_ABI_CATCH
 int outfit_hip_session_create(const outfit_iod_params_t* params, const outfit_obs_batch_t* batch,
-                              const outfit_ephem_t* ephem, int device, outfit_hip_session_t** out) {
+                              const outfit_ephem_t* ephem, int device, outfit_hip_session_t** out) try {
   return outfit_hip_session_create_ex(params, batch, ephem, device, nullptr, out);
-}
+} OUTFIT_ABI_CATCH
 }  // extern "C"
 namespace {
 int session_create(const outfit_iod_params_t* params, const outfit_obs_batch_t* batch, const outfit_ephem_t* ephem,
@@ -1173,13 +1181,13 @@ int session_create(const outfit_iod_params_t* params, const outfit_obs_batch_t* 
 }  // namespace
 extern "C" {
 
-int outfit_hip_session_run(outfit_hip_session_t* s, void* stream, void* d_out) {
+int outfit_hip_session_run(outfit_hip_session_t* s, void* stream, void* d_out) try {
   if (!s) return fail(OUTFIT_ERR_BAD_HANDLE, "session is NULL");
   hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : s->own_stream;
   return session_run(s, st, reinterpret_cast<outfit::GaussResultRec*>(d_out));
-}
+} OUTFIT_ABI_CATCH
 
-int outfit_hip_session_results(outfit_hip_session_t* s, outfit_gauss_result_t* out) {
+int outfit_hip_session_results(outfit_hip_session_t* s, outfit_gauss_result_t* out) try {
   if (!s || !out) return fail(OUTFIT_ERR_BAD_HANDLE, "session or out is NULL");
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(wait_last_run(s));
@@ -1190,14 +1198,14 @@ int outfit_hip_session_results(outfit_hip_session_t* s, outfit_gauss_result_t* o
     HIP_TRY(hipMemcpy(out, s->results.p, (size_t)s->n_traj * sizeof(outfit_gauss_result_t),
                       hipMemcpyDeviceToHost));
   return OUTFIT_OK;
-}
+} OUTFIT_ABI_CATCH
 
-int outfit_hip_trim_cache(void) {
+int outfit_hip_trim_cache(void) try {
   g_cache.trim();
   return OUTFIT_OK;
-}
+} OUTFIT_ABI_CATCH
 
-int outfit_hip_session_check(outfit_hip_session_t* s) {
+int outfit_hip_session_check(outfit_hip_session_t* s) try {
   if (!s) return fail(OUTFIT_ERR_BAD_HANDLE, "session is NULL");
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(wait_last_run(s));
@@ -1205,12 +1213,12 @@ int outfit_hip_session_check(outfit_hip_session_t* s) {
   HIP_TRY(hipMemcpy(&flag, s->error_flag.p, sizeof(int), hipMemcpyDeviceToHost));
   if (flag) return fail(OUTFIT_ERR_EPHEM_RANGE, "an observation epoch lies outside the ephemeris table");
   return OUTFIT_OK;
-}
+} OUTFIT_ABI_CATCH
 
 void* outfit_hip_session_device_results(outfit_hip_session_t* s) { return s ? s->results.p : nullptr; }
 
 int outfit_hip_session_candidate_scores(outfit_hip_session_t* s, uint64_t capacity, double* sum, uint32_t* n_win,
-                                        uint32_t* flags, uint64_t* n_out) {
+                                        uint32_t* flags, uint64_t* n_out) try {
   if (!s || !n_out) return fail(OUTFIT_ERR_BAD_HANDLE, "session or n_out is NULL");
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(wait_last_run(s));
@@ -1222,9 +1230,9 @@ int outfit_hip_session_candidate_scores(outfit_hip_session_t* s, uint64_t capaci
   if (n && n_win) HIP_TRY(hipMemcpy(n_win, s->n_win.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
   if (n && flags) HIP_TRY(hipMemcpy(flags, s->flags.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
   return OUTFIT_OK;
-}
+} OUTFIT_ABI_CATCH
 
-int outfit_hip_session_set_profiling(outfit_hip_session_t* s, int enabled) {
+int outfit_hip_session_set_profiling(outfit_hip_session_t* s, int enabled) try {
   if (!s) return fail(OUTFIT_ERR_BAD_HANDLE, "session is NULL");
   s->profiling = enabled != 0;
   if (s->profiling) {
@@ -1232,10 +1240,10 @@ int outfit_hip_session_set_profiling(outfit_hip_session_t* s, int enabled) {
     s->timed.clear();
   }
   return OUTFIT_OK;
-}
+} OUTFIT_ABI_CATCH
 
 int outfit_hip_session_kernel_times(outfit_hip_session_t* s, int max_n, const char** names, float* ms,
-                                    int* launches) {
+                                    int* launches) try {
   if (!s) return fail(OUTFIT_ERR_BAD_HANDLE, "session is NULL");
   if (collect_times(s) != OUTFIT_OK) return OUTFIT_ERR_HIP;
   int n = 0;
@@ -1247,7 +1255,7 @@ int outfit_hip_session_kernel_times(outfit_hip_session_t* s, int max_n, const ch
     ++n;
   }
   return n;
-}
+} OUTFIT_ABI_CATCH
 
 void outfit_hip_session_destroy(outfit_hip_session_t* s) {
   if (!s) return;
@@ -1257,13 +1265,13 @@ void outfit_hip_session_destroy(outfit_hip_session_t* s) {
 }
 
 int outfit_hip_fit_full_iod(const outfit_iod_params_t* params, const outfit_obs_batch_t* batch,
-                            const outfit_ephem_t* ephem, int n_devices, outfit_gauss_result_t* out) {
+                            const outfit_ephem_t* ephem, int n_devices, outfit_gauss_result_t* out) try {
   return outfit_hip_fit_full_iod_ex(params, batch, ephem, n_devices, nullptr, out);
-}
+} OUTFIT_ABI_CATCH
 
 int outfit_hip_fit_full_iod_ex(const outfit_iod_params_t* params, const outfit_obs_batch_t* batch,
                                const outfit_ephem_t* ephem, int n_devices, const outfit_hip_call_options_t* options,
-                               outfit_gauss_result_t* out) {
+                               outfit_gauss_result_t* out) try {
   TRY_RC(outfit_hip_iod_params_validate(params));
   TRY_RC(check_batch(params, batch, ephem));
   if (!out && batch->n_traj) return fail(OUTFIT_ERR_INVALID_BATCH, "out is NULL");
@@ -1285,7 +1293,7 @@ int outfit_hip_fit_full_iod_ex(const outfit_iod_params_t* params, const outfit_o
     g_last_error = keep;
     return r;
   });
-}
+} OUTFIT_ABI_CATCH
 
 void outfit_hip_diffcor_config_default(outfit_diffcor_config_t* c) {
   std::memset(c, 0, sizeof *c);
@@ -1299,21 +1307,21 @@ void outfit_hip_diffcor_config_default(outfit_diffcor_config_t* c) {
   for (int j = 0; j < 6; ++j) c->free_elements[j] = 1;
 }
 
-int outfit_hip_diffcor_config_validate(const outfit_diffcor_config_t* c) {
+int outfit_hip_diffcor_config_validate(const outfit_diffcor_config_t* c) try {
   if (!c) return fail(OUTFIT_ERR_INVALID_PARAM, "config is NULL");
   if (const char* m = validate_diffcor(c)) return fail(OUTFIT_ERR_INVALID_PARAM, m);
   return OUTFIT_OK;
-}
+} OUTFIT_ABI_CATCH
 
 int outfit_hip_session_run_lsq(outfit_hip_session_t* s, const outfit_diffcor_config_t* config,
-                               const outfit_gauss_result_t* initial_orbits, void* stream) {
+                               const outfit_gauss_result_t* initial_orbits, void* stream) try {
   if (!s) return fail(OUTFIT_ERR_BAD_HANDLE, "session is NULL");
   if (!config) return fail(OUTFIT_ERR_INVALID_PARAM, "config is NULL");
   hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : s->own_stream;
   return session_run_lsq(s, config, initial_orbits, st);
-}
+} OUTFIT_ABI_CATCH
 
-int outfit_hip_session_lsq_results(outfit_hip_session_t* s, outfit_lsq_result_t* out, outfit_obs_fit_t* obs_fit) {
+int outfit_hip_session_lsq_results(outfit_hip_session_t* s, outfit_lsq_result_t* out, outfit_obs_fit_t* obs_fit) try {
   if (!s || !out) return fail(OUTFIT_ERR_BAD_HANDLE, "session or out is NULL");
   if (!s->lsq_ran) return fail(OUTFIT_ERR_BAD_HANDLE, "outfit_hip_session_run_lsq has not been called");
   HIP_TRY(hipSetDevice(s->device));
@@ -1333,19 +1341,19 @@ int outfit_hip_session_lsq_results(outfit_hip_session_t* s, outfit_lsq_result_t*
     }
   }
   return OUTFIT_OK;
-}
+} OUTFIT_ABI_CATCH
 
 int outfit_hip_fit_lsq(const outfit_iod_params_t* params, const outfit_diffcor_config_t* config,
                        const outfit_obs_batch_t* batch, const outfit_ephem_t* ephem,
                        const outfit_gauss_result_t* initial, int n_devices, outfit_lsq_result_t* out,
-                       outfit_obs_fit_t* obs_fit) {
+                       outfit_obs_fit_t* obs_fit) try {
   return outfit_hip_fit_lsq_ex(params, config, batch, ephem, initial, n_devices, nullptr, out, obs_fit);
-}
+} OUTFIT_ABI_CATCH
 
 int outfit_hip_fit_lsq_ex(const outfit_iod_params_t* params, const outfit_diffcor_config_t* config,
                           const outfit_obs_batch_t* batch, const outfit_ephem_t* ephem,
                           const outfit_gauss_result_t* initial, int n_devices, const outfit_hip_call_options_t* options,
-                          outfit_lsq_result_t* out, outfit_obs_fit_t* obs_fit) {
+                          outfit_lsq_result_t* out, outfit_obs_fit_t* obs_fit) try {
   TRY_RC(outfit_hip_iod_params_validate(params));
   TRY_RC(outfit_hip_diffcor_config_validate(config));
   TRY_RC(check_batch(params, batch, ephem));
@@ -1367,10 +1375,10 @@ int outfit_hip_fit_lsq_ex(const outfit_iod_params_t* params, const outfit_diffco
     g_last_error = keep;
     return r;
   });
-}
+} OUTFIT_ABI_CATCH
 
 int outfit_hip_observer_positions(const outfit_ephem_t* eph, uint64_t n, const double* mjd_tt, const double* mjd_ut1,
-                                  const double* body_fixed, double* geo_ecl, double* helio_equ) {
+                                  const double* body_fixed, double* geo_ecl, double* helio_equ) try {
   if (n == 0) return OUTFIT_OK;
   if (!eph || !mjd_tt || !mjd_ut1 || !body_fixed || !geo_ecl || !helio_equ)
     return fail(OUTFIT_ERR_INVALID_BATCH, "NULL argument");
@@ -1417,10 +1425,10 @@ int outfit_hip_observer_positions(const outfit_ephem_t* eph, uint64_t n, const d
   if (rc != OUTFIT_OK) return rc;
   if (e != hipSuccess) return fail(OUTFIT_ERR_HIP, hipGetErrorString(e));
   return OUTFIT_OK;
-}
+} OUTFIT_ABI_CATCH
 
 int outfit_hip_device_normals(uint64_t noise_seed, const uint64_t* traj_key, uint64_t traj_key_base, uint64_t n_traj,
-                              uint32_t max_triplets, uint64_t n_noise, double* out) {
+                              uint32_t max_triplets, uint64_t n_noise, double* out) try {
   const uint64_t n = n_traj * max_triplets * n_noise * 6;
   if (n == 0) return OUTFIT_OK;
   if (!out) return fail(OUTFIT_ERR_INVALID_BATCH, "out is NULL");
@@ -1444,9 +1452,9 @@ int outfit_hip_device_normals(uint64_t noise_seed, const uint64_t* traj_key, uin
   k.release();
   if (e != hipSuccess) return fail(OUTFIT_ERR_HIP, hipGetErrorString(e));
   return OUTFIT_OK;
-}
+} OUTFIT_ABI_CATCH
 
-int outfit_hip_selftest_aberth(uint64_t n_polys, uint64_t seed, uint64_t* counts) {
+int outfit_hip_selftest_aberth(uint64_t n_polys, uint64_t seed, uint64_t* counts) try {
   if (!counts) return fail(OUTFIT_ERR_INVALID_BATCH, "NULL argument");
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
@@ -1464,9 +1472,9 @@ int outfit_hip_selftest_aberth(uint64_t n_polys, uint64_t seed, uint64_t* counts
   counts[0] = h[0];
   counts[1] = h[1];
   return OUTFIT_OK;
-}
+} OUTFIT_ABI_CATCH
 
-int outfit_hip_selftest_crmath(uint64_t n_args, uint64_t seed, uint64_t* counts) {
+int outfit_hip_selftest_crmath(uint64_t n_args, uint64_t seed, uint64_t* counts) try {
   if (!counts) return fail(OUTFIT_ERR_INVALID_BATCH, "NULL argument");
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
@@ -1483,9 +1491,9 @@ int outfit_hip_selftest_crmath(uint64_t n_args, uint64_t seed, uint64_t* counts)
   if (e != hipSuccess) return fail(OUTFIT_ERR_HIP, hipGetErrorString(e));
   for (int i = 0; i < 4; ++i) counts[i] = h[i];
   return OUTFIT_OK;
-}
+} OUTFIT_ABI_CATCH
 
-int outfit_hip_crmath_eval(int fn, uint64_t n, const double* x, double* out) {
+int outfit_hip_crmath_eval(int fn, uint64_t n, const double* x, double* out) try {
   if ((fn & 15) > 12 || (fn & ~31)) return fail(OUTFIT_ERR_INVALID_PARAM, "fn: 0 sin, 1 cos, 2 acos, 3 sinh, 4 cosh, 5 log, 6 atan2 (+16: full evaluation), 7 / 8 sin / cos of the residual loop, 9..12 glibc-faithful sin / cos / sinh / cosh");
   if (n && (!x || !out)) return fail(OUTFIT_ERR_INVALID_BATCH, "NULL argument");
   int n_dev = 0;
@@ -1502,9 +1510,9 @@ int outfit_hip_crmath_eval(int fn, uint64_t n, const double* x, double* out) {
   dy.release();
   if (e != hipSuccess) return fail(OUTFIT_ERR_HIP, hipGetErrorString(e));
   return OUTFIT_OK;
-}
+} OUTFIT_ABI_CATCH
 
-int outfit_hip_glibc_eval(int fn, uint64_t n, const double* x, const double* y, double* out) {
+int outfit_hip_glibc_eval(int fn, uint64_t n, const double* x, const double* y, double* out) try {
   if (fn < 0 || fn > 6) return fail(OUTFIT_ERR_INVALID_PARAM, "fn: 0 sin1, 1 cos1, 2 tan, 3 atan2(x, y), 4 hypot(x, y), 5 acos, 6 log");
   const bool two = fn == 3 || fn == 4;
   if (n && (!x || !out || (two && !y))) return fail(OUTFIT_ERR_INVALID_BATCH, "NULL argument");
@@ -1524,9 +1532,9 @@ int outfit_hip_glibc_eval(int fn, uint64_t n, const double* x, const double* y, 
   dz.release();
   if (e != hipSuccess) return fail(OUTFIT_ERR_HIP, hipGetErrorString(e));
   return OUTFIT_OK;
-}
+} OUTFIT_ABI_CATCH
 
-int outfit_hip_calibration_stream(uint64_t n_doubles, int repeats) {
+int outfit_hip_calibration_stream(uint64_t n_doubles, int repeats) try {
   if (n_doubles == 0 || repeats <= 0) return OUTFIT_OK;
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
@@ -1541,9 +1549,9 @@ int outfit_hip_calibration_stream(uint64_t n_doubles, int repeats) {
   b.release();
   if (e != hipSuccess) return fail(OUTFIT_ERR_HIP, hipGetErrorString(e));
   return OUTFIT_OK;
-}
+} OUTFIT_ABI_CATCH
 
-int outfit_hip_prelim_kepuni(uint64_t n, const double* problems, double* out) {
+int outfit_hip_prelim_kepuni(uint64_t n, const double* problems, double* out) try {
   if (n == 0) return OUTFIT_OK;
   if (!problems || !out) return fail(OUTFIT_ERR_INVALID_BATCH, "NULL argument");
   int n_dev = 0;
@@ -1559,9 +1567,16 @@ int outfit_hip_prelim_kepuni(uint64_t n, const double* problems, double* out) {
   dy.release();
   if (e != hipSuccess) return fail(OUTFIT_ERR_HIP, hipGetErrorString(e));
   return OUTFIT_OK;
-}
+} OUTFIT_ABI_CATCH
 
-int outfit_hip_selftest_division(uint64_t n_pairs, uint64_t seed, uint64_t* mismatches) {
+int outfit_hip_selftest_abi_guard(int kind) try {
+  if (kind == 0) throw std::bad_alloc();
+  if (kind == 1) throw std::runtime_error("selftest");
+  if (kind == 2) throw 42;
+  return OUTFIT_OK;
+} OUTFIT_ABI_CATCH
+
+int outfit_hip_selftest_division(uint64_t n_pairs, uint64_t seed, uint64_t* mismatches) try {
   if (!mismatches) return fail(OUTFIT_ERR_INVALID_BATCH, "NULL argument");
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
@@ -1578,7 +1593,7 @@ int outfit_hip_selftest_division(uint64_t n_pairs, uint64_t seed, uint64_t* mism
   if (e != hipSuccess) return fail(OUTFIT_ERR_HIP, hipGetErrorString(e));
   *mismatches = h;
   return OUTFIT_OK;
-}
+} OUTFIT_ABI_CATCH
 
 void outfit_hip_solver_type_default(outfit_solver_type_t* s) {
   std::memset(s, 0, sizeof *s);
@@ -1589,15 +1604,15 @@ void outfit_hip_solver_type_default(outfit_solver_type_t* s) {
 }
 
 int outfit_hip_propagate_universal(uint64_t n, const double* r0v0, const double* t0, const double* t1,
-                                   double convergency, double* out, int32_t* status) {
+                                   double convergency, double* out, int32_t* status) try {
   outfit_solver_type_t st;
   outfit_hip_solver_type_default(&st);
   st.convergency = convergency;
   return outfit_hip_propagate_universal_ex(n, r0v0, t0, t1, &st, out, status);
-}
+} OUTFIT_ABI_CATCH
 
 int outfit_hip_propagate_universal_ex(uint64_t n, const double* r0v0, const double* t0, const double* t1,
-                                      const outfit_solver_type_t* solver, double* out, int32_t* status) {
+                                      const outfit_solver_type_t* solver, double* out, int32_t* status) try {
   if (!solver) return fail(OUTFIT_ERR_INVALID_PARAM, "solver is NULL");
   if (solver->kind < 0 || solver->kind > OUTFIT_SOLVER_AUTO)
     return fail(OUTFIT_ERR_INVALID_PARAM, "solver kind must be OUTFIT_SOLVER_NEWTON_RAPHSON, _BRENT_DECKER or _AUTO");
@@ -1636,6 +1651,6 @@ int outfit_hip_propagate_universal_ex(uint64_t n, const double* r0v0, const doub
   } while (false);
   cleanup();
   return rc;
-}
+} OUTFIT_ABI_CATCH
 
 }  // extern "C"

@@ -9,6 +9,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <memory>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -46,16 +48,23 @@ constexpr int kBodies[3] = {2, 9, 10};     // EMB, Moon, Sun (horizon_ids.rs / h
 
 }  // namespace
 
+// nothing unwinds through the C ABI (api.hip OUTFIT_ABI_CATCH): allocation failures come back as a code
+#define OUTFIT_EPHEM_CATCH                                                                                             \
+  catch (const std::bad_alloc&) { return outfit::set_last_error(OUTFIT_ERR_NO_MEMORY, "host allocation failed"); }     \
+  catch (...) { return outfit::set_last_error(OUTFIT_ERR_NO_MEMORY, "internal error in the ephemeris reader"); }
+
 extern "C" {
 
-int outfit_hip_ephem_open(const char* path, outfit_ephem_file_t** out) {
+int outfit_hip_ephem_open(const char* path, outfit_ephem_file_t** out) try {
   if (!out) return outfit::set_last_error(OUTFIT_ERR_BAD_HANDLE, "out is NULL");
   *out = nullptr;
   if (!path) return outfit::set_last_error(OUTFIT_ERR_INVALID_BATCH, "path is NULL");
-  FILE* f = std::fopen(path, "rb");
+  // the file and the object under construction are owned by holders: every return and every exception releases them
+  struct Closer { void operator()(FILE* p) const { if (p) std::fclose(p); } };
+  std::unique_ptr<FILE, Closer> file(std::fopen(path, "rb"));
+  FILE* f = file.get();
   if (!f) return outfit::set_last_error(OUTFIT_ERR_EPHEM_FILE, std::string("cannot open ") + path);
   auto fail = [&](const std::string& m) {
-    std::fclose(f);
     return outfit::set_last_error(OUTFIT_ERR_EPHEM_FILE, std::string(path) + ": " + m);
   };
   unsigned char head[4096];  // the reference reads 1 << 12 bytes up front (:627-629)
@@ -99,14 +108,15 @@ int outfit_hip_ephem_open(const char* path, outfit_ephem_file_t** out) {
   if (size < (long)(2 * h.recsize)) return fail("no data records");
   h.n_blocks = ((uint64_t)size - 2 * h.recsize) / h.recsize;  // parse_all_blocks :527-565
   if (h.n_blocks == 0) return fail("no data records");
-  auto* e = new outfit_ephem_file();
+  std::unique_ptr<outfit_ephem_file> holder(new outfit_ephem_file());
+  outfit_ephem_file* e = holder.get();
   e->header = h;
   e->path = path;
   e->coef.resize((size_t)h.n_blocks * per_block);
   std::vector<unsigned char> rec((size_t)h.recsize);
-  if (std::fseek(f, (long)(2 * h.recsize), SEEK_SET) != 0) { delete e; return fail("seek failed"); }
+  if (std::fseek(f, (long)(2 * h.recsize), SEEK_SET) != 0) return fail("seek failed");
   for (uint64_t nb = 0; nb < h.n_blocks; ++nb) {
-    if (std::fread(rec.data(), 1, rec.size(), f) != rec.size()) { delete e; return fail("truncated data record"); }
+    if (std::fread(rec.data(), 1, rec.size(), f) != rec.size()) return fail("truncated data record");
     double* dst = e->coef.data() + (size_t)nb * per_block;
     for (int b = 0; b < 3; ++b) {
       // HorizonRecord::new (horizon_records.rs:132-171): coefficient j of axis a of sub-interval s is
@@ -119,10 +129,9 @@ int outfit_hip_ephem_open(const char* path, outfit_ephem_file_t** out) {
       dst += n;
     }
   }
-  std::fclose(f);
-  *out = e;
+  *out = holder.release();
   return OUTFIT_OK;
-}
+} OUTFIT_EPHEM_CATCH
 
 int outfit_hip_ephem_header(const outfit_ephem_file_t* e, outfit_de_header_t* header) {
   if (!e || !header) return outfit::set_last_error(OUTFIT_ERR_BAD_HANDLE, "handle or header is NULL");
@@ -151,7 +160,7 @@ int outfit_hip_ephem_view(const outfit_ephem_file_t* e, outfit_ephem_t* view) {
 // that order — plus the block's [start_jd, end_jd]. Lets the reference's record known answers for bodies the path
 // does not consume (Mercury, Jupiter, Mars: horizon_data.rs:898-1003,1101-1140) be checked through this reader.
 int outfit_hip_ephem_body_record(const outfit_ephem_file_t* e, uint32_t ipt_row, uint64_t block, double* jd_range,
-                                 double* out, uint64_t capacity) {
+                                 double* out, uint64_t capacity) try {
   if (!e || !out) return outfit::set_last_error(OUTFIT_ERR_BAD_HANDLE, "handle or out is NULL");
   const outfit_de_header_t& h = e->header;
   if (ipt_row >= 15 || block >= h.n_blocks) return outfit::set_last_error(OUTFIT_ERR_INVALID_BATCH, "IPT row or block out of range");
@@ -161,9 +170,9 @@ int outfit_hip_ephem_body_record(const outfit_ephem_file_t* e, uint32_t ipt_row,
   if (capacity < n) return outfit::set_last_error(OUTFIT_ERR_INVALID_BATCH, "out is too small for this body's record");
   if (r[0] < 3 || (uint64_t)r[0] - 1 + n > h.recsize / 8)
     return outfit::set_last_error(OUTFIT_ERR_EPHEM_FILE, "IPT row points outside the record");
+  std::vector<unsigned char> rec((size_t)h.recsize);  // (allocated before the file is opened: nothing to release if it throws)
   FILE* f = std::fopen(e->path.c_str(), "rb");
   if (!f) return outfit::set_last_error(OUTFIT_ERR_EPHEM_FILE, "cannot reopen " + e->path);
-  std::vector<unsigned char> rec((size_t)h.recsize);
   const bool ok = std::fseek(f, (long)((2 + block) * h.recsize), SEEK_SET) == 0 &&
                   std::fread(rec.data(), 1, rec.size(), f) == rec.size();
   std::fclose(f);
@@ -172,7 +181,7 @@ int outfit_hip_ephem_body_record(const outfit_ephem_file_t* e, uint32_t ipt_row,
   const unsigned char* src = rec.data() + 8 * ((size_t)r[0] - 1);
   for (uint64_t k = 0; k < n; ++k) out[k] = le_f64(src + 8 * k);
   return (int)n;
-}
+} OUTFIT_EPHEM_CATCH
 
 void outfit_hip_ephem_close(outfit_ephem_file_t* e) { delete e; }
 

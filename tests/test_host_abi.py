@@ -283,3 +283,16 @@ def test_issue_cost_microbenchmark_compiles(tmp_path):
     r = subprocess.run([hipcc, "-O2", "--offload-arch=gfx950", "-c", src, "-o", str(tmp_path / "issue_cost.o")],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_no_exception_crosses_the_c_abi():
+    """Every entry point that can allocate is a function-try-block: a C++ exception inside the library comes back as
+    OUTFIT_ERR_NO_MEMORY with a message, never as an unwinding through the caller's (Rust / C / ctypes) frames."""
+    L = _lib.lib()
+    L.outfit_hip_selftest_abi_guard.argtypes = [C.c_int]
+    L.outfit_hip_selftest_abi_guard.restype = C.c_int
+    L.outfit_hip_last_error.restype = C.c_char_p
+    assert L.outfit_hip_selftest_abi_guard(3) == 0
+    for kind, text in ((0, b"allocation"), (1, b"selftest"), (2, b"unknown")):
+        assert L.outfit_hip_selftest_abi_guard(kind) == _abi.OUTFIT_ERR_NO_MEMORY
+        assert text in L.outfit_hip_last_error()
