@@ -91,6 +91,8 @@ def _raise_rc(rc):
         raise NativeLibraryError(msg)
     if rc == _abi.OUTFIT_ERR_EPHEM_FILE:
         raise EphemerisFileError(msg)
+    if rc == _abi.OUTFIT_ERR_NO_MEMORY:   # a host allocation (or another C++ exception) inside the library
+        raise MemoryError(msg)
     raise HipRuntimeError(f"rc={rc}: {msg}")
 
 
