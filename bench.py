@@ -443,6 +443,131 @@ def cpu_baseline_lsq(batch, ephem, params, seeds, n_obj_max, budget_s=5.0):
             "sample": f"first {n0} objects of the same batch, seeds = this run's IOD records, {dt:.1f} s"}
 
 
+LINE_BYTE_BUDGET = 4096        # the driver keeps an 8 KB tail of stdout: the line must fit it with room to spare
+
+
+def _num(x, digits=6):
+    """Floats of the printed line at `digits` significant digits (the detail file keeps full precision)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None            # the line is strict JSON: no NaN / Infinity tokens
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, dict):
+        return {k: _num(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_num(v, digits) for v in x]
+    return x
+
+
+def _get(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
+
+
+def compact_roofline(r):
+    """The contract keys of a roofline block plus ONE number per derived quantity."""
+    if r is None:
+        return None
+    return {"bound": r["bound"], "kernel": r["kernel"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"],
+            "frac": r["frac"], "traffic": r["traffic"], "avg_launch_ms": r["avg_launch_ms"],
+            "units_per_launch": r["units_per_launch"], "algorithmic_bytes_per_object": r["algorithmic_bytes_per_object"],
+            "limited_by": "fp64 VALU issue, not HBM",
+            "issue": {"step_issue_frac": _get(r, "issue", "step_issue_frac"),
+                      "step_issue_cycle_frac_at_measured_clock": _get(r, "issue", "step_issue_cycle_frac_at_measured_clock")},
+            "fp64_executed": {"frac": _get(r, "fp64_executed", "frac"), "achieved_tflops": _get(r, "fp64_executed", "achieved_tflops"),
+                              "peak_tflops": FP64_PEAK_TFLOPS},
+            "step_traffic": {"ratio": _get(r, "step_traffic", "ratio"), "counter_bytes": _get(r, "step_traffic", "counter_bytes")},
+            "counters_source_hash": _get(r, "counters", "source_hash"),
+            "kernel_ms_per_step": r["all_kernels_avg_ms_per_step"]}
+
+
+def compact_line(full, detail_path):
+    """What rank 0 prints: the contract keys, `roofline`, `cpu_baseline`, a short parity summary and one number per side
+    workload. Everything else of `full` (per-kernel tables, mode tables, long arcs, notes) is in the detail file."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "math_mode")
+    line = {k: full[k] for k in keep if k in full}
+    c = full["config"]
+    line["config"] = {"workload": c["workload"], "objects_per_gpu": c["objects_per_gpu"], "obs_per_object": c["obs_per_object"],
+                      "triplets_per_object": c["triplets_per_object"], "n_noise_realizations": c["n_noise_realizations"],
+                      "orbits_found_rank0": c["orbits_found_rank0"], "parallelism": c["parallelism"]}
+    line["roofline"] = compact_roofline(full.get("roofline"))
+    if "cpu_baseline" in full:
+        line["cpu_baseline"] = full["cpu_baseline"]
+        line["cpu_baseline_1thread_objects_per_s"] = _get(full, "cpu_baseline_1thread", "value")
+        line["cpu_baseline_hoisted_objects_per_s"] = _get(full, "cpu_baseline_hoisted", "value")
+    p = full.get("parity_vs_libm")
+    if p is not None:
+        m = p.get(full["math_mode"], {})
+        line["parity_vs_libm"] = {"objects": m.get("orbits") and int(p["sample"].split()[1]), "mode": full["math_mode"],
+                                  "host_libm_is_the_pinned_build": p["host_libm_is_the_pinned_build"],
+                                  "byte_identical_records": m.get("byte_identical_records"),
+                                  "beyond_1e-10_AU": m.get("beyond_1e-10_AU"), "beyond_1e-12_rad": m.get("beyond_1e-12_rad")}
+    if "math_modes" in full:
+        mm = full["math_modes"]
+        other = [k for k in ("glibc", "cr") if k in mm and k != mm["headline"]]
+        if other:
+            line["other_math_mode"] = {"mode": other[0], "objects_per_s": mm[other[0]]["value"]}
+    side = full.get("side") or {}
+    s = {}
+    if side:
+        s["isolated_run_ms"] = side.get("isolated_run_ms")
+        s["blocking_call_ms"] = side.get("blocking_call_ms")
+        s["configs1_1000_objects_ms_per_step"] = _get(side, "configs1_1000_objects", "ms_per_step_back_to_back")
+        s["configs1_1000_objects_blocking_call_ms"] = _get(side, "configs1_1000_objects", "blocking_call_ms")
+        s["noise_default_objects_per_s"] = _get(side, "noise", "iod_params_default", "objects_per_s")
+        s["noise_8d_objects_per_s"] = _get(side, "noise", "survey_8d", "objects_per_s")
+        la = side.get("long_arcs") or {}
+        if la:
+            s["long_arcs_ms_per_10000_objects"] = {k: v["ms_per_step"] for k, v in la.items()}
+    if "fit_lsq" in full:
+        f = full["fit_lsq"]
+        s["fit_lsq"] = {"ms_per_step": f["ms_per_step"], "objects_per_s_stage": f["objects_per_s_stage"],
+                        "objects_per_s_iod_plus_lsq": f["objects_per_s_iod_plus_lsq"],
+                        "roofline_frac": _get(f, "roofline", "frac"),
+                        "cpu_baseline_objects_per_s": _get(f, "cpu_baseline", "value"),
+                        "ms_per_step_by_config": {k: v["ms_per_step"] for k, v in (f.get("workloads") or {}).items()}}
+    if s:
+        line["side"] = s
+    g = full.get("gather_check")
+    if g is not None:
+        line["gather_check"] = {"ranks_verified_by_every_rank": g["ranks_verified_by_every_rank"], "records": g["records"],
+                                "ipc_mode": g["ipc_mode"],
+                                "ms_per_step_per_rank": g["per_rank"]["ms_per_step"],
+                                "gather_wait_ms_per_step_per_rank": g["per_rank"]["gather_wait_ms_per_step"]}
+    line["detail"] = detail_path
+    exact = {k: line[k] for k in ("value", "ms_per_step") if k in line}     # the driver re-derives these: full precision
+    line = _num(line)
+    line.update(exact)
+    if len(json.dumps(line)) > LINE_BYTE_BUDGET:        # never again a line the driver cannot keep: shed the optional parts
+        for k in ("side", "gather_check", "other_math_mode"):
+            line.pop(k, None)
+            if len(json.dumps(line)) <= LINE_BYTE_BUDGET:
+                break
+    return line
+
+
+def write_detail(full):
+    """The full record (per-kernel tables, mode tables, side workloads) beside the line: gpurun_out/ is merged back from
+    the GPU box; falls back to the working directory, then to stderr only."""
+    text = json.dumps(full)
+    for d in (os.path.join(ROOT, "gpurun_out"), os.getcwd()):
+        try:
+            os.makedirs(d, exist_ok=True)
+            path = os.path.join(d, f"bench_detail_n{full.get('n_gpus', 1)}.json")
+            with open(path, "w") as f:
+                f.write(text + "\n")
+            return os.path.relpath(path, ROOT)
+        except OSError:
+            continue
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -801,7 +926,10 @@ def main():
             line["cpu_baseline_hoisted"] = cpu_baseline(batch, ephem, params, n_obj, budget_s=5.0, hoist=1)
             if lsq is not None:
                 line["fit_lsq"]["cpu_baseline"] = cpu_baseline_lsq(batch, ephem, params, res, n_obj)
-        print(json.dumps(line), flush=True)
+        detail = write_detail(line)
+        if detail is None:                                       # no writable place: the full record goes to stderr
+            print(json.dumps(line), file=sys.stderr, flush=True)
+        print(json.dumps(compact_line(line, detail), allow_nan=False), flush=True)   # THE line: last on stdout, compact
     session.close()
     if multi:
         dist.barrier()

@@ -29,7 +29,16 @@ def run_bench(*extra, port="29541"):
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-1500:]          # ONE JSON line on stdout (RCCL's banner must not land there)
-    return json.loads(lines[0])
+    return checked_line(p.stdout, lines[0])
+
+
+def checked_line(stdout, text):
+    """The printed line is the LAST thing on stdout and short enough for the driver's 8 KB tail; the per-rank tables
+    live in the detail file it names (returned under "_detail")."""
+    assert stdout.rstrip().splitlines()[-1] == text and len(text) < 4096, len(text)
+    line = json.loads(text)
+    line["_detail"] = json.load(open(os.path.join(ROOT, line["detail"])))
+    return line
 
 
 def test_rccl_gather_path_with_one_rank():
@@ -38,7 +47,8 @@ def test_rccl_gather_path_with_one_rank():
     assert line["math_mode"] == "glibc"
     assert line["config"]["orbits_found_rank0"] > 19000
     gc = line["gather_check"]
-    assert gc["ranks_verified_by_every_rank"] == 1 and gc["records"] == 20000 and len(gc["crc32_per_rank"]) == 1
+    assert gc["ranks_verified_by_every_rank"] == 1 and gc["records"] == 20000
+    assert len(line["_detail"]["gather_check"]["crc32_per_rank"]) == 1
     assert line["roofline"]["kernel"].startswith("k_") and line["value"] > 1e5
 
 
@@ -73,10 +83,13 @@ def test_two_ranks_share_the_gpu_through_gloo_unequal_shards():
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-1500:]
-    line = json.loads(lines[0])
+    line = checked_line(p.stdout, lines[0])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["objects_per_gpu"] == [25000, 50000]
     gc = line["gather_check"]
-    assert gc["ranks_verified_by_every_rank"] == 2 and gc["records"] == 75000 and len(set(gc["crc32_per_rank"])) == 2
+    assert gc["ranks_verified_by_every_rank"] == 2 and gc["records"] == 75000 and len(gc["ms_per_step_per_rank"]) == 2
+    assert gc["ipc_mode"] == "HSA_ENABLE_IPC_MODE_LEGACY=0"
+    gc = line["_detail"]["gather_check"]
+    assert len(set(gc["crc32_per_rank"])) == 2
     # per-rank timing of the timed region, and the IPC mode the ranks ran with (set by bench.py itself)
     pr = gc["per_rank"]
     assert all(len(pr[k]) == 2 for k in ("ms_per_step", "gather_wait_ms_per_step", "host_enqueue_ms_per_step",

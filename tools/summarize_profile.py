@@ -31,7 +31,7 @@ def bench_runs(passdir):
             iod = 1 + int(r["steps"])
         else:
             iod = int(j["steps"]) + int(j["warmup"])
-            if "fit_lsq" in j:                   # --workload lsq_*: + the seed run; corrector: one warm-up + steps
+            if "fit_lsq" in j or "fit_lsq" in (j.get("side") or {}):                   # --workload lsq_*: + the seed run; corrector: one warm-up + steps
                 iod += 1
                 lsq = 1 + int(j["steps"])
     except (OSError, IndexError, KeyError, ValueError):
