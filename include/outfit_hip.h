@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define OUTFIT_HIP_ABI_VERSION 6
+#define OUTFIT_HIP_ABI_VERSION 7
 
 /* ---- whole-call return codes --------------------------------------------- */
 #define OUTFIT_OK                 0
@@ -45,8 +45,10 @@ extern "C" {
 #define OUTFIT_ERR_HIP           -4 /* a HIP runtime call failed                                                  */
 #define OUTFIT_ERR_EPHEM_RANGE   -5 /* an epoch lies outside the table (reference panics: horizon_data.rs:722-724)*/
 #define OUTFIT_ERR_BAD_HANDLE    -6
-#define OUTFIT_ERR_NO_MEMORY     -8 /* a host allocation (or any other C++ exception) failed inside the library: entry
-                                       points never let an exception cross the C ABI (-7: OUTFIT_ERR_EPHEM_FILE, below) */
+#define OUTFIT_ERR_NO_MEMORY     -8 /* a host allocation failed inside the library (std::bad_alloc): entry points never
+                                       let an exception cross the C ABI (-7: OUTFIT_ERR_EPHEM_FILE, below) */
+#define OUTFIT_ERR_INTERNAL      -9 /* v7: any other C++ exception inside the library (a bug, not a resource limit);
+                                       outfit_hip_last_error() carries what() */
 
 /* ---- per-trajectory status (outfit_gauss_result_t.status) ------------------
  * mirrors the Err variants `estimate_best_orbit` can return
@@ -209,13 +211,29 @@ int  outfit_hip_iod_params_validate(const outfit_iod_params_t *p);
 int outfit_hip_set_math_mode(int mode); /* 0 or OUTFIT_ERR_INVALID_PARAM */
 int outfit_hip_get_math_mode(void);
 
-/* Per-call options (ABI v6). Everything a call depends on besides its arguments lives here, so that concurrent
- * callers with different settings do not meet in process-wide state. `struct_size` = sizeof the caller's struct:
- * later versions append fields. NULL options = all defaults. */
+/* Per-call options (ABI v6, extended in v7). Everything a call depends on besides its arguments lives here, so that
+ * concurrent callers with different settings do not meet in process-wide state. `struct_size` = sizeof the caller's
+ * struct: later versions append fields. NULL options = all defaults.
+ *
+ * ABI v7 gives two of v6's reserved words a meaning (the struct keeps its 32 bytes; a v6 caller, whose reserved words
+ * had to be zero, gets the v6 behaviour):
+ *   n_obs_capacity    rows the caller's per-observation columns hold (mjd_tt, ra, dec, sigma_*, mjd_ut1: that many
+ *                     doubles; obs_helio_equ, obs_geo_ecl, obs_body_fixed: three times that). 0 = not stated. When
+ *                     stated, a batch whose traj_offset[n_traj] exceeds it is OUTFIT_ERR_INVALID_BATCH instead of an
+ *                     out-of-bounds read: the columns are indexed by the offsets themselves, and a table can be
+ *                     monotone and still run past them. (The reference materialises each trajectory from data it owns,
+ *                     obs_dataset_api.rs:210-226, and cannot overrun; across a C ABI only the caller knows the lengths.)
+ *   noise_z_capacity  doubles in noise_z; 0 = not stated. When stated with host-drawn noise, fewer than
+ *                     n_traj x max_triplets x n_noise_realizations x 6 is OUTFIT_ERR_INVALID_BATCH.
+ * Contract since the round-4 build of v6, restated for v7: options with a struct_size that does not cover math_mode,
+ * with a non-zero reserved word, or with an unknown math_mode are OUTFIT_ERR_INVALID_PARAM (initialise the struct
+ * with outfit_hip_call_options_default). */
 typedef struct outfit_hip_call_options {
   uint32_t struct_size;
-  int32_t  math_mode;   /* OUTFIT_MATH_DEFAULT, OUTFIT_MATH_CORRECTLY_ROUNDED or OUTFIT_MATH_GLIBC */
-  uint64_t reserved[3]; /* zero */
+  int32_t  math_mode;        /* OUTFIT_MATH_DEFAULT, OUTFIT_MATH_CORRECTLY_ROUNDED or OUTFIT_MATH_GLIBC */
+  uint64_t n_obs_capacity;   /* v7; 0 = unchecked */
+  uint64_t noise_z_capacity; /* v7; 0 = unchecked */
+  uint64_t reserved[1];      /* zero */
 } outfit_hip_call_options_t;
 void outfit_hip_call_options_default(outfit_hip_call_options_t *o);
 

@@ -202,7 +202,13 @@ class FitIOD {
     outfit_ephem_t e{};
     if (!jpl.empty()) e = ephem(jpl);
     std::vector<outfit_gauss_result_t> out(f.ids.size());
-    const int rc = outfit_hip_fit_full_iod_ex(&params, &b, jpl.empty() ? nullptr : &e, n_devices, &options, out.data());
+    // the lengths of what is handed over (ABI v7): the columns are this function's own; the normals are the caller's —
+    // a vector shorter than n_traj * max_triplets * n_noise_realizations * 6 comes back as InvalidBatch, not as a read
+    // past its end
+    CallOptions opt = options;
+    opt.n_obs_capacity = f.t.size();
+    if (noise_z) opt.noise_z_capacity = noise_z->size();
+    const int rc = outfit_hip_fit_full_iod_ex(&params, &b, jpl.empty() ? nullptr : &e, n_devices, &opt, out.data());
     if (rc == OUTFIT_ERR_INVALID_PARAM) throw InvalidIODParameter(outfit_hip_last_error());
     if (rc == OUTFIT_ERR_INVALID_BATCH) throw InvalidBatch(outfit_hip_last_error());
     if (rc != OUTFIT_OK) throw DeviceError(outfit_hip_last_error());
@@ -355,8 +361,11 @@ class FitLSQ {
       }
     }
     std::vector<outfit_lsq_result_t> out(f.ids.size());
-    const int rc = outfit_hip_fit_lsq(&iod_params, &config, &b, jpl.empty() ? nullptr : &e,
-                                      initial_orbits ? init.data() : nullptr, n_devices, out.data(), nullptr);
+    CallOptions opt;
+    opt.n_obs_capacity = f.t.size();
+    if (noise_z) opt.noise_z_capacity = noise_z->size();
+    const int rc = outfit_hip_fit_lsq_ex(&iod_params, &config, &b, jpl.empty() ? nullptr : &e,
+                                         initial_orbits ? init.data() : nullptr, n_devices, &opt, out.data(), nullptr);
     if (rc == OUTFIT_ERR_INVALID_PARAM) throw InvalidIODParameter(outfit_hip_last_error());
     if (rc == OUTFIT_ERR_INVALID_BATCH) throw InvalidBatch(outfit_hip_last_error());
     if (rc != OUTFIT_OK) throw DeviceError(outfit_hip_last_error());

@@ -7,7 +7,7 @@ src/initial_orbit_determination/obs_dataset_api.rs:145-296).
 """
 import ctypes as C
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 OUTFIT_OK = 0
 OUTFIT_ERR_INVALID_PARAM = -1
@@ -18,6 +18,7 @@ OUTFIT_ERR_EPHEM_RANGE = -5
 OUTFIT_ERR_BAD_HANDLE = -6
 OUTFIT_ERR_EPHEM_FILE = -7
 OUTFIT_ERR_NO_MEMORY = -8
+OUTFIT_ERR_INTERNAL = -9
 
 TRAJ_OK = 0
 TRAJ_NO_FEASIBLE_TRIPLETS = 1
@@ -148,8 +149,10 @@ NOISE_DEVICE = 1
 
 
 class CallOptionsC(C.Structure):
-    """outfit_hip_call_options_t (ABI v6): per-call settings; math_mode -1 = the process-wide default."""
-    _fields_ = [("struct_size", C.c_uint32), ("math_mode", C.c_int32), ("reserved", C.c_uint64 * 3)]
+    """outfit_hip_call_options_t (ABI v7): per-call settings; math_mode -1 = the process-wide default; the two
+    capacities (0 = not stated) let the library refuse an offset table that runs past the caller's arrays."""
+    _fields_ = [("struct_size", C.c_uint32), ("math_mode", C.c_int32), ("n_obs_capacity", C.c_uint64),
+                ("noise_z_capacity", C.c_uint64), ("reserved", C.c_uint64 * 1)]
 
 
 class SolverTypeC(C.Structure):

@@ -33,8 +33,8 @@ class InvalidIODParameter(OutfitError):
     pass
 
 
-class InvalidBatch(OutfitError):
-    pass
+class InvalidBatch(OutfitError, ValueError):
+    """OUTFIT_ERR_INVALID_BATCH, and what ObsBatch.validate() raises before a malformed batch crosses the C ABI."""
 
 
 class EphemerisRange(OutfitError):
@@ -91,8 +91,10 @@ def _raise_rc(rc):
         raise NativeLibraryError(msg)
     if rc == _abi.OUTFIT_ERR_EPHEM_FILE:
         raise EphemerisFileError(msg)
-    if rc == _abi.OUTFIT_ERR_NO_MEMORY:   # a host allocation (or another C++ exception) inside the library
+    if rc == _abi.OUTFIT_ERR_NO_MEMORY:   # a host allocation inside the library failed (std::bad_alloc)
         raise MemoryError(msg)
+    if rc == _abi.OUTFIT_ERR_INTERNAL:    # any other C++ exception inside the library: a bug, not a resource limit
+        raise NativeLibraryError(msg)
     raise HipRuntimeError(f"rc={rc}: {msg}")
 
 
@@ -249,6 +251,46 @@ class ObsBatch:
         self.traj_key_base = int(traj_key_base)
         self.n_traj = len(self.traj_offset) - 1
         self.traj_ids = list(range(self.n_traj)) if traj_ids is None else list(traj_ids)
+        self.validate()
+
+    def validate(self, params=None):
+        """Every array against the offset table — the library indexes the columns with the offsets themselves, so a
+        table that is monotone but runs past them would be an out-of-bounds read on the other side of the C ABI (the
+        reference materialises each trajectory from data it owns, obs_dataset_api.rs:210-226, and cannot overrun).
+        Raises InvalidBatch (a ValueError). With `params`, also the length of the host-drawn normals."""
+        if self.traj_offset.ndim != 1 or self.n_traj < 0:
+            raise InvalidBatch("traj_offset needs n_traj + 1 entries (at least one)")
+        off = self.traj_offset
+        if self.n_traj and bool((off[1:] < off[:-1]).any()):
+            raise InvalidBatch("traj_offset must be non-decreasing")
+        end = int(off[-1])
+        for k in ("mjd_tt", "ra", "dec", "sigma_ra", "sigma_dec", "mjd_ut1"):
+            a = getattr(self, k)
+            if a is not None and a.size < end:
+                raise InvalidBatch(f"traj_offset[-1] = {end} runs past `{k}` ({a.size} rows)")
+            if a is None and k != "mjd_ut1" and end > int(off[0]):
+                raise InvalidBatch(f"`{k}` is missing")
+        for k in ("obs_helio_equ", "obs_geo_ecl", "obs_body_fixed"):
+            a = getattr(self, k)
+            if a is not None and a.size < 3 * end:
+                raise InvalidBatch(f"traj_offset[-1] = {end} runs past `{k}` ({a.size} doubles, 3 per observation are needed)")
+        if self.traj_key is not None and self.traj_key.size < self.n_traj:
+            raise InvalidBatch(f"`traj_key` has {self.traj_key.size} entries for {self.n_traj} trajectories")
+        if len(self.traj_ids) != self.n_traj:
+            raise InvalidBatch(f"`traj_ids` has {len(self.traj_ids)} entries for {self.n_traj} trajectories")
+        if params is not None and self.noise_z is not None and self.noise_seed is None and params.n_noise_realizations > 0:
+            need = self.n_traj * int(params.max_triplets) * int(params.n_noise_realizations) * 6
+            if self.noise_z.size < need:
+                raise InvalidBatch(f"`noise_z` has {self.noise_z.size} normals; n_traj x max_triplets x "
+                                   f"n_noise_realizations x 6 = {need} are needed")
+
+    def capacities(self):
+        """(n_obs_capacity, noise_z_capacity) for outfit_hip_call_options_t: what the arrays handed over really hold."""
+        cols = [getattr(self, k).size for k in ("mjd_tt", "ra", "dec", "sigma_ra", "sigma_dec", "mjd_ut1")
+                if getattr(self, k) is not None]
+        cols += [getattr(self, k).size // 3 for k in ("obs_helio_equ", "obs_geo_ecl", "obs_body_fixed")
+                 if getattr(self, k) is not None]
+        return (min(cols) if cols else 0), (0 if self.noise_z is None else int(self.noise_z.size))
 
     @classmethod
     def from_dict(cls, d, with_geo=True, device_geometry=False):
@@ -361,13 +403,18 @@ def record_to_result(rec, batch=None, traj_index=None, params=None):
 MATH_DEFAULT, MATH_CORRECTLY_ROUNDED, MATH_GLIBC = -1, 0, 1
 
 
-def _options(math_mode):
-    """outfit_hip_call_options_t for one call; None = all defaults (NULL pointer)."""
-    if math_mode is None:
+def _options(math_mode, batch=None, params=None):
+    """outfit_hip_call_options_t for one call: the math mode (None = the process-wide default) and, with `batch`, the
+    lengths of its arrays — checked here (InvalidBatch) and stated to the library, which checks them again."""
+    if math_mode is None and batch is None:
         return None
     o = CallOptionsC()
     lib().outfit_hip_call_options_default(C.byref(o))
-    o.math_mode = int(math_mode)
+    if math_mode is not None:
+        o.math_mode = int(math_mode)
+    if batch is not None:
+        batch.validate(params)          # attributes may have been replaced since __init__ (e.g. noise_z of a slice)
+        o.n_obs_capacity, o.noise_z_capacity = batch.capacities()
     return C.byref(o)
 
 
@@ -407,7 +454,8 @@ def fit_full_iod_records(batch, ephem, params, n_devices=0, math_mode=None):
     ec = ephem.as_c() if ephem is not None else None
     out = np.empty(max(batch.n_traj, 1), dtype=RESULT_DTYPE)   # the records land in the array that is returned
     rc = L.outfit_hip_fit_full_iod_ex(C.byref(pc), C.byref(bc), C.byref(ec) if ec is not None else None,
-                                      n_devices, _options(math_mode), out.ctypes.data_as(C.POINTER(GaussResultC)))
+                                      n_devices, _options(math_mode, batch, params),
+                                      out.ctypes.data_as(C.POINTER(GaussResultC)))
     if rc != 0:
         _raise_rc(rc)
     return out[:batch.n_traj]
@@ -446,7 +494,7 @@ class IODSession:
         h = C.c_void_p()
         rc = self._L.outfit_hip_session_create_ex(C.byref(pc), C.byref(bc),
                                                   C.byref(ec) if ec is not None else None, device,
-                                                  _options(math_mode), C.byref(h))
+                                                  _options(math_mode, batch, params), C.byref(h))
         if rc != 0:
             _raise_rc(rc)
         self._h = h
@@ -621,7 +669,7 @@ def fit_lsq_records(batch, ephem, iod_params, diff_cor_config, initial_orbits=No
     out = (LsqResultC * max(n, 1))()
     fit = (ObsFitC * max(n_obs, 1))()
     rc = L.outfit_hip_fit_lsq_ex(C.byref(pc), C.byref(cc), C.byref(bc), C.byref(ec) if ec is not None else None,
-                                 _initial_c(initial_orbits, n), n_devices, _options(math_mode), out, fit)
+                                 _initial_c(initial_orbits, n), n_devices, _options(math_mode, batch, iod_params), out, fit)
     if rc != 0:
         _raise_rc(rc)
     return (np.frombuffer(out, dtype=LSQ_DTYPE)[:n].copy(), np.frombuffer(fit, dtype=OBS_FIT_DTYPE)[:n_obs].copy())

@@ -17,6 +17,7 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <stdexcept>
@@ -44,9 +45,16 @@ int current_math_mode() {
   }
   return m;
 }
-// the mode one call runs in: what its options name, else the process-wide default at this moment
-int resolve_math_mode(const outfit_hip_call_options_t* o, int* out) {
-  if (!o) { *out = current_math_mode(); return OUTFIT_OK; }
+// what one call's options say: the math mode (else the process-wide default at this moment) and, since ABI v7, how many
+// rows / doubles the caller's arrays hold (0 = not stated: the library then trusts traj_offset, as the reference trusts
+// its own owned data, obs_dataset_api.rs:210-226)
+struct CallOpts {
+  int mode = 0;
+  uint64_t n_obs_capacity = 0, noise_z_capacity = 0;
+};
+int resolve_options(const outfit_hip_call_options_t* o, CallOpts* out) {
+  *out = CallOpts{};
+  if (!o) { out->mode = current_math_mode(); return OUTFIT_OK; }
   // struct_size first: only the bytes it covers may be read. A struct of an OLDER (shorter) ABI is accepted as long as
   // it reaches math_mode; fields it does not have take their defaults. reserved[] must be zero so that a later version
   // can give it a meaning.
@@ -54,22 +62,42 @@ int resolve_math_mode(const outfit_hip_call_options_t* o, int* out) {
     g_last_error = "call options: struct_size does not cover math_mode (set it to sizeof(outfit_hip_call_options_t))";
     return OUTFIT_ERR_INVALID_PARAM;
   }
-  for (size_t k = 0; k < 3; ++k) {
-    const size_t end = offsetof(outfit_hip_call_options_t, reserved) + (k + 1) * sizeof(uint64_t);
-    if (o->struct_size >= end && o->reserved[k] != 0) {
-      g_last_error = "call options: reserved words must be zero";
-      return OUTFIT_ERR_INVALID_PARAM;
-    }
+  auto covers = [o](size_t off) { return o->struct_size >= off + sizeof(uint64_t); };
+  if (covers(offsetof(outfit_hip_call_options_t, n_obs_capacity))) out->n_obs_capacity = o->n_obs_capacity;
+  if (covers(offsetof(outfit_hip_call_options_t, noise_z_capacity))) out->noise_z_capacity = o->noise_z_capacity;
+  if (covers(offsetof(outfit_hip_call_options_t, reserved)) && o->reserved[0] != 0) {
+    g_last_error = "call options: reserved words must be zero";
+    return OUTFIT_ERR_INVALID_PARAM;
   }
-  if (o->math_mode == OUTFIT_MATH_DEFAULT) { *out = current_math_mode(); return OUTFIT_OK; }
+  if (o->math_mode == OUTFIT_MATH_DEFAULT) { out->mode = current_math_mode(); return OUTFIT_OK; }
   if (o->math_mode != OUTFIT_MATH_CORRECTLY_ROUNDED && o->math_mode != OUTFIT_MATH_GLIBC) {
     g_last_error = "call options: math_mode must be OUTFIT_MATH_DEFAULT, _CORRECTLY_ROUNDED or _GLIBC";
     return OUTFIT_ERR_INVALID_PARAM;
   }
-  *out = o->math_mode;
+  out->mode = o->math_mode;
   return OUTFIT_OK;
 }
 
+int fail_nothrow(int code, const char* a, const char* b) noexcept {
+  try {
+    g_last_error = a;
+    if (b) g_last_error += b;
+  } catch (...) {
+    g_last_error.clear();  // noexcept
+  }
+  return code;
+}
+// what a catch block turns the exception in flight into (a shard thread stores it instead of returning it)
+int code_of_current_exception(std::string* msg) noexcept {
+  int code = OUTFIT_ERR_INTERNAL;
+  const char *a = "internal error: unknown exception", *b = nullptr;
+  try { throw; }
+  catch (const std::bad_alloc&) { code = OUTFIT_ERR_NO_MEMORY; a = "host allocation failed"; }
+  catch (const std::exception& e) { a = "internal error: "; b = e.what(); }
+  catch (...) {}
+  try { *msg = a; if (b) *msg += b; } catch (...) { msg->clear(); }
+  return code;
+}
 int fail(int code, const std::string& msg) {
   g_last_error = msg;
   return code;
@@ -77,10 +105,11 @@ int fail(int code, const std::string& msg) {
 
 // Nothing may unwind through the C ABI (the caller is Rust, C or ctypes): every entry point that can allocate or start a
 // thread is a function-try-block ending in this handler.
+// The handlers themselves must not throw: fail_nothrow() falls back to an empty message when even that allocation fails.
 #define OUTFIT_ABI_CATCH                                                                               \
-  catch (const std::bad_alloc&) { return fail(OUTFIT_ERR_NO_MEMORY, "host allocation failed"); }       \
-  catch (const std::exception& e) { return fail(OUTFIT_ERR_NO_MEMORY, std::string("internal error: ") + e.what()); } \
-  catch (...) { return fail(OUTFIT_ERR_NO_MEMORY, "internal error: unknown exception"); }
+  catch (const std::bad_alloc&) { return fail_nothrow(OUTFIT_ERR_NO_MEMORY, "host allocation failed", nullptr); } \
+  catch (const std::exception& e) { return fail_nothrow(OUTFIT_ERR_INTERNAL, "internal error: ", e.what()); }     \
+  catch (...) { return fail_nothrow(OUTFIT_ERR_INTERNAL, "internal error: unknown exception", nullptr); }
 
 }  // namespace
 namespace outfit {
@@ -212,18 +241,18 @@ struct DeviceCache {
     }
     return e;
   }
-  void put(void* p, size_t cap) {
+  void put(void* p, size_t cap) noexcept {  // called from destructors: a failed map insertion frees the block instead
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (disabled || dev < 0 || dev >= 64) { (void)hipFree(p); return; }
-    {
+    try {
       std::lock_guard<std::mutex> g(m);
       if (parked[dev] + cap <= limit) {
         blocks[dev].emplace(cap, p);
         parked[dev] += cap;
         return;
       }
-    }
+    } catch (...) {}
     (void)hipFree(p);  // over the limit: back to the driver
   }
   void trim() {
@@ -258,6 +287,12 @@ struct DevBuf {
     p = nullptr;
     n = cap = 0;
   }
+  // a buffer that goes out of scope (an early return, an exception on the way to OUTFIT_ERR_NO_MEMORY) gives its block
+  // back to the cache; sessions release theirs in free_all(), where the order against stream synchronisation matters
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
 };
 
 enum KernelId { K_TRIPLETS = 0, K_PREPASS, K_ROOTS, K_CORRECT_FAST, K_CORRECT, K_RMS, K_RMS_SLOW, K_SELECT, K_REFINE, K_DIFFCOR, K_COUNT };
@@ -389,7 +424,8 @@ hipError_t wait_last_run(outfit_hip_session* s) {
   return s->own_stream ? hipStreamSynchronize(s->own_stream) : hipSuccess;
 }
 
-int check_batch(const outfit_iod_params_t* params, const outfit_obs_batch_t* b, const outfit_ephem_t* eph) {
+int check_batch(const outfit_iod_params_t* params, const outfit_obs_batch_t* b, const outfit_ephem_t* eph,
+                const CallOpts& opts = CallOpts{}) {
   if (!b) return fail(OUTFIT_ERR_INVALID_BATCH, "batch is NULL");
   if (b->n_traj > 0 && !b->traj_offset) return fail(OUTFIT_ERR_INVALID_BATCH, "traj_offset is NULL");
   if (b->n_traj == 0) return OUTFIT_OK;
@@ -401,6 +437,11 @@ int check_batch(const outfit_iod_params_t* params, const outfit_obs_batch_t* b, 
       return fail(OUTFIT_ERR_INVALID_BATCH, "a trajectory has 2^21 or more observations");
   }
   const uint64_t n_obs = b->traj_offset[b->n_traj] - o0;
+  // the columns are indexed by the offsets themselves (row traj_offset[t] .. traj_offset[t+1]-1): a table that is
+  // monotone but runs past the caller's arrays is an out-of-bounds read unless the caller says how long they are
+  if (opts.n_obs_capacity && b->traj_offset[b->n_traj] > opts.n_obs_capacity)
+    return fail(OUTFIT_ERR_INVALID_BATCH, "traj_offset[n_traj] = " + std::to_string(b->traj_offset[b->n_traj]) +
+                " runs past the observation columns (options.n_obs_capacity = " + std::to_string(opts.n_obs_capacity) + " rows)");
   const bool device_geometry = b->obs_body_fixed != nullptr || b->mjd_ut1 != nullptr;
   if (device_geometry && (!b->obs_body_fixed || !b->mjd_ut1 || !eph))
     return fail(OUTFIT_ERR_INVALID_BATCH, "obs_body_fixed, mjd_ut1 and an ephemeris are needed together");
@@ -415,6 +456,12 @@ int check_batch(const outfit_iod_params_t* params, const outfit_obs_batch_t* b, 
   const uint64_t cpt = (uint64_t)params->max_triplets * (1 + params->n_noise_realizations);
   if (params->n_noise_realizations >= (1ull << 31) || cpt >= (1ull << 31))
     return fail(OUTFIT_ERR_INVALID_PARAM, "max_triplets * (1 + n_noise_realizations) must be < 2^31");
+  if (opts.noise_z_capacity && b->noise_z && params->n_noise_realizations > 0 && b->noise_source == OUTFIT_NOISE_HOST) {
+    const uint64_t per_traj = (uint64_t)params->max_triplets * params->n_noise_realizations * 6;   // < 2^34
+    if (b->n_traj > opts.noise_z_capacity / per_traj)
+      return fail(OUTFIT_ERR_INVALID_BATCH, "noise_z holds " + std::to_string(opts.noise_z_capacity) + " doubles (options."
+                  "noise_z_capacity); n_traj x max_triplets x n_noise_realizations x 6 are needed");
+  }
   if (eph) {
     if (!eph->coef || eph->n_blocks == 0) return fail(OUTFIT_ERR_INVALID_BATCH, "ephemeris table is empty");
     for (int k = 0; k < 3; ++k)
@@ -704,9 +751,8 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
     }
     const uint64_t lds = (reduced + 2ull * s->k_cap) * sizeof(double);
     if (wave_min && s->k_cap > 0 && reduced >= wave_min && lds <= 60ull * 1024 && s->n_traj < (1ull << 32)) {
-      const uint64_t keep = std::max<uint64_t>(params->max_obs_for_triplets, 3);
-      for (uint64_t t = 0; t < s->n_traj; ++t)
-        if (std::min<uint64_t>(off[t + 1] - off[t], keep) >= wave_min && off[t + 1] - off[t] >= 3)
+      for (uint64_t t = 0; t < s->n_traj; ++t)   // the lane kernels skip a trajectory by the same function
+        if (outfit::wave_form_owns(off[t + 1] - off[t], s->tp.max_keep, wave_min))
           s->wave_list_host.push_back((unsigned)t);
       if (!s->wave_list_host.empty()) {
         s->wave_min_obs = wave_min;
@@ -1064,14 +1110,32 @@ int run_sharded(const outfit_iod_params_t* params, const outfit_obs_batch_t* bat
       sub.noise_z = batch->noise_z + (size_t)t0 * params->max_triplets * (size_t)params->n_noise_realizations * 6;
     if (batch->traj_key) sub.traj_key = batch->traj_key + t0;
     else sub.traj_key_base = batch->traj_key_base + t0;
-    rc[d] = work(dev_map.empty() ? d : dev_map[d], sub, t0);
-    if (rc[d] != OUTFIT_OK) msg[d] = g_last_error;  // thread-local: keep the shard's message
+    // a worker thread is not behind the entry point's function-try-block: an exception that left this function would
+    // end in std::terminate, so it becomes the shard's return code here
+    try {
+      rc[d] = work(dev_map.empty() ? d : dev_map[d], sub, t0);
+      if (rc[d] != OUTFIT_OK) msg[d] = g_last_error;  // thread-local: keep the shard's message
+    } catch (...) {
+      rc[d] = code_of_current_exception(&msg[d]);
+    }
   };
   if (n_devices == 1) {
     shard(0);
   } else {
+    // threads that cannot be created (std::system_error) or stored: the shard runs on the calling thread instead, and
+    // every thread that did start is joined before anything can unwind past the vector
     std::vector<std::thread> th;
-    for (int d = 0; d < n_devices; ++d) th.emplace_back(shard, d);
+    try { th.reserve(n_devices); } catch (...) {}
+    for (int d = 0; d < n_devices; ++d) {
+      bool started = false;
+      if (th.size() < th.capacity()) {
+        try {
+          th.emplace_back(shard, d);
+          started = true;
+        } catch (...) {}
+      }
+      if (!started) shard(d);
+    }
     for (auto& t : th) t.join();
   }
   for (int d = 0; d < n_devices; ++d)
@@ -1145,9 +1209,13 @@ void outfit_hip_call_options_default(outfit_hip_call_options_t* o) {
 int outfit_hip_session_create_ex(const outfit_iod_params_t* params, const outfit_obs_batch_t* batch,
                                  const outfit_ephem_t* ephem, int device, const outfit_hip_call_options_t* options,
                                  outfit_hip_session_t** out) try {
-  int mode = 0;
-  TRY_RC(resolve_math_mode(options, &mode));
-  return session_create(params, batch, ephem, device, /*streaming=*/false, mode, out);
+  CallOpts opts;
+  TRY_RC(resolve_options(options, &opts));
+  if (opts.n_obs_capacity || opts.noise_z_capacity) {   // (session_create repeats the other checks)
+    TRY_RC(outfit_hip_iod_params_validate(params));
+    TRY_RC(check_batch(params, batch, ephem, opts));
+  }
+  return session_create(params, batch, ephem, device, /*streaming=*/false, opts.mode, out);
 } OUTFIT_ABI_CATCH
 int outfit_hip_session_create(const outfit_iod_params_t* params, const outfit_obs_batch_t* batch,
                               const outfit_ephem_t* ephem, int device, outfit_hip_session_t** out) try {
@@ -1165,17 +1233,21 @@ int session_create(const outfit_iod_params_t* params, const outfit_obs_batch_t* 
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
     return fail(OUTFIT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
   if (device < 0 || device >= n_dev) return fail(OUTFIT_ERR_NO_DEVICE, "device index out of range");
-  auto* s = new outfit_hip_session();
+  // owned by a holder until it is handed out: an exception inside session_build (its vectors, the wave list) gives
+  // the cached device blocks, streams and events back before the caller is told OUTFIT_ERR_NO_MEMORY
+  struct Release {
+    void operator()(outfit_hip_session* p) const {
+      p->free_all();
+      delete p;
+    }
+  };
+  std::unique_ptr<outfit_hip_session, Release> s(new outfit_hip_session());
   s->device = device;
   s->streaming = streaming;
   s->math_mode = math_mode;
-  const int rc = session_build(s, params, batch, ephem);
-  if (rc != OUTFIT_OK) {
-    s->free_all();
-    delete s;
-    return rc;
-  }
-  *out = s;
+  const int rc = session_build(s.get(), params, batch, ephem);
+  if (rc != OUTFIT_OK) return rc;
+  *out = s.release();
   return OUTFIT_OK;
 }
 }  // namespace
@@ -1273,10 +1345,11 @@ int outfit_hip_fit_full_iod_ex(const outfit_iod_params_t* params, const outfit_o
                                const outfit_ephem_t* ephem, int n_devices, const outfit_hip_call_options_t* options,
                                outfit_gauss_result_t* out) try {
   TRY_RC(outfit_hip_iod_params_validate(params));
-  TRY_RC(check_batch(params, batch, ephem));
+  CallOpts opts;
+  TRY_RC(resolve_options(options, &opts));  // once per call: every shard runs in the same mode
+  TRY_RC(check_batch(params, batch, ephem, opts));
   if (!out && batch->n_traj) return fail(OUTFIT_ERR_INVALID_BATCH, "out is NULL");
-  int mode = 0;
-  TRY_RC(resolve_math_mode(options, &mode));  // once per call: every shard runs in the same mode
+  const int mode = opts.mode;
   static const bool streamed_upload = std::getenv("OUTFIT_NO_STREAMED_UPLOAD") == nullptr;
   return run_sharded(params, batch, n_devices, [&](int d, const outfit_obs_batch_t& sub, uint64_t t0) {
     outfit_hip_session_t* s = nullptr;
@@ -1356,10 +1429,11 @@ int outfit_hip_fit_lsq_ex(const outfit_iod_params_t* params, const outfit_diffco
                           outfit_lsq_result_t* out, outfit_obs_fit_t* obs_fit) try {
   TRY_RC(outfit_hip_iod_params_validate(params));
   TRY_RC(outfit_hip_diffcor_config_validate(config));
-  TRY_RC(check_batch(params, batch, ephem));
+  CallOpts opts;
+  TRY_RC(resolve_options(options, &opts));
+  TRY_RC(check_batch(params, batch, ephem, opts));
   if (!out && batch->n_traj) return fail(OUTFIT_ERR_INVALID_BATCH, "out is NULL");
-  int mode = 0;
-  TRY_RC(resolve_math_mode(options, &mode));
+  const int mode = opts.mode;
   return run_sharded(params, batch, n_devices, [&](int d, const outfit_obs_batch_t& sub, uint64_t t0) {
     // the IOD runs only when some trajectory has no usable seed (obs_dataset_api.rs:118-120, mod.rs:86)
     bool need_iod = initial == nullptr;

@@ -144,11 +144,19 @@ __device__ __forceinline__ unsigned long long keep_index(unsigned long long i, u
   if (max_keep <= 3) return i == 0 ? 0 : (i == 1 ? n / 2 : n - 1);
   return i * (n - 1) / (max_keep - 1);
 }
-__device__ __forceinline__ unsigned long long reduced_len(unsigned long long n, unsigned long long max_keep) {
+__host__ __device__ __forceinline__ unsigned long long reduced_len(unsigned long long n, unsigned long long max_keep) {
   if (n == 0) return 0;
   if (max_keep >= n) return n;
   if (max_keep <= 3) return 3;
   return max_keep;
+}
+// Which form of K0 owns a trajectory: THE predicate of both sides — the host builds the wave kernel's list with it and
+// the lane kernels skip exactly those trajectories (`max_keep` is the raw max_obs_for_triplets: 0, 1 and 2 are legal
+// and behave like 3, index_generator.rs:66-75). Fewer than 3 observations have no triplet: always the lane form, which
+// writes n_triplets = 0 (a 1- or 2-observation trajectory with max_keep below its length has reduced_len 3).
+__host__ __device__ __forceinline__ bool wave_form_owns(unsigned long long n_obs, unsigned long long max_keep,
+                                                        unsigned wave_min_obs) {
+  return wave_min_obs != 0 && n_obs >= 3 && reduced_len(n_obs, max_keep) >= wave_min_obs;
 }
 
 // mod.rs:265-274

@@ -45,7 +45,7 @@ k_triplet_select(TripletArgs a) {
   const unsigned long long traj = a.traj0 + lt;
   const unsigned long long base = a.traj_offset[traj];
   const unsigned long long n_obs = a.traj_offset[traj + 1] - base;
-  if (a.wave_min_obs && reduced_len(n_obs, a.P.max_keep) >= a.wave_min_obs) return;  // k_triplet_select_wave's
+  if (wave_form_owns(n_obs, a.P.max_keep, a.wave_min_obs)) return;  // k_triplet_select_wave's
   // heap slot s of lane lt: scratch[(s * n_lanes_padded) + lt]
   HeapView h{a.heap_w + lt, a.heap_id + lt, a.heap_stride};
   const unsigned n = select_triplets(a.mjd + base, n_obs, a.P, h);
@@ -64,7 +64,7 @@ k_triplet_select_lds(TripletArgs a) {
   const unsigned long long traj = a.traj0 + lt;
   const unsigned long long base = a.traj_offset[traj];
   const unsigned long long n_obs = a.traj_offset[traj + 1] - base;
-  if (a.wave_min_obs && reduced_len(n_obs, a.P.max_keep) >= a.wave_min_obs) return;  // k_triplet_select_wave's
+  if (wave_form_owns(n_obs, a.P.max_keep, a.wave_min_obs)) return;  // k_triplet_select_wave's
   LdsHeapView h{lds_heap + threadIdx.x, reinterpret_cast<unsigned*>(lds_heap + (size_t)a.P.k_cap * 64) + threadIdx.x,
                 64u};
   const unsigned n = select_triplets(a.mjd + base, n_obs, a.P, h);

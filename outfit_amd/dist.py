@@ -58,6 +58,19 @@ def all_gather_records(local, counts, dist):
     return torch.cat([out[r * n_max: r * n_max + counts[r]] for r in range(world)], dim=0)
 
 
+def shard_of(batch, params, rank, world):
+    """(this rank's sub-batch, per-rank trajectory counts, t0, t1): the contiguous range the partition gives `rank`,
+    with its slice of the host-drawn normals (per trajectory max_triplets * n_noise_realizations * 6 of them)."""
+    cuts = partition_by_observations(batch.traj_offset, world)
+    counts = [cuts[r + 1] - cuts[r] for r in range(world)]
+    t0, t1 = cuts[rank], cuts[rank + 1]
+    sub = batch.slice(t0, t1)
+    if batch.noise_z is not None:
+        stride = params.max_triplets * params.n_noise_realizations * 6
+        sub.noise_z = batch.noise_z[t0 * stride: t1 * stride]
+    return sub, counts, t0, t1
+
+
 def records_from_tensor(t):
     """uint8 [n, 96] tensor -> numpy structured array of outfit_gauss_result_t."""
     return np.frombuffer(t.cpu().numpy().tobytes(), dtype=RESULT_DTYPE)
@@ -77,13 +90,8 @@ class ShardedIOD:
         from .api import IODSession
         self.dist, self.torch = dist, torch
         rank, world = dist.get_rank(), dist.get_world_size()
-        cuts = partition_by_observations(batch.traj_offset, world)
-        self.counts = [cuts[r + 1] - cuts[r] for r in range(world)]
-        self.rank, self.t0, self.t1 = rank, cuts[rank], cuts[rank + 1]
-        sub = batch.slice(self.t0, self.t1)
-        if batch.noise_z is not None:
-            stride = params.max_triplets * params.n_noise_realizations * 6
-            sub.noise_z = batch.noise_z[self.t0 * stride: self.t1 * stride]
+        sub, self.counts, self.t0, self.t1 = shard_of(batch, params, rank, world)
+        self.rank = rank
         self.dev = torch.device("cuda", device_index)
         torch.cuda.current_stream(self.dev)                      # torch's HIP runtime first (see _lib.lib)
         self.stream = torch.cuda.Stream(self.dev)                # explicit: handle 0 would mean "the session's own"
@@ -113,56 +121,32 @@ class ShardedIOD:
             self.session = None
 
 
-def fit_full_iod_distributed(batch, ephem, params, dist, device_index, compute=None, sharded=None):
+def fit_full_iod_distributed(batch, ephem, params, dist, device_index, sharded=None):
     """Strong-scaling entry: every rank passes the SAME batch, computes its own range on its GPU
     and returns the records of ALL trajectories (gathered). Pass `sharded` (a ShardedIOD built from the same
     arguments) to reuse the resident shard across calls; otherwise one is built and closed here.
-
-    `compute(sub_batch) -> structured records` may be injected (the CPU tests pass the oracle
-    there to exercise the sharding and the gather under gloo); by default it is the HIP session."""
-    import torch
-    if compute is None:
-        own = sharded is None
-        sh = sharded or ShardedIOD(batch, ephem, params, dist, device_index)
-        try:
-            return sh.run()
-        finally:
-            if own:
-                sh.close()
-    rank, world = dist.get_rank(), dist.get_world_size()
-    cuts = partition_by_observations(batch.traj_offset, world)
-    counts = [cuts[r + 1] - cuts[r] for r in range(world)]
-    t0, t1 = cuts[rank], cuts[rank + 1]
-    sub = batch.slice(t0, t1)
-    if batch.noise_z is not None:
-        stride = params.max_triplets * params.n_noise_realizations * 6
-        sub.noise_z = batch.noise_z[t0 * stride: t1 * stride]
-    recs = compute(sub) if counts[rank] else np.zeros(0, dtype=RESULT_DTYPE)
-    local = torch.from_numpy(np.frombuffer(recs.tobytes(), dtype=np.uint8).reshape(-1, RECORD_BYTES).copy())
-    return records_from_tensor(all_gather_records(local, counts, dist))
+    There is one code path: the HIP session (no device, no result)."""
+    own = sharded is None
+    sh = sharded or ShardedIOD(batch, ephem, params, dist, device_index)
+    try:
+        return sh.run()
+    finally:
+        if own:
+            sh.close()
 
 
-def fit_lsq_distributed(batch, ephem, iod_params, diff_cor_config, dist, device_index, initial_orbits=None,
-                        compute=None):
+def fit_lsq_distributed(batch, ephem, iod_params, diff_cor_config, dist, device_index, initial_orbits=None):
     """`FitLSQ::fit_lsq` sharded like the IOD (the reference loops over trajectories one by one,
     differential_orbit_correction/obs_dataset_api.rs:76-96: no exchange between them). Every rank passes
-    the SAME batch (and the same optional seeds) and gets the 480-byte records of ALL trajectories.
-
-    `compute(sub_batch, sub_initial) -> LSQ records` may be injected for the CPU tests."""
+    the SAME batch (and the same optional seeds) and gets the 480-byte records of ALL trajectories."""
     import torch
+    from .api import IODSession
     rank, world = dist.get_rank(), dist.get_world_size()
-    cuts = partition_by_observations(batch.traj_offset, world)
-    counts = [cuts[r + 1] - cuts[r] for r in range(world)]
-    t0, t1 = cuts[rank], cuts[rank + 1]
-    sub = batch.slice(t0, t1)
-    if batch.noise_z is not None:
-        stride = iod_params.max_triplets * iod_params.n_noise_realizations * 6
-        sub.noise_z = batch.noise_z[t0 * stride: t1 * stride]
+    sub, counts, t0, t1 = shard_of(batch, iod_params, rank, world)
     sub_init = None if initial_orbits is None else np.ascontiguousarray(initial_orbits[t0:t1])
     if not counts[rank]:
         recs = np.zeros(0, dtype=LSQ_DTYPE)
-    elif compute is None:
-        from .api import IODSession
+    else:
         dev = torch.device("cuda", device_index)
         torch.cuda.current_stream(dev)  # torch's HIP runtime first (see _lib.lib)
         s = IODSession(sub, ephem, iod_params, device=device_index)
@@ -172,10 +156,8 @@ def fit_lsq_distributed(batch, ephem, iod_params, diff_cor_config, dist, device_
         s.run_lsq(diff_cor_config, sub_init, stream=stream)
         recs, _ = s.lsq_results()
         s.close()
-    else:
-        recs = compute(sub, sub_init)
     local = torch.from_numpy(np.frombuffer(recs.tobytes(), dtype=np.uint8).reshape(-1, LSQ_RECORD_BYTES).copy())
-    if compute is None and dist.get_backend() == "nccl":
+    if dist.get_backend() == "nccl":
         local = local.to(torch.device("cuda", device_index))
     out = all_gather_records(local, counts, dist)
     return np.frombuffer(out.cpu().numpy().tobytes(), dtype=LSQ_DTYPE)

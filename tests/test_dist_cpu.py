@@ -1,7 +1,9 @@
 """The N > 1 path on CPU: world_size-2 gloo run of the sharding + gather logic
-(outfit_amd/dist.py). The per-rank compute is injected (the CPU oracle stands in for the
-HIP session here, tests only); what is under test is the partition, the per-rank slicing
-incl. noise, the padded all_gather and the global ordering of the 96-byte records."""
+(outfit_amd/dist.py). What is under test is the partition, the per-rank slicing incl. noise
+(`shard_of`), the padded all_gather (`all_gather_records`) and the global ordering of the
+96- and 480-byte records. The product's entry points have ONE code path, the HIP session; the
+stand-in for it on a box without a GPU — the CPU oracle — lives HERE, in the tests
+(`_distributed_with`), built from the product's own partition and gather functions."""
 import os
 import socket
 import sys
@@ -60,23 +62,49 @@ def _oracle_lsq_compute(ephem, params, cfg):
     return compute
 
 
+def _distributed_with(compute, batch, params, dist, width, dtype, initial=None):
+    """fit_*_distributed with `compute` in the place of the rank's HIP session: same shard, same gather."""
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    sub, counts, t0, t1 = odist.shard_of(batch, params, rank, world)
+    args = (sub,) if initial is None else (sub, np.ascontiguousarray(initial[t0:t1]))
+    recs = compute(*args) if counts[rank] else np.zeros(0, dtype=dtype)
+    local = torch.from_numpy(np.frombuffer(recs.tobytes(), dtype=np.uint8).reshape(-1, width).copy())
+    out = odist.all_gather_records(local, counts, dist)
+    return np.frombuffer(out.numpy().tobytes(), dtype=dtype)
+
+
 def _worker(rank, world, port, out_dir):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     batch, ephem, params = _ragged_batch()
-    recs = odist.fit_full_iod_distributed(batch, ephem, params, dist, device_index=0,
-                                          compute=_oracle_compute(ephem, params))
+    recs = _distributed_with(_oracle_compute(ephem, params), batch, params, dist, odist.RECORD_BYTES,
+                             outfit_amd._abi.RESULT_DTYPE)
     np.save(os.path.join(out_dir, f"rank{rank}.npy"), recs)
     cfg = outfit_amd.DifferentialCorrectionConfig(rms_divergence_ratio=10.0)
     seeds = recs.copy()
     seeds["status"][::3] = 2          # a third of the seeds "missing": the IOD is rerun for them
-    lsq = odist.fit_lsq_distributed(batch, ephem, params, cfg, dist, device_index=0, initial_orbits=seeds,
-                                    compute=_oracle_lsq_compute(ephem, params, cfg))
+    lsq = _distributed_with(_oracle_lsq_compute(ephem, params, cfg), batch, params, dist, odist.LSQ_RECORD_BYTES,
+                            outfit_amd._abi.LSQ_DTYPE, initial=seeds)
     np.save(os.path.join(out_dir, f"lsq_rank{rank}.npy"), lsq)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_shard_of_slices_the_normals_with_the_trajectories():
+    batch, _, params = _ragged_batch()
+    stride = params.max_triplets * params.n_noise_realizations * 6
+    seen = 0
+    for rank in range(3):
+        sub, counts, t0, t1 = odist.shard_of(batch, params, rank, 3)
+        assert sub.n_traj == counts[rank] == t1 - t0 and t0 == seen
+        assert np.array_equal(sub.noise_z, batch.noise_z[t0 * stride:t1 * stride])
+        assert np.array_equal(sub.mjd_tt, batch.mjd_tt[int(batch.traj_offset[t0]):int(batch.traj_offset[t1])])
+        sub.validate(params)
+        seen = t1
+    assert seen == batch.n_traj
 
 
 def test_partition_is_contiguous_and_balanced():

@@ -129,6 +129,33 @@ def test_wave_form_of_k0_equals_the_lane_form(case, monkeypatch):
     assert (rec_lane["n_triplets"] > 0).any()
 
 
+@pytest.mark.parametrize("max_keep", [0, 1, 2])
+def test_tiny_max_obs_for_triplets_and_trajectories_without_a_triplet(max_keep, monkeypatch):
+    """max_obs_for_triplets of 0, 1 or 2 is legal and behaves like 3 (index_generator.rs:66-75). A trajectory of 1 or 2
+    observations then has a REDUCED length of 3 although it has no triplet: the lane kernels used to leave it to the
+    wave kernel while the host did not list it there, so n_triplets kept what the cached block held. One
+    predicate now (device/triplets.hpp wave_form_owns). The block is polluted first: a run of the same shape in which
+    every trajectory has triplets."""
+    ephem_d = synth.make_ephemeris(n_blocks=24)
+    ephem = outfit_amd.Ephemeris.from_dict(ephem_d)
+    ragged = _ragged(ephem_d)                                   # lengths 32, 20, 3, 2, 0, 1, 7, ... (40 trajectories)
+    full = outfit_amd.ObsBatch.from_dict(synth.make_dataset(40, seed=5, ephem=ephem_d, n_nights=8, n_exp=4))
+    params = outfit_amd.IODParams(n_noise_realizations=0, max_obs_for_triplets=max_keep, max_triplets=30)
+    ref = oracle(params, ragged, ephem)
+    lens = np.diff(ragged.traj_offset.astype(np.int64))
+    assert (ref["status"][lens < 3] == 1).all() and (ref["n_triplets"][lens < 3] == 0).all()   # NoFeasibleTriplets
+    for wave_min in ("3", None, "0"):                           # every trajectory by the wave form / the host's choice / none
+        if wave_min is None:
+            monkeypatch.delenv("OUTFIT_K0_WAVE_MIN", raising=False)
+        else:
+            monkeypatch.setenv("OUTFIT_K0_WAVE_MIN", wave_min)
+        pol, _ = _run(full, ephem, outfit_amd.IODParams(n_noise_realizations=0, max_triplets=30))
+        assert (pol["n_triplets"] == 30).all()
+        got, _ = _run(ragged, ephem, params)
+        assert np.array_equal(got["n_triplets"], ref["n_triplets"]) and np.array_equal(got["status"], ref["status"])
+        assert got.tobytes() == ref.tobytes() or compare(got, ref) == 0
+
+
 def test_mixed_batch_uses_both_forms():
     """Short and long trajectories in one batch: the lane kernel takes the short ones, the wave kernel the long ones
     (the session's list), slice by slice; records == the same batch with the wave form switched off."""

@@ -146,6 +146,11 @@ def test_product_does_not_reference_the_oracle():
                 assert "oracle_lib" not in text and "liboutfit_oracle" not in text \
                     and not re.search(r"\borc_\w+\(", text), \
                     f"{os.path.join(dirpath, f)} refers to the oracle"
+                # ... nor keep a hook through which a caller could put something else in the kernels' place
+                # (outfit_amd/dist.py had `compute=` for the CPU tests until round 5: that stand-in lives in tests/ now)
+                if f.endswith(".py"):
+                    assert "compute=" not in text and not re.search(r"def \w+\([^)]*\bcompute\b", text), \
+                        f"{os.path.join(dirpath, f)} has a compute-injection hook"
 
 
 def test_record_to_result_mirrors_reference_variants():
@@ -202,7 +207,7 @@ def test_equinoctial_to_keplerian_known_answer():
 def test_round2_host_entry_points_without_a_gpu(L):
     """Host-side behaviour of the ABI v5 additions (no compute): math mode, SolverType defaults and validation, cache."""
     from outfit_amd import _abi
-    assert L.outfit_hip_abi_version() == 6
+    assert L.outfit_hip_abi_version() == 7
     prev = L.outfit_hip_get_math_mode()
     assert prev == _abi_const("OUTFIT_MATH_GLIBC")        # the drop-in default (unless OUTFIT_MATH_MODE=cr)
     try:
@@ -257,7 +262,8 @@ def test_call_options_abi_v6_without_a_gpu(L):
         assert b"struct_size" in L.outfit_hip_last_error()
     # reserved words must be zero (so that a later ABI can give them a meaning) ...
     L.outfit_hip_call_options_default(C.byref(o))
-    o.reserved[1] = 5
+    assert (o.n_obs_capacity, o.noise_z_capacity) == (0, 0)     # ABI v7: two of v6's reserved words; 0 = not stated
+    o.reserved[0] = 5
     assert L.outfit_hip_fit_full_iod_ex(C.byref(pc), C.byref(bc), C.byref(ec), 1, C.byref(o), out) == -1
     assert b"reserved" in L.outfit_hip_last_error()
     # ... but are not read beyond struct_size: a caller struct that ends after math_mode is a valid shorter ABI
@@ -265,7 +271,7 @@ def test_call_options_abi_v6_without_a_gpu(L):
     rc = L.outfit_hip_fit_full_iod_ex(C.byref(pc), C.byref(bc), C.byref(ec), 1, C.byref(o), out)
     assert b"reserved" not in L.outfit_hip_last_error() and b"struct_size" not in L.outfit_hip_last_error()
     assert rc in (0, _abi_const("OUTFIT_ERR_NO_DEVICE"))    # options accepted: the call gets as far as the device
-    o.reserved[1] = 0
+    o.reserved[0] = 0
     o.math_mode, o.struct_size = 1, 4
     h = C.c_void_p()
     assert L.outfit_hip_session_create_ex(C.byref(pc), C.byref(bc), C.byref(ec), 0, C.byref(o), C.byref(h)) == -1
@@ -293,6 +299,79 @@ def test_no_exception_crosses_the_c_abi():
     L.outfit_hip_selftest_abi_guard.restype = C.c_int
     L.outfit_hip_last_error.restype = C.c_char_p
     assert L.outfit_hip_selftest_abi_guard(3) == 0
-    for kind, text in ((0, b"allocation"), (1, b"selftest"), (2, b"unknown")):
-        assert L.outfit_hip_selftest_abi_guard(kind) == _abi.OUTFIT_ERR_NO_MEMORY
+    # std::bad_alloc is a resource limit (-8, MemoryError in the Python mirror); anything else is a bug (-9, v7)
+    for kind, text, code in ((0, b"allocation", _abi.OUTFIT_ERR_NO_MEMORY), (1, b"selftest", _abi.OUTFIT_ERR_INTERNAL),
+                             (2, b"unknown", _abi.OUTFIT_ERR_INTERNAL)):
+        assert L.outfit_hip_selftest_abi_guard(kind) == code
         assert text in L.outfit_hip_last_error()
+
+
+def _overrunning_batch():
+    """The offset table of the round-4 crash (gpurun_out/r4c, fixed in the TEST by e84fdce): blocks appended with
+    `off.extend(off[-1] + n * (i + 1) ...)` evaluated lazily, so that the offsets grow as b + n, b + 3n, b + 6n, ... —
+    non-decreasing, every trajectory shorter than 2^21 rows, and far past the end of the observation columns."""
+    import outfit_amd
+    from outfit_amd import synth
+    ds = synth.make_dataset(40)
+    n = 20
+    off = [0]
+    for _ in range(2):
+        off.extend(off[-1] + n * (i + 1) for i in range(20))     # the generator reads off[-1] while extend() grows it
+    off = np.array(off, dtype=np.uint64)
+    assert (np.diff(off.astype(np.int64)) > 0).all() and int(off[-1]) > 40 * n
+    cols = [ds[k] for k in ("mjd_tt", "ra", "dec", "sigma_ra", "sigma_dec")]
+    return outfit_amd, ds, off, cols
+
+
+def test_offset_table_past_the_columns_is_an_error_not_a_crash(L):
+    """the library indexes the columns with the offsets themselves. The Python mirror knows every
+    length and refuses the batch (InvalidBatch, a ValueError); a C caller states the lengths in the call options
+    (n_obs_capacity, ABI v7) and gets OUTFIT_ERR_INVALID_BATCH — before any device work, so this runs without a GPU."""
+    from outfit_amd import _abi
+    outfit_amd, ds, off, cols = _overrunning_batch()
+    with pytest.raises(ValueError, match="runs past"):
+        outfit_amd.ObsBatch(off, *cols, ds["obs_helio_equ"], ds["obs_geo_ecl"])
+    good = outfit_amd.ObsBatch.from_dict(ds)
+    # every column is checked, the 3-vectors against 3 x rows
+    for k in ("ra", "sigma_dec"):
+        d = dict(ds); d[k] = ds[k][:-1]
+        with pytest.raises(outfit_amd.InvalidBatch, match=k):
+            outfit_amd.ObsBatch.from_dict(d)
+    for k in ("obs_helio_equ", "obs_geo_ecl"):
+        d = dict(ds); d[k] = ds[k][:-3]
+        with pytest.raises(outfit_amd.InvalidBatch, match=k):
+            outfit_amd.ObsBatch.from_dict(d)
+    with pytest.raises(outfit_amd.InvalidBatch, match="non-decreasing"):
+        outfit_amd.ObsBatch(np.array([0, 40, 20], dtype=np.uint64), *cols, ds["obs_helio_equ"])
+    with pytest.raises(outfit_amd.InvalidBatch, match="traj_key"):
+        outfit_amd.ObsBatch(ds["traj_offset"], *cols, ds["obs_helio_equ"], traj_key=np.arange(3))
+    # host-drawn normals against the parameters, at call time (attributes can be replaced after construction)
+    params = outfit_amd.IODParams(n_noise_realizations=2, max_triplets=5)
+    good.noise_z = np.zeros(40 * 5 * 2 * 6 - 1)
+    with pytest.raises(outfit_amd.InvalidBatch, match="noise_z"):
+        outfit_amd.fit_full_iod_records(good, outfit_amd.Ephemeris.from_dict(ds["ephem"]), params, n_devices=1)
+    good.noise_z = None
+    good.traj_offset = off                                     # the crash's table, put in behind the constructor's back
+    with pytest.raises(ValueError, match="runs past"):
+        outfit_amd.IODSession(good, outfit_amd.Ephemeris.from_dict(ds["ephem"]), outfit_amd.IODParams())
+    # the C side: the same table with the lengths stated in the options
+    good.traj_offset = ds["traj_offset"]
+    pc, bc, ec = outfit_amd.IODParams().as_c(), good.as_c(), outfit_amd.Ephemeris.from_dict(ds["ephem"]).as_c()
+    bc.traj_offset = off.ctypes.data_as(C.POINTER(C.c_uint64))
+    o = _abi.CallOptionsC()
+    L.outfit_hip_call_options_default(C.byref(o))
+    o.n_obs_capacity = 40 * 20
+    out = (_abi.GaussResultC * 40)()
+    h = C.c_void_p()
+    assert L.outfit_hip_fit_full_iod_ex(C.byref(pc), C.byref(bc), C.byref(ec), 1, C.byref(o), out) == _abi.OUTFIT_ERR_INVALID_BATCH
+    assert b"n_obs_capacity" in L.outfit_hip_last_error()
+    assert L.outfit_hip_session_create_ex(C.byref(pc), C.byref(bc), C.byref(ec), 0, C.byref(o), C.byref(h)) == _abi.OUTFIT_ERR_INVALID_BATCH
+    assert not h.value
+    # noise_z_capacity: one normal short
+    bc.traj_offset = good.traj_offset.ctypes.data_as(C.POINTER(C.c_uint64))
+    z = np.zeros(40 * 5 * 2 * 6 - 1)
+    bc.noise_z = z.ctypes.data_as(C.POINTER(C.c_double))
+    o.noise_z_capacity = z.size
+    pn = params.as_c()
+    assert L.outfit_hip_fit_full_iod_ex(C.byref(pn), C.byref(bc), C.byref(ec), 1, C.byref(o), out) == _abi.OUTFIT_ERR_INVALID_BATCH
+    assert b"noise_z_capacity" in L.outfit_hip_last_error()
