@@ -330,7 +330,7 @@ struct outfit_hip_session {
   DevBuf<unsigned long long> traj_offset, traj_key;
   bool noise_device = false;
   unsigned long long noise_seed = 0, traj_key_base = 0;
-  DevBuf<double> mjd, ra, dec, sra, sdec, helio, geo, obs_pos, cos_dec, unit[2], noise, coef;
+  DevBuf<double> mjd, ra, dec, sra, sdec, helio, geo, obs_pos, cos_dec, obs_rec, unit[2], noise, coef;
   DevBuf<double> heap_w, sum, dirS, roots, state, psi0, sel_bound;
   DevBuf<unsigned long long> heap_id, triplets[2], queue, slow_list, slow_count;
   DevBuf<unsigned> sel_list;  // K3 -> K3b: contender candidates per trajectory of the chunk (kernels.h)
@@ -395,7 +395,7 @@ struct outfit_hip_session {
       if (st) (void)hipStreamSynchronize(st);
     g_trace.mark("  destroy: sync");
     traj_offset.release(); traj_key.release(); mjd.release(); ra.release(); dec.release(); sra.release(); sdec.release();
-    helio.release(); geo.release(); obs_pos.release(); cos_dec.release(); unit[0].release(); unit[1].release(); noise.release(); coef.release();
+    helio.release(); geo.release(); obs_pos.release(); cos_dec.release(); obs_rec.release(); unit[0].release(); unit[1].release(); noise.release(); coef.release();
     heap_w.release(); sum.release(); dirS.release(); roots.release(); state.release();
     psi0.release(); slow_list.release(); slow_count.release(); sel_bound.release(); sel_list.release();
     heap_id.release(); triplets[0].release(); triplets[1].release(); queue.release(); wave_list.release();
@@ -629,6 +629,7 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
   if (device_geometry) HIP_TRY(s->helio.alloc(3 * n));
   else TRY_RC(put_rows(s, s->helio, n ? b->obs_helio_equ + 3 * o0 : nullptr, n, 3, 1));
   HIP_TRY(s->cos_dec.alloc(n));
+  HIP_TRY(s->obs_rec.alloc((size_t)outfit::kObsRecDoubles * n));
   for (int b = 0; b < 2; ++b) HIP_TRY(s->unit[b].alloc(3 * n));  // double-buffered: written ahead on k0_stream
   if (s->has_ephem && s->has_geo) {
     if (device_geometry) HIP_TRY(s->geo.alloc(3 * n));
@@ -728,6 +729,7 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
   s->gp.max_tested_solutions = saturate_u32(params->max_tested_solutions);
   s->gp.newton_max_it = saturate_u32(params->newton_max_it);
   s->gp.math_mode = s->math_mode;
+  s->gp.derive();
   s->tp.dt_min = params->dt_min;
   s->tp.dt_max = params->dt_max_triplet;
   s->tp.inv_dtw = 1.0 / params->optimal_interval_time;  // f64::recip (mod.rs:347)
@@ -801,6 +803,7 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
   outfit::PrepassArgs pa{};
   pa.n_obs = s->n_obs; pa.mjd = s->mjd.p; pa.dec = s->dec.p; pa.geo_ecl = s->geo.p; pa.obs_pos = s->obs_pos.p;
   pa.cos_dec = s->cos_dec.p; pa.unit = s->unit[ub].p; pa.ra = s->ra.p; pa.has_table = on_device_earth;
+  pa.obs_rec = s->obs_rec.p; pa.sra = s->sra.p; pa.sdec = s->sdec.p; pa.helio = s->helio.p;
   pa.T = s->table; pa.error_flag = s->error_flag.p; pa.math_mode = s->math_mode;
   // Streamed blocking call: the inputs of these two launches are still on their way; each is enqueued (first chunk)
   // right after its upload group, while K0 / the candidate kernels already run (see `Deferred`).
@@ -936,7 +939,7 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
     const bool glibc_mode = s->math_mode == OUTFIT_MATH_GLIBC;
     const int rms_mode = exact_all ? 1 : (no_screen_env || (!glibc_mode && exact_all_env)) ? 0 : 2;
     const bool refine = glibc_mode ? !exact_all : rms_mode == 2;
-    const outfit::RmsArgs rm{ci, w, obs_pos, s->cos_dec.p, s->params.extf, s->params.dtmax, outfit::sincos_consts(),
+    const outfit::RmsArgs rm{ci, w, obs_pos, s->cos_dec.p, s->obs_rec.p, s->params.extf, s->params.dtmax, outfit::sincos_consts(),
                              rms_mode};
     HIP_TRY(hipStreamWaitEvent(st, s->ev_prepass, 0));
     {
@@ -1026,6 +1029,7 @@ int session_run_lsq(outfit_hip_session* s, const outfit_diffcor_config_t* cfg,
     outfit::PrepassArgs pa{};
     pa.n_obs = s->n_obs; pa.mjd = s->mjd.p; pa.dec = s->dec.p; pa.geo_ecl = s->geo.p; pa.obs_pos = s->obs_pos.p;
     pa.cos_dec = s->cos_dec.p; pa.unit = s->unit[0].p; pa.ra = s->ra.p; pa.has_table = on_device_earth;
+    pa.obs_rec = s->obs_rec.p; pa.sra = s->sra.p; pa.sdec = s->sdec.p; pa.helio = s->helio.p;
     pa.parts = outfit::kPrepassObserver;  // the corrector reads obs_pos only
     pa.T = s->table; pa.error_flag = s->error_flag.p; pa.math_mode = s->math_mode;
     Stamp stamp(s, st, K_PREPASS);

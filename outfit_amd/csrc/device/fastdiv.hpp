@@ -73,31 +73,57 @@ __device__ __forceinline__ void div2_shared(double a1, double a2, double b, doub
 // which is built without a guard). Inside the window the fast forms return the bits of `/` (selftest on 2^27 operands,
 // tests/test_gpu_parity.py::test_fast_division_is_exact), so results never depend on which path ran.
 // A null guard = plain divisions: every other caller of the functions that take one.
+// Round 5: the record is ONE 32-bit word. With e the biased exponent of an operand, |x| lies in [2^-300, 2^300) iff
+// 723 <= e <= 1322, i.e. iff (e - 723) as an unsigned number is < 600; zero and denormals (e = 0) wrap to a huge value,
+// Inf / NaN (e = 2047) give 1324. The high word shifted left by one (drops the sign) minus 723 << 21 is that number with
+// mantissa bits below it — one v_lshl_add_u32 — and the running maximum one v_max_u32 (v_max3_u32 for two operands):
+// two 32-bit instructions per operand instead of four fp64-rate ones (|x| added to a sum, and fmin, which the compiler
+// brackets with two canonicalising v_max_f64), one VGPR instead of four.
 struct Guard {
-  double lo, sum;
-  __device__ __forceinline__ void reset() { lo = 1.0; sum = 0.0; }
+  unsigned worst;
+  static constexpr unsigned kBias = 723u << 21, kSpan = 600u << 21;
+  __device__ __forceinline__ void reset() { worst = 0u; }
   __device__ __forceinline__ void see(double a) {
-    const double ax = fabs(a);
-    sum += ax;
-    lo = fmin(lo, ax);
+    unsigned u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (written out: from `(hi << 1) - bias` the compiler builds v_alignbit_b32 + v_and_b32 + v_add_u32)
+    asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(u) : "v"(__double2hiint(a)), "s"(0u - kBias));
+#else
+    u = ((unsigned)__double2hiint(a) << 1) - kBias;
+#endif
+    worst = u > worst ? u : worst;
   }
-  __device__ __forceinline__ bool ok() const { return lo >= 4.909093465297727e-91 && sum <= 2.037035976334486e+90; }
+  __device__ __forceinline__ bool ok() const { return worst < kSpan; }
 };
+
+// A compile-time constant held in a scalar register pair where it is used (device build). `fma(-q0, c, a)` with a
+// constant c whose low word is zero (3.0, the series' integer denominators) otherwise becomes v_fmac_f64 with a
+// 32-bit literal — a VOP2 whose destination is its addend, so the addend (a value that stays live: beta, the
+// numerator) is copied first with a v_mov_b64 on the vector ALU. From a scalar register the same fma is ONE VOP3
+// instruction; the two s_mov_b32 that load the constant issue on the scalar unit beside other waves' vector work.
+__device__ __forceinline__ double scalar_const(double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+s"(c));
+#endif
+  return c;
+}
 // a / c, c a compile-time constant of moderate magnitude, rc == RN(1 / c)
 __device__ __forceinline__ double div_const(double a, double c, double rc, Guard* g) {
   if (!g) return a / c;
   g->see(a);
+  rc = scalar_const(rc);
   const double q0 = a * rc;
-  return fma(fma(-q0, c, a), rc, q0);
+  return fma(fma(-q0, scalar_const(c), a), rc, q0);
 }
 // (a[0] / b, .., a[N-1] / b): velocity.rs:155-157 divides the three components of the corrected velocity by the same g,
 // eccentricity_control 1 and mu by the same |r|
+// Returns the refined reciprocal of b it used (0 without a guard) for callers that divide by the same b again later.
 template <int N>
-__device__ __forceinline__ void divn_shared(const double (&a)[N], double b, double (&q)[N], Guard* g) {
+__device__ __forceinline__ double divn_shared(const double (&a)[N], double b, double (&q)[N], Guard* g) {
   if (!g) {
 #pragma unroll
     for (int k = 0; k < N; ++k) q[k] = a[k] / b;
-    return;
+    return 0.0;
   }
   g->see(b);
   const double y = refined_rcp(b);
@@ -106,6 +132,7 @@ __device__ __forceinline__ void divn_shared(const double (&a)[N], double b, doub
     g->see(a[k]);
     q[k] = div_with_rcp(a[k], b, y);
   }
+  return y;
 }
 
 // Stumpff-series denominators and their correctly-rounded reciprocals, term j = 1..70:

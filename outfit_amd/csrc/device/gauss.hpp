@@ -37,6 +37,21 @@ struct GaussParams {
   unsigned max_tested_solutions;  // saturated to 2^32-1 on the host
   unsigned newton_max_it;         // saturated likewise
   int math_mode;                  // kMathCr / kMathGlibc (kepler.hpp)
+  // Derived by derive() on the host: the outer bounds of the two-sided pre-tests (kepler.hpp `eccentricity_control`,
+  // `correction_iteration` below). NaN switches a pre-test off — every compare is then false and the literal
+  // quotient decides — which is what derive() stores when a parameter is outside the range the error analysis covers.
+  // (NaN until derive() has run: a GaussParams filled in by hand is slower, never wrong)
+  double peri_lo = __builtin_nan(""), peri_hi = __builtin_nan("");   // max_perihelion_au (1 -/+ 2^-49)
+  double eps2_lo = __builtin_nan(""), eps2_hi = __builtin_nan("");   // newton_eps^2 (1 -/+ 2^-45)
+  __host__ __device__ void derive() {
+    const double nan = __builtin_nan("");
+    const bool peri_sane = max_perihelion_au >= 1e-100 && max_perihelion_au <= 1e100 && max_ecc <= 1e100;
+    peri_lo = peri_sane ? max_perihelion_au * (1.0 - 0x1p-49) : nan;
+    peri_hi = peri_sane ? max_perihelion_au * (1.0 + 0x1p-49) : nan;
+    const bool eps_sane = newton_eps >= 1e-30 && newton_eps <= 1.0;
+    eps2_lo = eps_sane ? (newton_eps * newton_eps) * (1.0 - 0x1p-45) : nan;
+    eps2_hi = eps_sane ? (newton_eps * newton_eps) * (1.0 + 0x1p-45) : nan;
+  }
 };
 
 // error codes = OUTFIT_CAUSE_* of include/outfit_hip.h
@@ -389,12 +404,13 @@ __device__ __forceinline__ Vec3 gibbs_correction(const Mat3& pos, double tau1, d
 }
 
 // Matrix3::norm(): sum over columns of (x^2+y^2)+z^2 accumulated from 0, then sqrt
-__device__ __forceinline__ double frob(const Mat3& A) {
+__device__ __forceinline__ double frob_sq(const Mat3& A) {
   double s = 0.0;
 #pragma unroll
   for (int k = 0; k < 3; ++k) s += (A.m[0][k] * A.m[0][k] + A.m[1][k] * A.m[1][k]) + A.m[2][k] * A.m[2][k];
-  return sqrt(s);
+  return s;
 }
+__device__ __forceinline__ double frob(const Mat3& A) { return sqrt(frob_sq(A)); }
 
 // accept_root (gauss.rs:816-870): root -> positions at the three epochs, Gibbs velocity
 __device__ __forceinline__ bool accept_root(const Mat3& obs, const Mat3& S, const Mat3& Sinv, double t_mid,
@@ -405,7 +421,7 @@ __device__ __forceinline__ bool accept_root(const Mat3& obs, const Mat3& S, cons
   if (!position_and_epoch(obs, S, Sinv, t_mid, c, P.min_rho2_au, pos, epoch)) return false;
   vel = gibbs_correction(pos, q.tau1, q.tau3);
   const Vec3 rm = column(pos, 1);
-  const EccControl ec = eccentricity_control(rm, vel, P.max_perihelion_au, P.max_ecc);
+  const EccControl ec = eccentricity_control(rm, vel, P.max_perihelion_au, P.max_ecc, nullptr, P.peri_lo, P.peri_hi);
   vc = velocity_common_from(ec, rm, vel);
   return ec.some && ec.accepted;
 }
@@ -420,6 +436,21 @@ struct CorrectionState {
   unsigned it;           // iterations consumed so far
   VelCommon vc;          // velocity.rs:105-129 evaluated on (pos[:,1], vel): shared by both sides
 };
+
+// |P_new - P|_F / |P_new|_F <= newton_eps (gauss.rs:1393-1411) from the two SQUARED norms; lo / hi = newton_eps^2
+// (1 -/+ 2^-45) from GaussParams::derive(). The literal value is RN(RN(sqrt d) / RN(sqrt n)) = sqrt(d / n)(1 + t) with
+// |t| < 2^-51; d <= RN(n lo) gives sqrt(d / n) <= newton_eps (1 - 2^-47), so the literal compare is true, and
+// d >= RN(n hi) makes it false. In between (or with NaN bounds / operands) the literal expression decides. The caller
+// has already excluded n <= kFrobSqMax and a non-finite n.
+__device__ __forceinline__ bool rel_converged(double diff_sq, double denom_sq, double newton_eps, double lo, double hi) {
+  if (diff_sq <= denom_sq * lo) return true;
+  if (diff_sq >= denom_sq * hi) return false;
+  return sqrt(diff_sq) / sqrt(denom_sq) <= newton_eps;
+}
+
+// Before the FIRST guarded iteration of a root (correction_iteration<kFast = true>, throughput form): accept_root
+// evaluates eccentricity_control without a guard, so the carried reciprocal of r2 is not there yet.
+__device__ __forceinline__ void prepare_guarded(CorrectionState& st) { st.vc.inv_r2 = fdiv::refined_rcp(st.vc.r2); }
 
 // kCorrRedo (fast kernel only): an operand of one of the iteration's guarded divisions (fastdiv.hpp Guard) was zero,
 // outside the window or not finite — nothing of this iteration is used, the general kernel (plain divisions) replays the
@@ -456,6 +487,14 @@ __device__ __forceinline__ double pair_swap(double x) {  // the partner lane's x
   const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), 0xB1, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
 }
+// The parameters the TAIL of an iteration reads (everything behind the two Kepler solves). For GaussParams that is the
+// object itself; a kernel may pass a type whose tail() fetches them at that point instead (kernels.hip SplitParams: one
+// block load from the kernarg segment per iteration, so that ~20 scalar registers are not held — or spilled into
+// VGPR lanes and read back with v_readlane — across the solves' loops).
+__device__ __forceinline__ const GaussParams& tail_params(const GaussParams& P) { return P; }
+template <class Params>
+__device__ __forceinline__ auto tail_params(const Params& P) -> decltype(P.tail()) { return P.tail(); }
+
 template <bool kFast, bool kWarmOnly = kFast, class Params = GaussParams, bool kPair = false>
 __device__ __forceinline__ CorrStep correction_iteration_impl(const Mat3& obs, const Mat3& S, const Mat3& Sinv,
                                                               double t_mid, double dt01, double dt21,
@@ -471,6 +510,7 @@ __device__ __forceinline__ CorrStep correction_iteration_impl(const Mat3& obs, c
   const CorrStep rare = kCorrSome;
   const Vec3 r1 = column(st.pos, 0), r2 = column(st.pos, 1), r3 = column(st.pos, 2);
   if (!st.vc.ok) return rare;
+  if (G) G->see(st.vc.r2);  // divided by through its carried reciprocal (velocity_finish)
   const bool had_both = st.has01 && st.has21;
   const long long chi01_old = __double_as_longlong(st.chi01), chi21_old = __double_as_longlong(st.chi21);
   // the two Lagrange corrections (t1<-t2 and t3<-t2) are independent; a rolled loop keeps ONE
@@ -501,12 +541,13 @@ __device__ __forceinline__ CorrStep correction_iteration_impl(const Mat3& obs, c
 #ifdef OUTFIT_K2B_STATS  // histogram of Newton rounds per solve: first iteration of a candidate (cold start) / later ones
     atomicAdd(&g_kstat[(st.it == 1 ? 24 : 16) + (sol.rounds < 7 ? sol.rounds : 7)], 1ull);
 #endif
-    const VelCorr vc = velocity_finish(sol, side ? r3 : r1, r2, st.vc.r2, dt, G);
+    const VelCorr vc = velocity_finish(sol, side ? r3 : r1, r2, st.vc.r2, dt, G, st.vc.inv_r2);
     if (side) b = vc; else a = vc;
   }
   }
   KSTAT(4);
   if (!(a.ok && b.ok)) return rare;
+  const auto& T = tail_params(P);
   st.has01 = true; st.chi01 = a.chi;
   st.has21 = true; st.chi21 = b.chi;
   const bool fixed_point = had_both && __double_as_longlong(a.chi) == chi01_old &&
@@ -521,24 +562,26 @@ __device__ __forceinline__ CorrStep correction_iteration_impl(const Mat3& obs, c
   Mat3 np;
   double ne;
   KSTAT(5);
-  if (!position_and_epoch(obs, S, Sinv, t_mid, c, P.min_rho2_au, np, ne, G)) return skip;  // common
+  if (!position_and_epoch(obs, S, Sinv, t_mid, c, T.min_rho2_au, np, ne, G)) return skip;  // common
   KSTAT(6);
   const Vec3 nr2 = column(np, 1);
-  const EccControl ec = eccentricity_control(nr2, nv, P.max_perihelion_au, P.max_ecc, G);
+  const EccControl ec = eccentricity_control(nr2, nv, T.max_perihelion_au, T.max_ecc, G, T.peri_lo, T.peri_hi);
   if (!ec.some || !ec.accepted) return kFast ? kCorrSlow : kCorrNone;
-  const double denom = frob(np);
-  if (!isfinite(denom) || denom <= kEps) return skip;
+  // denom = |P_new|_F: `!isfinite(denom) || denom <= eps` decided on its square (kepler.hpp kFrobSqMax)
+  const double denom_sq = frob_sq(np);
+  if (!isfinite(denom_sq) || denom_sq <= kFrobSqMax) return skip;
   Mat3 d;
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
     for (int k = 0; k < 3; ++k) d.m[r][k] = np.m[r][k] - st.pos.m[r][k];
-  const double rel = frob(d) / denom;
+  // rel = |P_new - P|_F / |P_new|_F is only compared with newton_eps
+  const bool converged = rel_converged(frob_sq(d), denom_sq, T.newton_eps, T.eps2_lo, T.eps2_hi);
   st.pos = np;
   st.vel = nv;
   st.epoch = ne;
   st.vc = velocity_common_from(ec, nr2, nv, G);
-  if (rel <= P.newton_eps) return kCorrSome;
+  if (converged) return kCorrSome;
   return last ? kCorrSome : kCorrContinue;
 }
 // The throughput form of the fast kernel runs the iteration's divisions by constants and by shared denominators in their

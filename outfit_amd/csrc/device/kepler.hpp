@@ -84,6 +84,12 @@ __device__ __forceinline__ double clampd(double x, double lo, double hi) {
   return x < lo ? lo : (x > hi ? hi : x);  // f64::clamp (NaN passes through)
 }
 
+// f64::clamp(x, -m, m) for m > 0: one compare on the magnitude and a sign transfer instead of two compares and two
+// selects per word — x < -m gives -m, x > m gives m, anything else (NaN included: the compare is false) passes through
+__device__ __forceinline__ double clamp_symmetric(double x, double m) {
+  return fabs(x) > m ? copysign(m, x) : x;
+}
+
 // f64::rem_euclid(2*pi)   (kepler/angles.rs:10-12)
 __device__ __forceinline__ double principal_angle(double a) {
   double r = fmod(a, kTwoPi);
@@ -112,10 +118,12 @@ __device__ __forceinline__ Stumpff s_funct(double psi, double alpha, fdiv::Guard
       const double d2 = fdiv::kSeries.d2[j], d3 = fdiv::kSeries.d3[j];
       double x2, x3;
       if (decltype(fast_tag)::value) {
-        const double rc2 = fdiv::kSeries.r2[j], rc3 = fdiv::kSeries.r3[j];
+        // (every constant loaded into its scalar pair where it is used, see fdiv::scalar_const: held across the loop the 32
+        //  words of the eight unrolled terms' reciprocals overflow the scalar file and come back through v_readlane)
+        const double rc2 = fdiv::scalar_const(fdiv::kSeries.r2[j]), rc3 = fdiv::scalar_const(fdiv::kSeries.r3[j]);
         const double q2 = beta * rc2, q3 = beta * rc3;
-        x2 = fma(fma(-q2, d2, beta), rc2, q2);
-        x3 = fma(fma(-q3, d3, beta), rc3, q3);
+        x2 = fma(fma(-q2, fdiv::scalar_const(d2), beta), rc2, q2);
+        x3 = fma(fma(-q3, fdiv::scalar_const(d3), beta), rc3, q3);
       } else {
         x2 = beta / d2;
         x3 = beta / d3;
@@ -125,6 +133,14 @@ __device__ __forceinline__ Stumpff s_funct(double psi, double alpha, fdiv::Guard
       t3 *= x3;
       s3 += t3;
       const double a2 = fabs(t2), a3 = fabs(t3);
+      if (decltype(fast_tag)::value) {
+        // Inside the window neither term can be NaN: beta is finite, non-zero and normal, so psi is finite and non-zero,
+        // t2 starts finite, t3 starts finite or +-Inf, and every factor x is finite and non-zero (Inf * x stays Inf,
+        // 0 * x stays 0). Without NaNs (a2 < tol && a3 < tol) is max(a2, a3) < tol and (a2 > ovf || a3 > ovf) is
+        // max(a2, a3) > ovf: one v_max_f64 and two compares instead of four compares, the same decisions.
+        const double m = fmax(a2, a3);
+        return m < tol || m > ovf;
+      }
       return (a2 < tol && a3 < tol) || a2 > ovf || a3 > ovf;
     };
     using yes = std::true_type;
@@ -480,7 +496,7 @@ __device__ __forceinline__ KeplerSolution run_newton(const KeplerProblem& p, dou
     if (fabs(residual) <= res_tol) { out.psi = psi; out.s = s; out.ok = true; break; }
     if (!isfinite(derivative) || fabs(derivative) < 10.0 * kEps) { psi *= 0.5; continue; }
     const double mx = 2.0 * (1.0 + fabs(psi));
-    const double step = clampd(-residual / derivative, -mx, mx);
+    const double step = clamp_symmetric(-residual / derivative, mx);
     const double cand = psi + step;
     psi = (cand * psi < 0.0) ? 0.5 * psi : cand;
     const double sa = fabs(step);
@@ -575,34 +591,63 @@ __device__ __forceinline__ KeplerSolution solve_kepuni_kind(const KeplerProblem&
 struct EccControl {
   bool some;      // false = None (zero angular momentum)
   bool accepted;
-  double ecc, peri, energy;
-  double dist, h_norm;  // |r| and |r x v| as computed on the way (reused by velocity_common_from)
+  double ecc, energy;
+  double dist, h2;  // |r| and |r x v|^2 as computed on the way (reused by velocity_common_from)
+  double inv_dist;  // with a guard: the refined reciprocal of |r| (fastdiv.hpp), reused for s2 / r2 in the next iteration
 };
 
-// orb_elem.rs:257-301
+// Decisions that the reference takes on a SQUARE ROOT or on a QUOTIENT, taken here on the operands — same outcome for
+// every input, without the 20-instruction sqrt or the division (round 5):
+//  * sqrt is correctly rounded and monotone, so RN(sqrt(x)) <= c  <=>  x <= T(c), T(c) the largest double whose rounded
+//    root is <= c (no ties: the midpoint above c squared is not a double). tools/sqrt_thresholds.py derives the two
+//    constants with exact rational arithmetic and tests/test_device_math_host.py checks them against sqrt around T.
+//      |r x v| <= 1e6 eps   <=>  |r x v|^2 <= kHnormSqMax      (velocity.rs:167-178, the angular-momentum guard)
+//      |P|_F <= eps         <=>  |P|_F^2 <= kFrobSqMax         (gauss.rs:1392, the denominator guard)
+//    and RN(sqrt(x)) == 0 <=> x == 0, isfinite(RN(sqrt(x))) <=> isfinite(x) for x >= 0 or NaN.
+//  * a quotient against a threshold, RN(a / b) < t: decided by two products when a lies clearly on one side of b t
+//    (margins of 2^-49, far above the rounding errors of the products and of the quotient), by the division itself in
+//    the sliver between — `two_sided` below.
+constexpr double kHnormSqMax = 0x1.d1a94a2p-65;          // T(1e6 * 2^-52) = (1e6 * 2^-52)^2 exactly
+constexpr double kFrobSqMax = 0x1.0000000000001p-104;    // T(2^-52)
+
+// RN(h2 / den) < peri_max (orb_elem.rs:296-299: the perihelion distance is only ever compared), for den = mu (1 + e) of
+// a finite e. lo / hi = peri_max (1 -/+ 2^-49): with q = RN(h2 / den) = (h2 / den)(1 + t), |t| <= 2^-53, and the
+// products below carrying 2^-53 each, h2 <= RN(den lo) puts h2 / den below peri_max (1 - 2^-50), hence q < peri_max by
+// monotonicity of the rounding; h2 >= RN(den hi) likewise puts q above. NaN bounds (pre-test off) or a NaN operand
+// fail both compares and the quotient decides.
+__device__ __forceinline__ bool peri_below(double h2, double den, double peri_max, double lo, double hi) {
+  if (h2 <= den * lo) return true;
+  if (h2 >= den * hi) return false;
+  return (h2 / den) < peri_max;
+}
+
+// orb_elem.rs:257-301. peri_lo / peri_hi: peri_max (1 -/+ 2^-49) from GaussParams::derive(), or NaN (the default: every
+// compare with them is false and the division decides).
 __device__ __forceinline__ EccControl eccentricity_control(const Vec3& r, const Vec3& v, double peri_max,
-                                                  double ecc_max, fdiv::Guard* guard = nullptr) {
+                                                  double ecc_max, fdiv::Guard* guard = nullptr,
+                                                  double peri_lo = __builtin_nan(""), double peri_hi = __builtin_nan("")) {
   EccControl o;
   const double v2 = dot(v, v);
   const double dist = norm(r);
   const Vec3 h = cross(r, v);
   const double h2 = dot(h, h);
   o.dist = dist;
-  o.h_norm = sqrt(h2);
-  o.some = !(o.h_norm == 0.0);
+  o.h2 = h2;
+  o.some = !(h2 == 0.0);   // h_norm == 0.0 with h_norm = sqrt(h2)
   const Vec3 vxh = cross(v, h);
   // 1 / |r| and mu / |r| (the energy, below) share their denominator
   const double inv_mu = 1.0 / kMu;
   const double one_mu[2] = {1.0, kMu};
   double over_d[2];
-  fdiv::divn_shared<2>(one_mu, dist, over_d, guard);
+  o.inv_dist = fdiv::divn_shared<2>(one_mu, dist, over_d, guard);
   const double inv_d = over_d[0];
   const Vec3 lenz = {vxh.x * inv_mu - r.x * inv_d, vxh.y * inv_mu - r.y * inv_d,
                      vxh.z * inv_mu - r.z * inv_d};
   o.ecc = norm(lenz);
-  o.peri = h2 / (kMu * (1.0 + o.ecc));
+  // peri = h2 / (mu (1 + e)) is only ever compared with peri_max
+  const bool peri_ok = peri_below(h2, kMu * (1.0 + o.ecc), peri_max, peri_lo, peri_hi);
   o.energy = v2 / 2.0 - over_d[1];
-  o.accepted = (o.ecc < ecc_max) && (o.peri < peri_max);
+  o.accepted = (o.ecc < ecc_max) && peri_ok;
   return o;
 }
 
@@ -619,12 +664,14 @@ struct VelCorr {
 struct VelCommon {
   bool ok;
   double r2, sig0, alpha, e0;
+  double inv_r2;  // guarded path only: refined reciprocal of r2 (fastdiv.hpp refined_rcp), else unused
 };
 __device__ __forceinline__ VelCommon velocity_common(const Vec3& x2, const Vec3& v2, double peri_max,
                                                      double ecc_max) {
   VelCommon c;
   c.ok = false;
   c.r2 = norm(x2);
+  c.inv_r2 = 0.0;
   c.sig0 = dot(x2, v2) / sqrt(kMu);
   c.alpha = 0.0; c.e0 = 0.0;
   const double hn = norm(cross(x2, v2));
@@ -642,10 +689,12 @@ __device__ __forceinline__ VelCommon velocity_common_from(const EccControl& ec, 
                                                           fdiv::Guard* guard = nullptr) {
   VelCommon c;
   c.r2 = ec.dist;
+  c.inv_r2 = ec.inv_dist;
   c.sig0 = div_by_sqrt_mu(dot(x2, v2), guard);
   c.alpha = div_by_mu(2.0 * ec.energy, guard);
   c.e0 = ec.ecc;
-  c.ok = isfinite(ec.h_norm) && !(ec.h_norm <= 1e6 * kEps) && ec.some;
+  // isfinite(h_norm) && !(h_norm <= 1e6 eps) with h_norm = sqrt(h2): decided on h2 (see kHnormSqMax)
+  c.ok = isfinite(ec.h2) && !(ec.h2 <= kHnormSqMax) && ec.some;
   return c;
 }
 __device__ __forceinline__ KeplerProblem velocity_problem(const VelCommon& c, double dt, double eps, int math_mode) {
@@ -655,12 +704,17 @@ __device__ __forceinline__ KeplerProblem velocity_problem(const VelCommon& c, do
   return p;
 }
 // Lagrange f, g and the corrected velocity from a Kepler solution (velocity.rs:144-161)
+// With a guard, `inv_r2` is the refined reciprocal of r2 (r2 itself recorded by the caller): the quotient's last three
+// operations only, the same bits as `/` inside the guard's window.
 __device__ __forceinline__ VelCorr velocity_finish(const KeplerSolution& sol, const Vec3& x1, const Vec3& x2,
-                                                   double r2, double dt, fdiv::Guard* guard = nullptr) {
+                                                   double r2, double dt, fdiv::Guard* guard = nullptr, double inv_r2 = 0.0) {
   VelCorr o;
   o.ok = false;
   if (!sol.ok) return o;
-  const double f = 1.0 - sol.s.s2 / r2;
+  double s2_over_r2;
+  if (guard) { guard->see(sol.s.s2); s2_over_r2 = fdiv::div_with_rcp(sol.s.s2, r2, inv_r2); }
+  else s2_over_r2 = sol.s.s2 / r2;
+  const double f = 1.0 - s2_over_r2;
   const double g = dt - div_by_sqrt_mu(sol.s.s3, guard);
   const double ga = fabs(g);
   if (!isfinite(ga) || ga < 100.0 * kEps * (1.0 + fabs(dt))) return o;

@@ -116,10 +116,11 @@ __device__ __forceinline__ ScreenFrame screen_frame(const Equinoctial& q, const 
 
 // The squared normalised residual of one observation from (sin F, cos F): equinoctial_element.rs:850-867,
 // observation_ephemeris.rs:222-275,388-416 (incl. the sign-keeping `%` of quirk Q6), in the screen's arithmetic.
+// w_ra = cos(dec_obs) / sigma_ra and w_dec = 1 / sigma_dec depend on the observation only: K1 evaluates them once per
+// observation (kernels.h kObsRecDoubles) instead of the loop once per (candidate, observation).
 __device__ __forceinline__ double screen_term(const Equinoctial& q, const TwoBodyFrame& F, const ScreenFrame& G,
-                                              double sx, double cx, double ra, double dec, double cos_dec, double sra,
-                                              double sdec, const Vec3& obs_pos_equ, const ScreenConsts& C,
-                                              double& inv_rho_max) {
+                                              double sx, double cx, double ra, double dec, double w_ra, double w_dec,
+                                              const Vec3& obs_pos_equ, const ScreenConsts& C, double& inv_rho_max) {
   const double xe = q.a * fma(F.one_bh2, cx, fma(F.bet, sx, -q.k));
   const double ye = q.a * fma(F.one_bk2, sx, fma(F.bet, cx, -q.h));
   double r, inv_r;
@@ -143,8 +144,8 @@ __device__ __forceinline__ double screen_term(const Equinoctial& q, const TwoBod
   double da = ra - alpha;
   if (!(fabs(da) < C.two_pi)) da = fmod_2pi(da);
   if (da > C.pi) da -= C.two_pi;
-  const double t1 = cos_dec * (da * rcp_nr2(sra));
-  const double t2 = (dec - delta) * rcp_nr2(sdec);
+  const double t1 = da * w_ra;
+  const double t2 = (dec - delta) * w_dec;
   return fma(t1, t1, t2 * t2);
 }
 

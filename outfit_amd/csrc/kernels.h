@@ -75,6 +75,12 @@ struct PrepassArgs {
   double* obs_pos;
   double* cos_dec;
   double* unit;    // [3][n_obs] direction cosines of the (noise-free) observations
+  // the screening loop's per-observation record (kObsRecDoubles doubles per observation, see RmsArgs::obs_rec): written
+  // with the observer half; `helio` = the observer positions when there is no table (the residuals use obs_helio_equ)
+  double* obs_rec;
+  const double* sra;
+  const double* sdec;
+  const double* helio;
   bool has_table;  // false: only cos(dec) is produced, the residuals use obs_helio_equ
   int math_mode;   // kMathCr / kMathGlibc for the direction cosines
   EphemTable T;
@@ -136,11 +142,18 @@ struct CorrectArgs {
                               // saw an operand outside its window" — for every (candidate + iteration) divisible by m
 };
 
+// What the screening loop of K2c reads per (candidate, observation), packed by K1 into ONE 64-byte record per
+// observation: (mjd_tt, ra, dec, cos(dec) / sigma_ra, 1 / sigma_dec, observer x, y, z). Nine separate arrays cost nine
+// 64-bit address computations and nine loads per pass and two reciprocals of values that depend on the observation only;
+// the record is one address, four 16-byte loads and no reciprocal. The exact loops keep the reference's operands.
+constexpr unsigned kObsRecDoubles = 8;
+
 struct RmsArgs {
   CandidateIndex I;
   CandidateScratch W;
   const double* obs_pos;
   const double* cos_dec;
+  const double* obs_rec;
   double extf, dtmax;
   SinCosConsts sc;  // polynomial constants as kernel arguments = scalar registers (device/orbit.hpp)
   int rms_mode;     // 0 exact with the platform functions (correctly-rounded mode) | 1 every candidate with the

@@ -118,7 +118,16 @@ k_observer_prepass(PrepassArgs a) {
   if (!(a.parts & kPrepassObserver)) return;
   // cos(dec_obs) of ephemeris_error (observation_ephemeris.rs:412) depends on the observation only. It is an ISOLATED
   // cosine in the reference: the standalone libm entry point (glm::cos1 in the glibc-faithful mode; glibcmath.hpp)
-  if (live) a.cos_dec[o] = a.math_mode == kMathGlibc ? glm::cos1(a.dec[o]) : cos(a.dec[o]);
+  double cd = 0.0;
+  if (live) {
+    cd = a.math_mode == kMathGlibc ? glm::cos1(a.dec[o]) : cos(a.dec[o]);
+    a.cos_dec[o] = cd;
+    // the screen's record (a zero uncertainty gives Inf / NaN weights: a non-finite sum, i.e. the exact loop)
+    double* rec = a.obs_rec + (size_t)kObsRecDoubles * o;
+    rec[0] = a.mjd[o]; rec[1] = a.ra[o]; rec[2] = a.dec[o];
+    rec[3] = cd / a.sra[o]; rec[4] = 1.0 / a.sdec[o];
+    if (!a.has_table) { rec[5] = a.helio[3 * o]; rec[6] = a.helio[3 * o + 1]; rec[7] = a.helio[3 * o + 2]; }
+  }
   if (!a.has_table) return;
   if (threadIdx.x == 0) { s_min = ~0ull; s_max = 0ull; s_bad = 0; }
   __syncthreads();
@@ -151,6 +160,8 @@ k_observer_prepass(PrepassArgs a) {
   a.obs_pos[3 * o] = out.x;
   a.obs_pos[3 * o + 1] = out.y;
   a.obs_pos[3 * o + 2] = out.z;
+  double* rec = a.obs_rec + (size_t)kObsRecDoubles * o;
+  rec[5] = out.x; rec[6] = out.y; rec[7] = out.z;
 }
 
 // ------------------------------------------------------------------------------
@@ -519,9 +530,24 @@ struct KernargGaussParams {
   OUTFIT_LAZY(double, max_ecc); OUTFIT_LAZY(double, max_perihelion_au); OUTFIT_LAZY(double, min_rho2_au);
   OUTFIT_LAZY(double, aberth_eps); OUTFIT_LAZY(double, kepler_eps); OUTFIT_LAZY(double, r2_min_au);
   OUTFIT_LAZY(double, r2_max_au); OUTFIT_LAZY(double, newton_eps); OUTFIT_LAZY(double, root_imag_eps);
+  OUTFIT_LAZY(double, peri_lo); OUTFIT_LAZY(double, peri_hi); OUTFIT_LAZY(double, eps2_lo); OUTFIT_LAZY(double, eps2_hi);
   OUTFIT_LAZY(unsigned, aberth_max_iter); OUTFIT_LAZY(unsigned, max_tested_solutions);
   OUTFIT_LAZY(unsigned, newton_max_it); OUTFIT_LAZY(int, math_mode);
 #undef OUTFIT_LAZY
+};
+
+// The fast kernel's parameters, split by where an iteration reads them (gauss.hpp tail_params): what the two Kepler
+// solves need stays in scalar registers; what the tail needs (thresholds of position_and_epoch, eccentricity_control and
+// the convergence test: 16 doubles with the derived bounds) is fetched from the kernarg segment behind the solves.
+#ifndef OUTFIT_K2B_SPLIT_PARAMS
+#define OUTFIT_K2B_SPLIT_PARAMS 1
+#endif
+template <unsigned kOff>
+struct SplitParams {
+  double kepler_eps;
+  unsigned newton_max_it;
+  int math_mode;
+  __device__ __forceinline__ GaussParams tail() const { return kernarg_field<GaussParams>(kOff); }
 };
 
 // wave-wide grab of the next queue entries for the lanes in need_mask
@@ -604,6 +630,7 @@ k_gauss_correct_fast(CorrectArgs a) {
             // same inputs as in K2a' -> same (pos, vel, vc); accepted there, so accepted here
             (void)accept_root(g.obs, g.S, g.Sinv, g.t[1], g.q, a.P, W.roots[(unsigned long long)slot * n + my],
                               st.pos, st.vel, e_pre, st.vc);
+            if constexpr (!kPair) prepare_guarded(st);
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -643,6 +670,8 @@ k_gauss_correct_fast(CorrectArgs a) {
       }
 #if OUTFIT_KERNARG_LAZY_PARAMS
     const KernargGaussParams<(unsigned)offsetof(CorrectArgs, P)> P;
+#elif OUTFIT_K2B_SPLIT_PARAMS
+    const SplitParams<(unsigned)offsetof(CorrectArgs, P)> P{a.P.kepler_eps, a.P.newton_max_it, a.P.math_mode};
 #else
     const GaussParams& P = a.P;
 #endif
@@ -920,13 +949,15 @@ __device__ __forceinline__ void rms_candidate(const RmsArgs& a, unsigned long lo
       S.dmin = 1.0;
       S.inv_rho_max = 0.0;
       for (unsigned long long i = i_start; i <= i_end; ++i) {
-        const unsigned long long o = c.base + i;
-        if (!screen_kepler(eq, F, a.I.mjd[o] - eq.epoch, S, a.sc, SCR)) {
+        // one 64-byte record per observation (kernels.h kObsRecDoubles): four 16-byte loads from one address
+        const double2* rec = reinterpret_cast<const double2*>(a.obs_rec + (size_t)kObsRecDoubles * (c.base + i));
+        const double2 r01 = rec[0], r23 = rec[1], r45 = rec[2], r67 = rec[3];
+        if (!screen_kepler(eq, F, r01.x - eq.epoch, S, a.sc, SCR)) {
           err = true;
           break;
         }
-        const Vec3 op = {a.obs_pos[3 * o], a.obs_pos[3 * o + 1], a.obs_pos[3 * o + 2]};
-        acc += screen_term(eq, F, G, S.sx, S.cx, a.I.ra[o], a.I.dec[o], a.cos_dec[o], a.I.sra[o], a.I.sdec[o], op, SCR, S.inv_rho_max);
+        const Vec3 op = {r45.y, r67.x, r67.y};
+        acc += screen_term(eq, F, G, S.sx, S.cx, r01.y, r23.x, r23.y, r45.x, op, SCR, S.inv_rho_max);
       }
       // anything the screen's shortcuts were not made for (non-finite or absurd inputs: overflow, 0 / 0, a zero
       // uncertainty) shows up as a non-finite sum: such a candidate takes the reference's expressions instead — here

@@ -47,6 +47,48 @@ void crm_eval(int fn, unsigned long long n, const double* a, const double* b, do
     }
   }
 }
+// Round 5: decisions taken on operands instead of on a square root / a quotient (kepler.hpp peri_below, kHnormSqMax,
+// kFrobSqMax; gauss.hpp rel_converged, GaussParams::derive), the symmetric clamp of the Newton step, and the one-word
+// operand record of the guarded divisions.
+void decision_constants(double* out /* 2 */) { out[0] = kHnormSqMax; out[1] = kFrobSqMax; }
+void derive_params(double max_peri, double max_ecc, double newton_eps, double* out /* 4 */) {
+  GaussParams P{};
+  P.max_perihelion_au = max_peri; P.max_ecc = max_ecc; P.newton_eps = newton_eps;
+  P.derive();
+  out[0] = P.peri_lo; out[1] = P.peri_hi; out[2] = P.eps2_lo; out[3] = P.eps2_hi;
+}
+// in: (h2, den, peri_max, lo, hi) x n; out: decision with the bounds, decision with NaN bounds (the quotient alone)
+void peri_below_array(unsigned long long n, const double* in, int* with_bounds, int* literal) {
+  const double nan = __builtin_nan("");
+  for (unsigned long long i = 0; i < n; ++i) {
+    const double* q = in + 5 * i;
+    with_bounds[i] = peri_below(q[0], q[1], q[2], q[3], q[4]);
+    literal[i] = peri_below(q[0], q[1], q[2], nan, nan);
+  }
+}
+// in: (diff_sq, denom_sq, newton_eps, lo, hi) x n
+void rel_converged_array(unsigned long long n, const double* in, int* with_bounds, int* literal) {
+  const double nan = __builtin_nan("");
+  for (unsigned long long i = 0; i < n; ++i) {
+    const double* q = in + 5 * i;
+    with_bounds[i] = rel_converged(q[0], q[1], q[2], q[3], q[4]);
+    literal[i] = rel_converged(q[0], q[1], q[2], nan, nan);
+  }
+}
+void clamp_symmetric_array(unsigned long long n, const double* x, const double* m, double* out) {
+  for (unsigned long long i = 0; i < n; ++i) out[i] = clamp_symmetric(x[i], m[i]);
+}
+// per operand: does a guard that has seen only this operand pass, and is the operand inside fdiv::in_window?
+void guard_array(unsigned long long n, const double* x, int* passes, int* in_window) {
+  for (unsigned long long i = 0; i < n; ++i) {
+    fdiv::Guard g;
+    g.reset();
+    g.see(1.0);
+    g.see(x[i]);
+    passes[i] = g.ok();
+    in_window[i] = fdiv::in_window(x[i]);
+  }
+}
 void s_funct_array(unsigned long long n, const double* psi, const double* alpha, double* out /* 4 n */) {
   for (unsigned long long i = 0; i < n; ++i) {
     const Stumpff s = s_funct(psi[i], alpha[i]);
@@ -189,6 +231,7 @@ void correction_loop_array(unsigned long long n, const double* in, double max_ec
   GaussParams P{};
   P.max_ecc = max_ecc; P.max_perihelion_au = max_peri; P.min_rho2_au = min_rho2; P.kepler_eps = kepler_eps;
   P.newton_eps = newton_eps; P.newton_max_it = newton_max_it; P.math_mode = math_mode;
+  P.derive();
   for (unsigned long long i = 0; i < n; ++i) {
     const double* q = in + 22 * i;
     double* o = out + 10 * i;
@@ -206,6 +249,7 @@ void correction_loop_array(unsigned long long n, const double* in, double max_ec
     const double dt01 = t[0] - t[1], dt21 = t[2] - t[1];
     if (fabs(dt01) <= kEps || fabs(dt21) <= kEps) continue;  // gauss.rs:1311-1313: None
     st.epoch = 0.0; st.has01 = false; st.has21 = false; st.chi01 = st.chi21 = 0.0; st.it = 0;
+    if (guarded) prepare_guarded(st);
     CorrStep step = kCorrContinue;
     while (step == kCorrContinue)
       step = guarded ? correction_iteration<true, false>(obs, S, Sinv, t[1], dt01, dt21, P, st)

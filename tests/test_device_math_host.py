@@ -435,3 +435,108 @@ def test_guarded_divisions_equal_plain_divisions_inside_the_guard(D):
     assert (~passed[n:]).sum() > 1000 and passed[n:].sum() > 1000
     fast, plain = np.ascontiguousarray(out[passed, 1:10]), np.ascontiguousarray(out[passed, 10:19])
     assert same_bits(fast, plain).all()
+
+
+def test_decisions_on_operands_equal_the_literal_expressions(D):
+    """Round 5 takes four decisions of the correction loop on the operands of a square root or of a quotient instead of on
+    its value (kepler.hpp kHnormSqMax / kFrobSqMax / peri_below, gauss.hpp rel_converged). They must be the literal
+    decisions for EVERY input: checked here at and around the switching points, where a sloppy bound would show, on
+    random operands far from them, and with the pre-tests switched off (NaN bounds)."""
+    import math
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import sqrt_thresholds
+    c = (C.c_double * 2)()
+    D.decision_constants(c)
+    assert c[0] == sqrt_thresholds.CONSTANTS["kHnormSqMax"] and c[1] == sqrt_thresholds.CONSTANTS["kFrobSqMax"]
+    for t, lim in ((c[0], 1e6 * EPS), (c[1], EPS)):
+        x = t
+        for _ in range(64):                                   # 64 doubles on either side of T
+            assert math.sqrt(x) <= lim
+            x = math.nextafter(x, 0.0)
+        x = math.nextafter(t, math.inf)
+        for _ in range(64):
+            assert math.sqrt(x) > lim
+            x = math.nextafter(x, math.inf)
+    rng = np.random.default_rng(5)
+
+    def ulps(x, k):
+        return (x.view(np.int64) + k).view(np.float64)
+
+    # ---- perihelion test: RN(h2 / den) < peri_max
+    out = (C.c_double * 4)()
+    cases = []
+    for pm, emax in ((1e3, 5.0), (0.7, 5.0), (3.3e-7, 2.0), (9.1e40, 1e100)):
+        D.derive_params(C.c_double(pm), C.c_double(emax), C.c_double(1e-10), out)
+        lo, hi = out[0], out[1]
+        assert lo < pm < hi and abs(lo / pm - 1) < 1e-14 and abs(hi / pm - 1) < 1e-14
+        den = 2.959122082855911e-4 * (1.0 + rng.uniform(0, emax if emax < 10 else 5, 40000))
+        # h2 so that the quotient lands within a few ulps of peri_max (the sliver), at the bounds, and anywhere
+        near = ulps(den * pm, rng.integers(-40, 41, den.size))
+        at_lo = ulps(den * lo, rng.integers(-3, 4, den.size))
+        at_hi = ulps(den * hi, rng.integers(-3, 4, den.size))
+        far = den * pm * 10.0 ** rng.uniform(-8, 8, den.size)
+        for h2 in (near, at_lo, at_hi, far):
+            cases.append(np.stack([h2, den, np.full_like(den, pm), np.full_like(den, lo), np.full_like(den, hi)], axis=1))
+    # degenerate operands: zero, denormal, huge, infinite, NaN angular momentum; the denominator mu (1 + e) of any
+    # FINITE e (an infinite or NaN eccentricity fails `e < max_ecc` before the perihelion test counts: max_ecc <= 1e100
+    # whenever the bounds are not NaN) and a NaN one
+    D.derive_params(C.c_double(1e3), C.c_double(5.0), C.c_double(1e-10), out)
+    odd = [(h2, den, 1e3, out[0], out[1]) for h2 in (0.0, 5e-324, 1e-310, 1e300, math.inf, math.nan)
+           for den in (2.96e-4, 1e-3, 2.96e96, math.nan)]
+    cases.append(np.array(odd))
+    allc = np.ascontiguousarray(np.concatenate(cases))
+    a, b = np.zeros(len(allc), np.int32), np.zeros(len(allc), np.int32)
+    D.peri_below_array(C.c_ulonglong(len(allc)), _p(allc), a.ctypes.data_as(C.POINTER(C.c_int)), b.ctypes.data_as(C.POINTER(C.c_int)))
+    assert np.array_equal(a, b)
+    lit = (allc[:, 0] / allc[:, 1]) < allc[:, 2]
+    assert np.array_equal(b.astype(bool), lit) and 0.2 < lit.mean() < 0.8
+    # pre-test off outside the analysed parameter range
+    for pm, emax in ((1e-200, 5.0), (1e200, 5.0), (1e3, math.inf), (1e3, 1e200)):
+        D.derive_params(C.c_double(pm), C.c_double(emax), C.c_double(1e-10), out)
+        assert math.isnan(out[0]) and math.isnan(out[1])
+
+    # ---- convergence test: sqrt(d) / sqrt(n) <= newton_eps
+    cases = []
+    for eps in (1e-10, 1e-3, 1.0, 7.3e-17, 1e-30):
+        D.derive_params(C.c_double(1e3), C.c_double(5.0), C.c_double(eps), out)
+        lo, hi = out[2], out[3]
+        assert lo < eps * eps < hi
+        n = 10.0 ** rng.uniform(-28, 12, 40000)               # above kFrobSqMax (the caller's guard), incl. huge
+        near = ulps(n * (eps * eps), rng.integers(-60, 61, n.size))
+        at_lo = ulps(n * lo, rng.integers(-3, 4, n.size))
+        at_hi = ulps(n * hi, rng.integers(-3, 4, n.size))
+        far = n * eps * eps * 10.0 ** rng.uniform(-6, 6, n.size)
+        for d in (near, at_lo, at_hi, far, np.zeros_like(n), np.full_like(n, math.nan), np.full_like(n, math.inf)):
+            cases.append(np.stack([d, n, np.full_like(n, eps), np.full_like(n, lo), np.full_like(n, hi)], axis=1))
+    allc = np.ascontiguousarray(np.concatenate(cases))
+    a, b = np.zeros(len(allc), np.int32), np.zeros(len(allc), np.int32)
+    D.rel_converged_array(C.c_ulonglong(len(allc)), _p(allc), a.ctypes.data_as(C.POINTER(C.c_int)), b.ctypes.data_as(C.POINTER(C.c_int)))
+    assert np.array_equal(a, b)
+    with np.errstate(invalid="ignore"):
+        lit = np.sqrt(allc[:, 0]) / np.sqrt(allc[:, 1]) <= allc[:, 2]
+    assert np.array_equal(b.astype(bool), lit)
+    for eps in (1e-31, 1.5, math.inf):
+        D.derive_params(C.c_double(1e3), C.c_double(5.0), C.c_double(eps), out)
+        assert math.isnan(out[2]) and math.isnan(out[3])
+
+    # ---- f64::clamp(x, -m, m) by magnitude
+    x = np.concatenate([rng.normal(0, 10, 5000), [0.0, -0.0, math.inf, -math.inf, math.nan, 3.0, -3.0, 2.9999999999999996]])
+    m = np.concatenate([rng.uniform(0.1, 5, 5000), [3.0] * 8])
+    got = np.zeros_like(x)
+    D.clamp_symmetric_array(C.c_ulonglong(x.size), _p(x), _p(m), _p(got))
+    want = np.where(x < -m, -m, np.where(x > m, m, x))        # f64::clamp: NaN passes through
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+    # ---- the one-word record of the guarded divisions never passes an operand outside fdiv::in_window
+    x = np.concatenate([10.0 ** rng.uniform(-320, 308, 20000) * rng.choice([-1.0, 1.0], 20000),
+                        2.0 ** np.arange(-310, 311, dtype=np.float64), -(2.0 ** np.arange(-310, 311, dtype=np.float64)),
+                        ulps(np.array([2.0 ** -300, 2.0 ** 300]), -1), ulps(np.array([2.0 ** -300, 2.0 ** 300]), 1),
+                        [0.0, -0.0, math.inf, -math.inf, math.nan, 5e-324, 2.2250738585072014e-308]])
+    x = np.ascontiguousarray(x)
+    ok, inw = np.zeros(x.size, np.int32), np.zeros(x.size, np.int32)
+    D.guard_array(C.c_ulonglong(x.size), _p(x), ok.ctypes.data_as(C.POINTER(C.c_int)), inw.ctypes.data_as(C.POINTER(C.c_int)))
+    assert not (ok.astype(bool) & ~inw.astype(bool)).any()    # passes  =>  inside the window
+    with np.errstate(invalid="ignore"):
+        inside = (np.abs(x) >= 2.0 ** -300) & (np.abs(x) < 2.0 ** 300)
+    assert np.array_equal(ok.astype(bool), inside)             # and it passes everything in [2^-300, 2^300)
