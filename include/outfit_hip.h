@@ -161,14 +161,29 @@ typedef struct outfit_ephem {
 
 /* What the host needs to rebuild
  *   Result<FitOrbitResult::IODGauss((GaussResult, IODRMS)), OutfitError>
- * for one trajectory (constants.rs:134-137,195). 96 bytes. */
+ * for one trajectory (constants.rs:134-137,195). 96 bytes.
+ *
+ * KNOWN DEVIATION — the order among triplets of EQUAL weight when max_triplets > 20. The reference sorts the kept
+ * triplets with `sort_unstable_by` (triplet_generation/mod.rs:404): an insertion sort up to 20 elements, which this
+ * library restates, and Rust's ipnsort beyond, whose order among equal keys is unspecified and is NOT restated — here
+ * equal weights keep the order in which the bounded heap released them (a stable order). Exactly equal weights are
+ * common on regular cadences (exposures a fixed interval apart). What that order can reach, and nothing else:
+ *   - `best_triplet`: an index of THIS ABI into the sorted list (the reference returns no triplet index);
+ *   - which tied triplet receives which noise draws (noise_z is indexed by triplet rank; the reference draws from one
+ *     RNG stream in triplet order): a different but equally distributed assignment;
+ *   - `cause` of OUTFIT_TRAJ_NO_VIABLE_ORBIT, which is the LAST error in triplet order (trajectory.rs:458-544): when
+ *     every triplet fails and the final run of kept triplets is a tie whose members fail differently
+ *     (tests/test_oracle_pipeline.py::test_order_of_equal_weights_can_decide_the_cause_of_no_viable_orbit);
+ *   - the winner between two candidates whose RMS is the same double (the fold keeps the first strict minimum).
+ * Without noise the selected orbit, its RMS, `status`, `attempts` and `n_triplets` do not depend on it
+ * (test_order_of_equal_weights_decides_nothing_the_reference_returns). For max_triplets <= 20 there is no deviation. */
 typedef struct outfit_gauss_result {
   int32_t  status;           /* OUTFIT_TRAJ_*                                   */
-  int32_t  cause;            /* OUTFIT_CAUSE_* (NoViableOrbit only)             */
+  int32_t  cause;            /* OUTFIT_CAUSE_* (NoViableOrbit only; tie order: see above) */
   int32_t  stage;            /* OUTFIT_STAGE_*                                  */
   int32_t  kind;             /* OUTFIT_KIND_*                                   */
   uint32_t attempts;         /* n_attempts (trajectory.rs:463,478)              */
-  uint32_t best_triplet;     /* index into the weight-sorted triplet list       */
+  uint32_t best_triplet;     /* index into the weight-sorted triplet list (tie order: see above) */
   uint32_t best_realization; /* 0 = noise-free original (gauss.rs:342-346)      */
   uint32_t n_triplets;       /* triplets generated for this trajectory          */
   double   epoch;            /* reference_epoch (MJD TT, light-time corrected)  */

@@ -16,6 +16,16 @@
 
 namespace outfit {
 
+#ifdef OUTFIT_K0_STATS  // diagnostic build (tools/perf_k0_stats.py): what one trajectory's wave-form selection does
+// 0 trajectories, 1 middle groups (64 rows tested at once), 2 rows enumerated, 3 last-chunks scored (ballots),
+// 4 chunks with a survivor, 5 survivors absorbed, 6 pushes while filling, 7 replacements (pop + push),
+// 8 survivors dropped (top fell since the ballot), 9 sift-down levels, 10 sift-up levels, 11 cycles
+__device__ unsigned long long g_k0_stat[16];
+#define K0STAT(slot, n) do { if ((threadIdx.x & 63u) == 0) k0_local[slot] += (n); } while (0)
+#else
+#define K0STAT(slot, n) do { } while (0)
+#endif
+
 struct TripletParams {
   double dt_min, dt_max, inv_dtw;
   unsigned long long max_keep;  // IODParams::max_obs_for_triplets
@@ -103,6 +113,9 @@ __device__ __forceinline__ unsigned heap_sift_up_raw(const View& h, unsigned sta
     const unsigned parent = (pos - 1) / 2;
     const double wp = h.W(parent);
     const typename View::Raw rp = h.raw(parent);
+#ifdef OUTFIT_K0_STATS
+    atomicAdd(&g_k0_stat[10], 1ull);
+#endif
     if (wt_le(ew, wp)) break;
     h.set_raw(pos, wp, rp);
     pos = parent;
@@ -126,6 +139,9 @@ __device__ __forceinline__ void heap_pop(const View& h, unsigned& len) {
   const unsigned end = len;
   unsigned pos = 0, child = 1;
   while (end >= 2 && child <= end - 2) {
+#ifdef OUTFIT_K0_STATS
+    atomicAdd(&g_k0_stat[9], 1ull);
+#endif
     const double wl = h.W(child), wr = h.W(child + 1);
     const typename View::Raw rl = h.raw(child), rr = h.raw(child + 1);
     const bool right = wt_le(wl, wr);
@@ -284,23 +300,32 @@ __device__ __forceinline__ unsigned select_triplets_wave(const double* mjd /* th
   __syncthreads();
   unsigned len = 0;       // wave-uniform
   double root_w = 0.0;    // wave-uniform copy of the heap's top weight
+#ifdef OUTFIT_K0_STATS
+  unsigned long long k0_local[12] = {};
+  const unsigned long long k0_t0 = clock64();
+#endif
   // survivors of one ballot, in lane order; `w` / `id` are the lanes' candidates
   auto absorb = [&](unsigned long long mask, double w, unsigned long long id) {
+    K0STAT(4, 1);
     while (mask) {
       const int l = __ffsll((long long)mask) - 1;
       mask &= mask - 1ull;
       const double wl = __shfl(w, l);
       const unsigned long long il = __shfl(id, l);
+      K0STAT(5, 1);
       if (len < P.k_cap) {
         if (lane == 0) heap_sift_up(h, 0, len, wl, il);
         ++len;
+        K0STAT(6, 1);
       } else if (wl < root_w) {
         if (lane == 0) {
           unsigned ll = len;
           heap_pop(h, ll);
           heap_sift_up(h, 0, ll, wl, il);
         }
+        K0STAT(7, 1);
       } else {
+        K0STAT(8, 1);
         continue;  // the top has dropped below this candidate since the ballot
       }
       __syncthreads();
@@ -336,6 +361,7 @@ __device__ __forceinline__ unsigned select_triplets_wave(const double* mjd /* th
       const double tm_mine = ep[m_in ? m_mine : 0];
       const double g12_mine = s_gap(tm_mine - t0, P.inv_dtw);
       unsigned long long rows = __ballot(m_in && (len < P.k_cap || g12_mine + 1.0 < root_w));
+      K0STAT(1, 1);
       while (rows) {
         const int rl = __ffsll((long long)rows) - 1;
         rows &= rows - 1ull;
@@ -344,7 +370,9 @@ __device__ __forceinline__ unsigned select_triplets_wave(const double* mjd /* th
         const unsigned middle = mb + (unsigned)rl;
         const double tm = __shfl(tm_mine, rl);
         const unsigned first = lo > middle + 1 ? lo : middle + 1;
+        K0STAT(2, 1);
         for (unsigned lb = first; lb <= hi; lb += 64u) {
+          K0STAT(3, 1);
           const unsigned last = lb + lane;
           const bool in = last <= hi;
           const double w = g12 + s_gap(ep[in ? last : 0] - tm, P.inv_dtw);
@@ -355,6 +383,13 @@ __device__ __forceinline__ unsigned select_triplets_wave(const double* mjd /* th
     }
   }
   __syncthreads();
+#ifdef OUTFIT_K0_STATS
+  if (lane == 0) {
+    atomicAdd(&g_k0_stat[0], 1ull);
+    for (int q = 1; q <= 8; ++q) atomicAdd(&g_k0_stat[q], k0_local[q]);
+    atomicAdd(&g_k0_stat[11], (unsigned long long)(clock64() - k0_t0));
+  }
+#endif
   // sort_unstable_by(weight) as the stable order of the heap's vector (see select_triplets): rank of every slot
   for (unsigned i = lane; i < len; i += 64u) {
     const double wi = h.W(i);

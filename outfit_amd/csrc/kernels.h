@@ -18,7 +18,10 @@ constexpr unsigned kRootSlots = 8;       // a degree-8 polynomial has at most 8 
 constexpr unsigned kCorrectBlock = OUTFIT_GENERAL_BLOCK;  // lanes per workgroup of the correction kernel
 constexpr unsigned kCorrectLdsDoubles = 34;  // per lane: S, S^-1, observer matrix (27) + prelim state (7)
 constexpr unsigned kFastBlock = 64;          // lanes per workgroup of the fast correction kernel
-constexpr unsigned kFastWavesPerSimd = 3;    // residency the fast kernel is compiled and launched for
+#ifndef OUTFIT_FAST_WAVES
+#define OUTFIT_FAST_WAVES 3
+#endif
+constexpr unsigned kFastWavesPerSimd = OUTFIT_FAST_WAVES;  // residency the fast kernel is compiled and launched for
 
 // per-candidate flag word (phase A writes it, phase B/C update it, K3 replays it)
 constexpr unsigned kFlagEmpty = 0x80000000u;  // slot beyond n_triplets (never read by K3)

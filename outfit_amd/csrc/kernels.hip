@@ -1873,7 +1873,26 @@ hipError_t launch_triplet_select(const TripletArgs& a, bool lds_heap, hipStream_
 }
 hipError_t launch_triplet_select_wave(const TripletArgs& a, size_t lds_bytes, hipStream_t s) {
   if (a.n_wave_list == 0) return hipSuccess;
+#ifdef OUTFIT_K0_STATS
+  {
+    static const unsigned long long zero[16] = {};
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_k0_stat), zero, sizeof zero);
+  }
+#endif
   hipLaunchKernelGGL(k_triplet_select_wave, dim3(a.n_wave_list), dim3(64), lds_bytes, s, a);
+#ifdef OUTFIT_K0_STATS
+  {
+    unsigned long long k[16] = {};
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpyFromSymbol(k, HIP_SYMBOL(g_k0_stat), sizeof k);
+    const double t = k[0] ? (double)k[0] : 1.0;
+    fprintf(stderr, "[k0 stats] trajectories %llu | per trajectory: middle groups %.1f  rows enumerated %.1f  last-chunks scored %.1f  "
+                    "chunks with a survivor %.1f  survivors %.1f (fill pushes %.1f, replacements %.1f, dropped %.1f)  "
+                    "sift-down levels %.1f  sift-up levels %.1f  cycles %.3e\n",
+            k[0], k[1] / t, k[2] / t, k[3] / t, k[4] / t, k[5] / t, k[6] / t, k[7] / t, k[8] / t, k[9] / t, k[10] / t, k[11] / t);
+  }
+#endif
   return hipGetLastError();
 }
 hipError_t launch_observer_prepass(const PrepassArgs& a, hipStream_t s) {

@@ -240,6 +240,50 @@ def test_order_of_equal_weights_decides_nothing_the_reference_returns(ds64):
     assert (a["best_triplet"] != b["best_triplet"]).any()   # the index does move
 
 
+def test_order_of_equal_weights_can_decide_the_cause_of_no_viable_orbit():
+    """The one field of the reference's OWN result that the order among equal weights can reach: `NoViableOrbit.cause`
+    is the LAST error in triplet order (trajectory.rs:458-544), so when every triplet fails and the final run of kept
+    triplets is a tie whose members fail differently, the cause is whichever of them the sort put last. For
+    max_triplets > 20 that sort is Rust's unstable ipnsort (triplet_generation/mod.rs:404), which this library does not
+    restate: it keeps the heap's order among equals (stable). A KNOWN DEVIATION, stated in include/outfit_hip.h at
+    `cause` and in INTEGRATION.md; constructed here: max_triplets = 24 ends the kept list of the bench cadence with two
+    triplets of equal weight; the three observations of one of them are given ONE direction (its direction matrix is
+    singular), every other direction is random (no admissible root)."""
+    L = O.lib()
+    L.orc_generate_triplet_indices.restype = C.c_size_t
+    L.orc_generate_triplet_indices.argtypes = [C.POINTER(C.c_double), C.c_size_t, C.c_void_p, C.POINTER(C.c_uint32),
+                                               C.POINTER(C.c_double)]
+    ds = synth.make_dataset(6, seed=77)
+    n, K = 20, 24
+    p = synth.bench_params(O.default_params())
+    p.max_triplets = K
+    rng = np.random.default_rng(3)
+    d = {k: np.array(v, copy=True) if isinstance(v, np.ndarray) else v for k, v in ds.items()}
+    for t in range(6):
+        m = np.ascontiguousarray(ds["mjd_tt"][t * n:(t + 1) * n])
+        idx, w = (C.c_uint32 * (3 * K))(), (C.c_double * K)()
+        k = L.orc_generate_triplet_indices(m.ctypes.data_as(C.POINTER(C.c_double)), n, C.byref(p), idx, w)
+        w, tri = np.array(w[:k]), np.array(idx[:3 * k]).reshape(k, 3)
+        last_run = np.nonzero(w == w[-1])[0]
+        assert k == K and len(last_run) == 2                     # the kept list ends in a tie
+        o = t * n
+        d["ra"][o:o + n] = rng.uniform(0, 2 * np.pi, n)
+        d["dec"][o:o + n] = rng.uniform(-1.2, 1.2, n)
+        one = tri[last_run[0]]
+        d["ra"][o + one], d["dec"][o + one] = d["ra"][o + one[0]], d["dec"][o + one[0]]
+    a = run(d, p)
+    flag = C.c_int.in_dll(L, "orc_tie_order")
+    flag.value = 1
+    try:
+        b = run(d, p)
+    finally:
+        flag.value = 0
+    assert (a["status"] == 2).all() and (b["status"] == 2).all()                 # NoViableOrbit either way
+    assert np.array_equal(a["attempts"], b["attempts"])
+    # GaussNoRootsFound with the stable order, SingularDirectionMatrix with the run reversed
+    assert (a["cause"] == 1).all() and (b["cause"] == 2).all()
+
+
 def test_select_rms_interval_on_the_reference_data_file():
     """src/trajectory.rs:566-625 (`test_select_rms_interval`): on the 37 observations of tests/data/2015AB.obs the best
     triplet (generator + weights + bounded heap, max_triplets = 10: the exactly restated insertion-sort regime)
