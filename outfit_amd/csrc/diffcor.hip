@@ -10,6 +10,20 @@
 
 namespace outfit {
 
+#ifdef OUTFIT_DC_STATS  // diagnostic build (tools/perf_lsq.py with a stats library): (wave passes, active lanes) per phase
+__device__ unsigned long long g_dc_stat[32];
+#define DCSTAT(slot)                                                                \
+  do {                                                                              \
+    const unsigned long long m__ = __ballot(true);                                  \
+    if (__lane_id() == (unsigned)__ffsll((long long)m__) - 1u) {                    \
+      atomicAdd(&g_dc_stat[2 * (slot)], 1ull);                                      \
+      atomicAdd(&g_dc_stat[2 * (slot) + 1], (unsigned long long)__popcll(m__));     \
+    }                                                                               \
+  } while (0)
+#else
+#define DCSTAT(slot) do { } while (0)
+#endif
+
 namespace {
 constexpr double kF64Max = 1.7976931348623157e308;
 
@@ -165,6 +179,7 @@ k_diffcor(DiffCorArgs A) {
       if (sub == 0) g = atomicAdd(A.queue, 1ull);
       g = __shfl(g, (int)(threadIdx.x - sub));
       if (g >= A.n_traj) { exhausted = true; break; }
+      DCSTAT(0);  // refill
       t = g;
       base = A.traj_offset[t];
       n = (unsigned)(A.traj_offset[t + 1] - base);
@@ -197,10 +212,13 @@ k_diffcor(DiffCorArgs A) {
       }
     }
     if (__ballot(t != kNone) == 0) break;  // queue drained and every group of the wave idle
+    DCSTAT(1);  // trip, all lanes of the wave that are still in the kernel
     if (t == kNone) continue;
+    DCSTAT(2);  // trip, lanes holding a trajectory
 
     bool finished = false;
     if (phase == kIterate) {
+      DCSTAT(3);  // Newton iteration
       total_iters += 1;
       // ---- single_iteration (single_iteration.rs:158-328) ----------------------------------------------
       const PartialsFrame P = partials_frame<kFn>(q);
@@ -216,9 +234,11 @@ k_diffcor(DiffCorArgs A) {
         bool eq_active = false;
         ObsPartials ob;
         double rra = 0.0, rdec = 0.0, wa = 0.0, wd = 0.0;
+        DCSTAT(4);  // observation pass
         if (i < n) {
           const unsigned char s = sel_written ? A.sel[o] : (unsigned char)0;
           if (s == 0) {
+            DCSTAT(5);  // obs_and_partials
             const Vec3 op = {A.obs_pos[3 * o], A.obs_pos[3 * o + 1], A.obs_pos[3 * o + 2]};
             if (obs_and_partials<kFn>(q, P, A.mjd[o], op, ob)) {
               eq_active = true;
@@ -259,6 +279,7 @@ k_diffcor(DiffCorArgs A) {
         }
       }
       active = group_sum<kG>(active);
+      DCSTAT(6);  // solve
       const double wss = sN[42][lane];
       // ---- solve_weighted_least_squares (least_square.rs:211-303) ---------------------------------------
       const unsigned num_meas = active * 2;
@@ -274,6 +295,7 @@ k_diffcor(DiffCorArgs A) {
       // the inverse goes column by column into the staging half of the covariance scratch
       double* cov_new = A.cov + (unsigned long long)cur * 36ull * A.n_traj + t;
       bool inv_ok = cholesky_inverse6_lds(&sN[0][lane], kSlots, cov_new, A.n_traj);
+      if (!inv_ok) DCSTAT(7);  // QR fallback
       if (!inv_ok)  // every lane of the group works on its own scratch column
         inv_ok = qr_inverse6(A.qr_work + t * kG + sub, A.n_traj * kG, &sN[0][lane], kSlots, cov_new, A.n_traj);
       if (!inv_ok) {
@@ -342,6 +364,7 @@ k_diffcor(DiffCorArgs A) {
       }
     } else {
       // ---- update_observation_selection (outlier_rejection.rs:132-235) ---------------------------------
+      DCSTAT(8);  // outlier pass
       double cov[36];
 #pragma unroll
       for (int i = 0; i < 36; ++i) cov[i] = A.cov[((unsigned long long)(cur ^ 1u) * 36ull + i) * A.n_traj + t];
@@ -394,7 +417,7 @@ k_diffcor(DiffCorArgs A) {
       if (changes == 0 || outer > C.max_outlier_rejection_passes) finished = true;
       else if (!begin_outer()) finished = true;
     }
-    if (finished) finish();
+    if (finished) { DCSTAT(9); finish(); }
   }
 }
 
@@ -418,6 +441,20 @@ hipError_t launch_diffcor(const DiffCorArgs& a, unsigned group, unsigned n_cu, h
             else hipLaunchKernelGGL((k_diffcor<8, kFnCr>), dim3(grid), dim3(64), 0, s, a); break;
     default: return hipErrorInvalidValue;
   }
+#ifdef OUTFIT_DC_STATS
+  {
+    unsigned long long k[32] = {};
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpyFromSymbol(k, HIP_SYMBOL(g_dc_stat), sizeof k);
+    static const unsigned long long zero[32] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dc_stat), zero, sizeof zero);
+    const char* names[10] = {"refill", "trip (lanes in the kernel)", "trip (lanes with a trajectory)", "Newton iteration",
+                             "observation pass", "obs_and_partials", "solve", "QR fallback", "outlier pass", "finish"};
+    for (int i = 0; i < 10; ++i)
+      fprintf(stderr, "[dc stats] %-32s wave passes %10llu  lanes/pass %5.2f\n", names[i], k[2 * i],
+              k[2 * i] ? (double)k[2 * i + 1] / k[2 * i] : 0.0);
+  }
+#endif
   return hipGetLastError();
 }
 

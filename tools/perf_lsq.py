@@ -1,4 +1,5 @@
-"""GPU box: k_diffcor time per 100k objects for a few configurations (HIP-event kernel times)."""
+"""GPU box: k_diffcor time per 100k objects for a few configurations (HIP-event kernel times).
+    python tools/perf_lsq.py [objects] [library to load instead of the shipped one]"""
 import os
 import sys
 
@@ -6,6 +7,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT]
+if len(sys.argv) > 2:
+    import outfit_amd._lib as _L  # noqa: E402
+    _L.LIB_PATH = sys.argv[2]
 import outfit_amd  # noqa: E402
 from outfit_amd import synth  # noqa: E402
 
