@@ -751,7 +751,7 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
       const long long v = std::atoll(e);
       if (v >= 0) wave_min = (unsigned)std::min<long long>(v, 1ll << 30);
     }
-    const uint64_t lds = (reduced + 2ull * s->k_cap) * sizeof(double);
+    const uint64_t lds = (((reduced + 1) & ~1ull) + 2ull * s->k_cap) * sizeof(double);  // epochs (padded to 16 B), heap slots of 16 B
     if (wave_min && s->k_cap > 0 && reduced >= wave_min && lds <= 60ull * 1024 && s->n_traj < (1ull << 32)) {
       for (uint64_t t = 0; t < s->n_traj; ++t)   // the lane kernels skip a trajectory by the same function
         if (outfit::wave_form_owns(off[t + 1] - off[t], s->tp.max_keep, wave_min))

@@ -66,6 +66,7 @@ struct HeapView {
     w[s * stride] = ww;
     id[s * stride] = r;
   }
+  __device__ __forceinline__ void load(unsigned s, double& ww, Raw& r) const { ww = w[s * stride]; r = id[s * stride]; }
 };
 struct LdsHeapView {
   double* w;
@@ -97,6 +98,7 @@ struct LdsHeapView {
     w[s * stride] = ww;
     id[s * stride] = r;
   }
+  __device__ __forceinline__ void load(unsigned s, double& ww, Raw& r) const { ww = w[s * stride]; r = id[s * stride]; }
 };
 
 // WeightedTriplet::cmp (mod.rs:135-146): weight first; indices only when a weight is NaN.
@@ -111,8 +113,9 @@ __device__ __forceinline__ unsigned heap_sift_up_raw(const View& h, unsigned sta
                                                      typename View::Raw er) {
   while (pos > start) {
     const unsigned parent = (pos - 1) / 2;
-    const double wp = h.W(parent);
-    const typename View::Raw rp = h.raw(parent);
+    double wp;
+    typename View::Raw rp;
+    h.load(parent, wp, rp);
 #ifdef OUTFIT_K0_STATS
     atomicAdd(&g_k0_stat[10], 1ull);
 #endif
@@ -132,8 +135,9 @@ __device__ __forceinline__ unsigned heap_sift_up(const View& h, unsigned start, 
 // BinaryHeap::pop(): swap the last element into the root, sift_down_to_bottom(0), sift_up
 template <class View>
 __device__ __forceinline__ void heap_pop(const View& h, unsigned& len) {
-  const double lw = h.W(len - 1);
-  const typename View::Raw lr = h.raw(len - 1);
+  double lw;
+  typename View::Raw lr;
+  h.load(len - 1, lw, lr);
   --len;
   if (len == 0) return;
   const unsigned end = len;
@@ -142,8 +146,10 @@ __device__ __forceinline__ void heap_pop(const View& h, unsigned& len) {
 #ifdef OUTFIT_K0_STATS
     atomicAdd(&g_k0_stat[9], 1ull);
 #endif
-    const double wl = h.W(child), wr = h.W(child + 1);
-    const typename View::Raw rl = h.raw(child), rr = h.raw(child + 1);
+    double wl, wr;
+    typename View::Raw rl, rr;
+    h.load(child, wl, rl);
+    h.load(child + 1, wr, rr);
     const bool right = wt_le(wl, wr);
     h.set_raw(pos, right ? wr : wl, right ? rr : rl);
     pos = child + (right ? 1u : 0u);
@@ -277,16 +283,25 @@ __device__ __forceinline__ unsigned select_triplets(const double* mjd /* this tr
 // (rank = #{w_j < w_i} + #{j < i : w_j == w_i}), which is what a stable insertion sort produces.
 // LDS: the reduced epochs [n] and the heap [k_cap] x (weight, 64-bit id); the launcher checks that it fits.
 // Returns the number of triplets (wave-uniform) and writes them, sorted, to `out` (global).
-struct WaveHeap {   // heap of one trajectory in LDS; same interface as HeapView (stride 1)
-  double* w;
-  unsigned long long* id;
-  __device__ __forceinline__ double W(unsigned s) const { return w[s]; }
-  __device__ __forceinline__ unsigned long long I(unsigned s) const { return id[s]; }
-  __device__ __forceinline__ void move(unsigned dst, unsigned src) const { w[dst] = w[src]; id[dst] = id[src]; }
+struct WaveHeap {   // heap of one trajectory in LDS; same interface as HeapView
+  // Round 5: slot s is ONE 16-byte element (weight, 64-bit id) at a 16-byte aligned address: a slot is read or written
+  // by a single DS instruction (ds_read_b128 / ds_write_b128) instead of two — the kernel issues one-lane LDS
+  // instructions for most of its time (profiles/round05_k0_multi_dropped.log), and half of those were the ids.
+  double2* e;
+  __device__ __forceinline__ double W(unsigned s) const { return e[s].x; }
+  __device__ __forceinline__ unsigned long long I(unsigned s) const { return (unsigned long long)__double_as_longlong(e[s].y); }
+  __device__ __forceinline__ void move(unsigned dst, unsigned src) const { e[dst] = e[src]; }
   typedef unsigned long long Raw;
-  __device__ __forceinline__ Raw raw(unsigned s) const { return id[s]; }
+  __device__ __forceinline__ Raw raw(unsigned s) const { return I(s); }
   __device__ __forceinline__ Raw encode(unsigned long long ii) const { return ii; }
-  __device__ __forceinline__ void set_raw(unsigned s, double ww, Raw r) const { w[s] = ww; id[s] = r; }
+  __device__ __forceinline__ void set_raw(unsigned s, double ww, Raw r) const {
+    e[s] = double2{ww, __longlong_as_double((long long)r)};
+  }
+  __device__ __forceinline__ void load(unsigned s, double& ww, Raw& r) const {
+    const double2 v = e[s];
+    ww = v.x;
+    r = (unsigned long long)__double_as_longlong(v.y);
+  }
 };
 
 __device__ __forceinline__ unsigned select_triplets_wave(const double* mjd /* this trajectory */, unsigned long long n_obs64,

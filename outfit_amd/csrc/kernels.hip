@@ -77,14 +77,14 @@ k_triplet_select_lds(TripletArgs a) {
 // heap's weights [k_cap] and 64-bit ids [k_cap].
 __global__ void __launch_bounds__(64)
 k_triplet_select_wave(TripletArgs a) {
-  extern __shared__ double lds_wave[];
+  extern __shared__ __attribute__((aligned(16))) double lds_wave[];
   const unsigned long long traj = a.wave_list[blockIdx.x];
   const unsigned long long lt = traj - a.traj0;
   const unsigned long long base = a.traj_offset[traj];
   const unsigned long long n_obs = a.traj_offset[traj + 1] - base;
   const unsigned n = (unsigned)reduced_len(n_obs, a.P.max_keep);
   double* ep = lds_wave;
-  WaveHeap h{lds_wave + n, reinterpret_cast<unsigned long long*>(lds_wave + n + a.P.k_cap)};
+  WaveHeap h{reinterpret_cast<double2*>(lds_wave + ((n + 1u) & ~1u))};   // 16-byte aligned behind the epochs
   const unsigned len = select_triplets_wave(a.mjd + base, n_obs, a.P, ep, h, a.triplets + lt * a.P.k_cap);
   if (threadIdx.x == 0) a.n_triplets[lt] = len;
 }

@@ -16,6 +16,7 @@ using std::hypot; using std::acos; using std::log; using std::exp; using std::si
 #ifndef INFINITY
 #define INFINITY __builtin_inf()
 #endif
+struct double2 { double x, y; };
 // bit casts and word access of the HIP device library
 static inline long long __double_as_longlong(double x) { long long r; std::memcpy(&r, &x, 8); return r; }
 static inline double __longlong_as_double(long long x) { double r; std::memcpy(&r, &x, 8); return r; }
