@@ -304,6 +304,26 @@ struct WaveHeap {   // heap of one trajectory in LDS; same interface as HeapView
   }
 };
 
+// value of `x` in lane `l` (wave-uniform l): v_readlane_b32 on the vector ALU instead of the ds_bpermute_b32 that
+// __shfl issues — the kernel is short of LDS issue slots, not of ALU ones
+__device__ __forceinline__ double lane_value(double x, int l) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+#else
+  (void)l;
+  return x;
+#endif
+}
+__device__ __forceinline__ unsigned long long lane_value(unsigned long long x, int l) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(x >> 32), l) << 32) |
+         (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(x & 0xFFFFFFFFull), l);
+#else
+  (void)l;
+  return x;
+#endif
+}
+
 __device__ __forceinline__ unsigned select_triplets_wave(const double* mjd /* this trajectory */, unsigned long long n_obs64,
                                                          const TripletParams& P, double* ep /* LDS [n] */,
                                                          const WaveHeap& h, unsigned long long* out) {
@@ -325,8 +345,8 @@ __device__ __forceinline__ unsigned select_triplets_wave(const double* mjd /* th
     while (mask) {
       const int l = __ffsll((long long)mask) - 1;
       mask &= mask - 1ull;
-      const double wl = __shfl(w, l);
-      const unsigned long long il = __shfl(id, l);
+      const double wl = lane_value(w, l);
+      const unsigned long long il = lane_value(id, l);
       K0STAT(5, 1);
       if (len < P.k_cap) {
         if (lane == 0) heap_sift_up(h, 0, len, wl, il);
@@ -380,10 +400,10 @@ __device__ __forceinline__ unsigned select_triplets_wave(const double* mjd /* th
       while (rows) {
         const int rl = __ffsll((long long)rows) - 1;
         rows &= rows - 1ull;
-        const double g12 = __shfl(g12_mine, rl);
+        const double g12 = lane_value(g12_mine, rl);
         if (len == P.k_cap && !(g12 + 1.0 < root_w)) continue;  // the top has dropped since the row ballot
         const unsigned middle = mb + (unsigned)rl;
-        const double tm = __shfl(tm_mine, rl);
+        const double tm = lane_value(tm_mine, rl);
         const unsigned first = lo > middle + 1 ? lo : middle + 1;
         K0STAT(2, 1);
         for (unsigned lb = first; lb <= hi; lb += 64u) {
