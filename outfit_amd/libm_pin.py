@@ -19,13 +19,40 @@ PINNED_LIBM_WHAT = "Ubuntu GLIBC 2.35-0ubuntu3.12, x86-64, Build ID df46fc5774ae
 
 
 def _libm_path():
-    """Path of the libm.so.6 this process resolves (the file whose code `sin`, `atan2`, ... come from)."""
+    """Path of the libm.so.6 MAPPED INTO THIS PROCESS — the object whose code `sin`, `atan2`, ... of a library loaded here
+    (the oracle, via ctypes) resolve to. A well-known path says nothing under conda, LD_LIBRARY_PATH or a container
+    with its own libm, so the mapping is read from /proc/self/maps after making sure a libm is loaded; only when that
+    is not possible (no procfs) the usual locations are tried."""
+    try:
+        ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")      # map it if nothing has yet
+    except OSError:
+        pass
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.split(None, 5)[5].strip() if len(line.split(None, 5)) == 6 else ""
+                base = os.path.basename(path)
+                if base.startswith("libm.so") or base.startswith("libm-"):
+                    return os.path.realpath(path)
+    except OSError:
+        pass
     for cand in ("/lib/x86_64-linux-gnu/libm.so.6", "/usr/lib/x86_64-linux-gnu/libm.so.6", "/lib64/libm.so.6",
                  "/usr/lib64/libm.so.6"):
         if os.path.exists(cand):
             return os.path.realpath(cand)
-    name = ctypes.util.find_library("m")
-    return name or None
+    return None
+
+
+def _cpu_flags():
+    """The flag tokens of the first `flags` line of /proc/cpuinfo (token membership: a flag may be last on its line)."""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    return set(line.split(":", 1)[1].split())
+    except OSError:
+        pass
+    return set()
 
 
 @functools.lru_cache(maxsize=1)
@@ -41,11 +68,7 @@ def host_libm_identity():
         out["libc"], out["version"] = "glibc", fn().decode()
     except (AttributeError, OSError):
         pass
-    try:
-        flags = open("/proc/cpuinfo").read()
-        out["fma_avx2"] = " fma " in flags and " avx2 " in flags  # the ifunc variants the restatement follows
-    except OSError:
-        pass
+    out["fma_avx2"] = {"fma", "avx2"} <= _cpu_flags()  # the ifunc variants the restatement follows
     p = _libm_path()
     if p and os.path.isfile(p):
         out["libm_path"] = p
