@@ -33,6 +33,9 @@ pass pmc_sq    "--steps 1 --warmup 0 $H" SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ
 pass pmc_f64   "--steps 1 --warmup 0 $H" SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64
 # 3a) lane utilisation: active lanes per VALU instruction = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU
 pass pmc_lanes "--steps 1 --warmup 0 $H" SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES
+# 3aa) dynamic instruction classes (round 5): what the VALU instructions that are not fp64 add / mul / fma / trans are,
+#      and what issues beside the VALU (scalar ALU, scalar memory, LDS, branches)
+pass pmc_mix   "--steps 1 --warmup 0 $H" SQ_INSTS_VALU SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_BRANCH
 # 3b) engine clock under this load: GRBM_GUI_ACTIVE counts GPU clock cycles while the kernel runs (cycles / duration)
 pass pmc_clk   "--steps 1 --warmup 0 $H" GRBM_GUI_ACTIVE
 # 4) the extra workloads: instruction + lane counters, bytes each way, fp64 mix

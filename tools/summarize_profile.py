@@ -165,6 +165,25 @@ with open(out, "w") as f:
         fl = (tot["SQ_INSTS_VALU_ADD_F64"] + tot["SQ_INSTS_VALU_MUL_F64"] + 2 * tot["SQ_INSTS_VALU_FMA_F64"] + tot["SQ_INSTS_VALU_TRANS_F64"]) * 64
         f.write("IOD kernels: executed fp64 lane-operations per step (add + mul + 2 fma + trans, x 64 lanes, upper bound: "
                 "inactive lanes included) %.3e = %.3e per object\n" % (fl, fl / n_obj))
+    mix, cmix = counters("pmc_mix")
+    if mix:
+        f.write("\ndynamic instruction classes per step (separate pass: SQ_INSTS_VALU, _VALU_INT32, _VALU_INT64, _VALU_CVT, _SALU, "
+                "_SMEM, _LDS, _BRANCH; `other VALU` = VALU - fp64 (pass above) - int32 - int64 - cvt: moves, selects, compares, "
+                "lane reads/writes, v_div_* scaffolding, ldexp, min/max):\n")
+        for k in kernels:
+            st = max(1.0, cmix.get(k, 0))
+            g = lambda c: mix.get((k, c), 0.0) / st  # noqa: E731
+            v = g("SQ_INSTS_VALU")
+            if v <= 0:
+                continue
+            st64 = max(1.0, c64.get(k, 0))
+            fp = sum(f64.get((k, c), 0.0) for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64",
+                                                     "SQ_INSTS_VALU_TRANS_F64")) / st64
+            i32, i64, cvt = g("SQ_INSTS_VALU_INT32"), g("SQ_INSTS_VALU_INT64"), g("SQ_INSTS_VALU_CVT")
+            f.write("%-24s VALU %.3e: fp64 %.3f  int32 %.3f  int64 %.3f  cvt %.3f  other %.3f | per VALU instruction: "
+                    "SALU %.2f  SMEM %.3f  LDS %.3f  branch %.3f\n"
+                    % (k, v, fp / v, i32 / v, i64 / v, cvt / v, max(0.0, 1.0 - (fp + i32 + i64 + cvt) / v),
+                       g("SQ_INSTS_SALU") / v, g("SQ_INSTS_SMEM") / v, g("SQ_INSTS_LDS") / v, g("SQ_INSTS_BRANCH") / v))
     if clk_lines:
         f.write("\nengine clock under this load (separate pass, --pmc GRBM_GUI_ACTIVE; kernels on side streams overlap others and read high):\n")
         f.write("\n".join(clk_lines) + "\n")
