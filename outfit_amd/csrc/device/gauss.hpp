@@ -495,6 +495,9 @@ __device__ __forceinline__ const GaussParams& tail_params(const GaussParams& P) 
 template <class Params>
 __device__ __forceinline__ auto tail_params(const Params& P) -> decltype(P.tail()) { return P.tail(); }
 
+#ifndef OUTFIT_K2B_UNROLL_SIDES   // measurement switch: two copies of the Kepler solver instead of a rolled loop over the sides
+#define OUTFIT_K2B_UNROLL_SIDES 0
+#endif
 template <bool kFast, bool kWarmOnly = kFast, class Params = GaussParams, bool kPair = false>
 __device__ __forceinline__ CorrStep correction_iteration_impl(const Mat3& obs, const Mat3& S, const Mat3& Sinv,
                                                               double t_mid, double dt01, double dt21,
@@ -532,7 +535,11 @@ __device__ __forceinline__ CorrStep correction_iteration_impl(const Mat3& obs, c
     a = odd ? other : mine;
     b = odd ? mine : other;
   } else {
+#if OUTFIT_K2B_UNROLL_SIDES
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
   for (int side = 0; side < 2; ++side) {
     const double dt = side ? dt21 : dt01;
     const double chi = side ? st.chi21 : st.chi01;

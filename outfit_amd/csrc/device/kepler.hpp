@@ -480,9 +480,12 @@ struct KeplerSolution {
 __device__ __forceinline__ KeplerSolution run_newton(const KeplerProblem& p, double psi, fdiv::Guard* guard = nullptr) {
   const double sqrt_mu = sqrt(kMu);
   const double res_tol = 10.0 * kEps * (1.0 + fabs(sqrt_mu * p.dt));
+  // Every exit of the reference's loop returns the CURRENT psi with the Stumpff values computed LAST (the residual exit:
+  // this round's; the absolute-step exit, quirk Q3: the new psi with this round's values; the relative-step exit: the
+  // new psi and values recomputed at it), so the loop's own variables are the result — no copies into a second set of
+  // registers at every exit (round 5: 14 v_mov_b64 per round in the compiled loop).
   KeplerSolution out;
   out.ok = false;
-  out.psi = psi;
   out.s = {1.0, 0.0, 0.0, 0.0};
   for (int it = 0; it < 50; ++it) {
     KSTAT(0);
@@ -490,10 +493,10 @@ __device__ __forceinline__ KeplerSolution run_newton(const KeplerProblem& p, dou
     out.rounds = it + 1;
 #endif
     if (!isfinite(psi)) { psi = 0.5; continue; }
-    const Stumpff s = s_funct(psi, p.alpha, guard);
-    const double residual = p.r0 * s.s1 + p.sig0 * s.s2 + s.s3 - sqrt_mu * p.dt;
-    const double derivative = p.r0 * s.s0 + p.sig0 * s.s1 + s.s2;
-    if (fabs(residual) <= res_tol) { out.psi = psi; out.s = s; out.ok = true; break; }
+    out.s = s_funct(psi, p.alpha, guard);
+    const double residual = p.r0 * out.s.s1 + p.sig0 * out.s.s2 + out.s.s3 - sqrt_mu * p.dt;
+    const double derivative = p.r0 * out.s.s0 + p.sig0 * out.s.s1 + out.s.s2;
+    if (fabs(residual) <= res_tol) { out.ok = true; break; }
     if (!isfinite(derivative) || fabs(derivative) < 10.0 * kEps) { psi *= 0.5; continue; }
     const double mx = 2.0 * (1.0 + fabs(psi));
     const double step = clamp_symmetric(-residual / derivative, mx);
@@ -501,13 +504,14 @@ __device__ __forceinline__ KeplerSolution run_newton(const KeplerProblem& p, dou
     psi = (cand * psi < 0.0) ? 0.5 * psi : cand;
     const double sa = fabs(step);
     if (sa <= p.convergency) {  // quirk Q3: new psi with the previous Stumpff values
-      out.psi = psi; out.s = s; out.ok = true; break;
+      out.ok = true; break;
     }
     if (sa <= p.convergency * (1.0 + fabs(psi))) {
       KSTAT(2);
-      out.psi = psi; out.s = s_funct(psi, p.alpha, guard); out.ok = true; break;
+      out.s = s_funct(psi, p.alpha, guard); out.ok = true; break;
     }
   }
+  out.psi = psi;
   return out;
 }
 
