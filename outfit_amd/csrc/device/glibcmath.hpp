@@ -105,9 +105,33 @@ __device__ __forceinline__ double cos(double x) {
 }
 // x.sin() and x.cos() of one operand = ONE sincos() call of the platform libm (see sin1 / cos1 below): these two are
 // its restatement, bit for bit
+// sincos(x) = (sin(x), cos(x)) of the two functions above — written WITHOUT their range branches (round 5). In each
+// range a call evaluates do_sin once and do_cos once, on range-specific arguments:
+//   |x| < 0.855..   sin = do_sin(x, 0)                          cos = do_cos(x, 0)
+//   |x| < 2.426..   sin = copysign(do_cos(hp0 - |x|, hp1), x)   cos = do_sin(a', da'), a' = (hp0 - |x|) + hp1, da' = ((hp0 - |x|) - a') + hp1
+//   |x| < 1.05e8    (a, da, n) = reduce_sincos(x):  sin = do_sincos(a, da, n), cos = do_sincos(a, da, n + 1)
+// so the arguments are SELECTED per lane and the two kernels evaluated once for the whole wave. Every lane performs
+// exactly the operations of its own range on the same operands — the same bits as sin(x), cos(x) above — but a wave
+// whose lanes fall into all three ranges (any wave of angles spread over [0, 2 pi): 14 / 25 / 61 %) issues ~120
+// instructions instead of the ~260 of the branches executed one after the other. Huge arguments keep their branch.
 __device__ __forceinline__ void sincos(double x, double& s, double& c) {
-  s = sin(x);
-  c = cos(x);
+  const unsigned k = (unsigned)__double2hiint(x) & 0x7fffffffu;
+  if (k >= 0x419921FBu) { s = ::sin(x); c = ::cos(x); return; }
+  const double ax = fabs(x);
+  double a, da;
+  const int n = reduce_sincos(x, a, da);
+  const double y = kHp0 - ax, ac = y + kHp1, dac = (y - ac) + kHp1;
+  const bool in_b = k < 0x3feb6000u, in_c = !in_b && k < 0x400368fdu;
+  const double ts = in_b ? x : (in_c ? ac : a), dts = in_b ? 0.0 : (in_c ? dac : da);
+  const double tc = in_b ? x : (in_c ? y : a), dtc = in_b ? 0.0 : (in_c ? kHp1 : da);
+  const double vs = do_sin(ts, dts), vc = do_cos(tc, dtc);
+  // the reduced ranges: n for the sine, n + 1 for the cosine (do_sincos)
+  const double rs = (n & 1) ? vc : vs, rc = ((n + 1) & 1) ? vc : vs;
+  const double ds = (n & 2) ? -rs : rs, dc = ((n + 1) & 2) ? -rc : rc;
+  s = in_b ? vs : (in_c ? copysign(vc, x) : ds);
+  c = in_b ? vc : (in_c ? vs : dc);
+  if (k < 0x3e500000u) s = x;
+  if (k < 0x3e400000u) c = 1.0;
 }
 
 // ---- sin / cos as the STANDALONE libm entry points return them (round 3) -------------------------------------
