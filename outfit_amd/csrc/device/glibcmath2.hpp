@@ -79,64 +79,46 @@ __device__ __forceinline__ double atan2(double y, double x) {
   if (ax < 0x1p-500 || ay < 0x1p-500) { ax *= 0x1p500; ay *= 0x1p500; }
   if (ax > 0x1p500 || ay > 0x1p500) { ax *= 0x1p-500; ay *= 0x1p-500; }
 
-  double u, du;
-  if (ay < ax) {
-    u = ay / ax;
-    const double v = ax * u, vv = fma(ax, u, -v);
-    du = ((ay - v) - vv) / ax;
-  } else {
-    u = ax / ay;
-    const double v = ay * u, vv = fma(ay, u, -v);
-    du = ((ax - v) - vv) / ay;
-  }
+  // Round 5: the quotient and the four quadrant cases WITHOUT their branches. glibc's code is eight straight-line
+  // tails — (x > 0 | x <= 0) x (|y| < |x| | not) x (u < 1/16: polynomial | table) — and a wave of directions spread over
+  // the circle used to run all of them one after the other. Operands and signs are selected per lane instead: the
+  // quotient is lo / hi for lo, hi = the smaller and the larger magnitude (the two branches were the same
+  // operations with the roles swapped); the three cases other than (x > 0, |y| < |x|) differ only in the constant
+  // (pi/2 or pi) and in signs, and A - B is A + (-B) exactly; the table tails share their argument v and the inner
+  // polynomial. What remains are two tails (polynomial | table) with a select on the case inside. Every lane performs
+  // the operations of its own case on the same operands: the same bits
+  // (tests/test_device_math_host.py, tests/test_glibcmath2.py).
+  const bool y_lt = ay < ax;
+  const double lo = y_lt ? ay : ax, hi = y_lt ? ax : ay;
+  const double u = lo / hi;
+  const double q0 = hi * u, q1 = fma(hi, u, -q0);
+  const double du = ((lo - q0) - q1) / hi;
+  const bool x_pos = x > 0.0;
+  const bool case1 = x_pos && y_lt;                // z = atan(u)
+  const bool case3 = !x_pos && ax < ay;            // z = pi/2 + atan(u); cases 2 and 4: pi/2 - atan(u), pi - atan(u)
+  const bool case4 = !x_pos && !case3;
+  const double K = case4 ? kOpi : kHpi, K1 = case4 ? kOpi1 : kHpi1;
   double z;
-  if (x > 0.0) {
-    if (ay < ax) {
-      if (u < 0.0625) {
-        const double v = u * u;
-        z = u + fma(u * v, atan_poly(v), du);
-      } else {
-        const double* c = kCij[cij_index(u)];
-        const double t3 = u - c[0], v = t3 + du;
-        const double dv = fabs(t3) > fabs(du) ? (t3 - v) + du : (du - v) + t3;
-        const double c2 = c[2];
-        const double p = fma(fma(fma(c[6], v, c[5]), v, c[4]), v, c[3]);
-        z = fma(v, c2, fma(dv, c2, (v * v) * p)) + c[1];
-      }
-    } else {
-      if (u < 0.0625) {
-        const double v = u * u, zz = (u * v) * atan_poly(v);
-        const double t2 = kHpi - u;
-        const double cor = kHpi > fabs(u) ? (kHpi - t2) - u : kHpi - (u + t2);
-        z = (((cor + kHpi1) - du) - zz) + t2;
-      } else {
-        const double* c = kCij[cij_index(u)];
-        const double v = (u - c[0]) + du;
-        z = (kHpi - c[1]) + fma(-cij_poly(c, v), v, kHpi1);
-      }
-    }
-  } else if (ax < ay) {
-    if (u < 0.0625) {
-      const double v = u * u, zz = (v * u) * atan_poly(v);
-      const double t2 = u + kHpi;
-      const double cor = kHpi > fabs(u) ? (kHpi - t2) + u : (u - t2) + kHpi;
-      z = (((cor + kHpi1) + du) + zz) + t2;
-    } else {
-      const double* c = kCij[cij_index(u)];
-      const double v = (u - c[0]) + du;
-      z = (kHpi + c[1]) + fma(cij_poly(c, v), v, kHpi1);
-    }
+  if (u < 0.0625) {
+    const double v = u * u, p = atan_poly(v), uv = u * v;
+    const double z1 = u + fma(uv, p, du);
+    const double zz = uv * p;
+    const double su = case3 ? u : -u, sdu = case3 ? du : -du, szz = case3 ? zz : -zz;
+    const double t2 = K + su;                      // K > |u| here (u < 1/16): always the first arm of glibc's `cor`
+    const double cor = (K - t2) + su;
+    const double zo = (((cor + K1) + sdu) + szz) + t2;
+    z = case1 ? z1 : zo;
   } else {
-    if (u < 0.0625) {
-      const double v = u * u, zz = (v * u) * atan_poly(v);
-      const double t2 = kOpi - u;
-      const double cor = kOpi > fabs(u) ? (kOpi - t2) - u : kOpi - (t2 + u);
-      z = (((cor + kOpi1) - du) - zz) + t2;
-    } else {
-      const double* c = kCij[cij_index(u)];
-      const double v = (u - c[0]) + du;
-      z = (kOpi - c[1]) + fma(-cij_poly(c, v), v, kOpi1);
-    }
+    const double* c = kCij[cij_index(u)];
+    const double t3 = u - c[0], v = t3 + du;
+    const double c1 = c[1], c2 = c[2];
+    const double p = fma(fma(fma(c[6], v, c[5]), v, c[4]), v, c[3]);
+    const double dv = fabs(t3) > fabs(du) ? (t3 - v) + du : (du - v) + t3;
+    const double z1 = fma(v, c2, fma(dv, c2, (v * v) * p)) + c1;
+    const double P = fma(p, v, c2);                // cij_poly(c, v)
+    const double sc1 = case3 ? c1 : -c1, sP = case3 ? P : -P;
+    const double zo = (K + sc1) + fma(sP, v, K1);
+    z = case1 ? z1 : zo;
   }
   return copysign(z, y);
 }
