@@ -76,6 +76,60 @@ def test_restated_glibc_functions_device_equals_oracle(D):
         assert same_bits(out, ref).all(), name
 
 
+def test_branch_free_sincos_and_atan2_at_the_switching_points_of_glibcs_branches(D):
+    """Round 5: glm::sincos and glm::atan2 select the operands of glibc's range / quadrant branches per lane instead of
+    branching (glibcmath.hpp, glibcmath2.hpp). The oracle keeps glibc's literal branches: same bits at and around every
+    switching point — the |x| limits of sin / cos (2^-26, 2^-27, 0.855469, 2.426265, 105414350), |y| = |x|, the
+    u = 1/16 limit between polynomial and table in all four quadrants, zeros, infinities, NaN."""
+    import math
+    L = O.lib()
+
+    def around(v, k=6):
+        out = [v]
+        lo = hi = v
+        for _ in range(k):
+            lo, hi = math.nextafter(lo, -math.inf), math.nextafter(hi, math.inf)
+            out += [lo, hi]
+        return out
+
+    def from_hi_word(w):
+        return np.array([np.uint64(w) << np.uint64(32)], dtype=np.uint64).view(np.float64)[0]
+
+    xs = []
+    for w in (0x3e400000, 0x3e500000, 0x3feb6000, 0x400368fd, 0x419921FB):
+        for v in around(float(from_hi_word(w))):
+            xs += [v, -v]
+    xs += [0.0, -0.0, 0.126, -0.126, math.pi / 2, math.pi, 3 * math.pi / 2, 2 * math.pi, 1e5, -1e5, 1e8, -1e8, 5e-324]
+    xs += list(np.random.default_rng(3).uniform(-7, 7, 20000))
+    x = np.ascontiguousarray(xs)
+    for name, fn in (("orc_glibc_sin", 2), ("orc_glibc_cos", 3)):
+        out = np.empty_like(x)
+        D.glm_eval(C.c_int(fn), C.c_uint64(x.size), _p(x), _p(x), _p(out))
+        f = scalar(L, name)
+        ref = np.array([f(float(v)) for v in x])
+        assert same_bits(out, ref).all(), (name, x[~same_bits(out, ref)][:5])
+    ys, xq = [], []
+    rng = np.random.default_rng(4)
+    for base in (1.0, 3.7e-5, 8.1e11):
+        for r in around(0.0625, 8) + around(1.0, 8) + [0.03, 0.0624, 0.0626, 0.5, 0.999, 1.001, 2.0, 16.0, 15.999, 16.001, 1e3]:
+            for sy in (1.0, -1.0):
+                for sx in (1.0, -1.0):
+                    ys.append(sy * base * r); xq.append(sx * base)        # |y| / |x| = r
+                    ys.append(sy * base); xq.append(sx * base * r)        # |x| / |y| = r
+    for a in (0.0, -0.0, math.inf, -math.inf, math.nan, 1e-310, 1e300, 1.0):
+        for b in (0.0, -0.0, math.inf, -math.inf, math.nan, 1e-310, 1e300, -1.0):
+            ys.append(a); xq.append(b)
+    ys += list(rng.normal(size=20000) * 10.0 ** rng.uniform(-2, 2, 20000))
+    xq += list(rng.normal(size=20000) * 10.0 ** rng.uniform(-2, 2, 20000))
+    y, x = np.ascontiguousarray(ys), np.ascontiguousarray(xq)
+    out = np.empty_like(x)
+    D.glm_eval(C.c_int(5), C.c_uint64(x.size), _p(y), _p(x), _p(out))
+    f = scalar(L, "orc_glibc_atan2", 2)
+    ref = np.array([f(float(a), float(b)) for a, b in zip(y, x)])
+    bad = ~(same_bits(out, ref) | (np.isnan(out) & np.isnan(ref)))
+    assert not bad.any(), (y[bad][:5], x[bad][:5], out[bad][:5], ref[bad][:5])
+
+
 def test_correctly_rounded_functions_device_equals_oracle(D):
     """crmath.hpp (double-double fast paths + full evaluations) == the oracle's correctly-rounded mode (its own
     double-double sin / cos / acos, binary128 for the rest)."""
