@@ -23,14 +23,13 @@ instruction = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU (both in quad-cycles),
 kernel                            SQ_INSTS_VALU  SQ_ACTIVE_INST_VALU  SQ_THREAD_CYCLES_VALU  lanes / instruction
 """ + "\n".join(lines) + f"""
 ```
-Throughput kernels as in round 3 (K2b 47.0, K2a 57.2, K2c 55.6): round 4 changed no control flow in them (K2a's instruction
-count fell 1.8 % with the shared cold start of the two solves). The review's target for K2b (>= 56) is not met; DESIGN.md §9
-(round 4) says what the measured round histogram, the rank-major experiment (34.6 lanes per round pass) and the homogeneity
-probe (3 % to gain for K2b, 12 % for K2a) leave to recover. The other workloads' figures (noise points, corrector
-configurations) are in profiles/{name}_rocprof_summary.md and, per kernel, in the bench line's
+Where the idle lanes are is measured from inside per kernel (stats builds): K2b's solves converge per lane and the wave
+waits for its slowest (HISTORY.md section 3, profiles/round05_k2b_isa_account.md); `k_diffcor` and K3b lost theirs in the
+range branches of glibc's sincos / atan2 until round 5 selected the operands per lane (37.7 -> 45.7 and 28.9 -> 39.0
+lanes; profiles/round05_diffcor_phase_lanes.log). The other workloads' figures (noise points, corrector configurations,
+long arcs) are in profiles/{name}_rocprof_summary.md and, per kernel, in the bench detail file's
 `roofline.per_kernel[].lanes_per_instruction`. What an instruction costs to issue (4 cycles; TRANS 16) is measured in
-profiles/round04_issue_cost_gfx950.json; with it the three kernels sit at 0.85 - 0.93 of the cycles their SIMDs can issue in
-at the measured clock (`roofline.per_kernel[].issue_cycle_frac_at_measured_clock`).
+profiles/round04_issue_cost_gfx950.json.
 """
 open(os.path.join(ROOT, "profiles", f"{name}_lane_utilisation.md"), "w").write(txt)
 print(txt)
