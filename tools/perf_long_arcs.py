@@ -5,6 +5,10 @@ import os, subprocess, sys
 code = r'''
 import sys, hashlib, time
 sys.path[:0] = [sys.argv[1]]
+import os
+if os.environ.get("OUTFIT_PERF_LIB"):          # measurement aid: load another build of the library
+    import outfit_amd._lib as _L
+    _L.LIB_PATH = os.environ["OUTFIT_PERF_LIB"]
 import outfit_amd
 from outfit_amd import synth
 n, n_obs = int(sys.argv[2]), int(sys.argv[3])
