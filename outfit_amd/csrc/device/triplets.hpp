@@ -324,6 +324,111 @@ __device__ __forceinline__ unsigned long long lane_value(unsigned long long x, i
 #endif
 }
 
+// BinaryHeap::pop() followed by push(new) on a FULL heap of K <= kWaveReplaceMaxK slots, by the whole wave: every lane
+// calls it with the same arguments; returns the new top weight. The array after the call is the array the literal
+// sequence (heap_pop + heap_sift_up above, lane 0 walking 5.7 + 3.7 levels with an LDS round trip each at K = 100)
+// leaves — tests/test_k0_wave_heap_model.py holds this formulation against the literal one operation by operation on
+// streams full of equal weights, tests/test_gpu_long_arcs.py the kernel against the oracle:
+//   1. lane p looks at node p: the larger of its children below `end` (ties: the right one, heap_pop's `wl <= wr`) and
+//      that child's element — the choice sift_down_to_bottom makes IF it comes through p;
+//   2. the path from the root is then a chase through the lanes' choices (v_readlane with a scalar index per level, on
+//      the scalar unit), ending in the hole at the bottom;
+//   3. sift_up of the former last element from the hole: the path's nodes hold their chosen child's element after the
+//      shift, the element climbs past every node it is greater than — one ballot finds the deepest node that holds it
+//      back; the nodes above take their child's element in ONE masked store, the element goes below that node;
+//   4. push (heap_push_wave): the ancestors of the last slot are a fixed chain; lane i reads the i-th, one ballot finds
+//      where the new element stops, one store shifts the others down.
+// Three LDS round trips and ~80 instructions (half of them scalar) instead of ~9.4 round trips and ~140 one-lane
+// vector instructions.
+constexpr unsigned kWaveReplaceMaxK = 128;  // internal nodes of the heap <= 64: one per lane
+#ifndef OUTFIT_K0_WAVE_REPLACE
+#define OUTFIT_K0_WAVE_REPLACE 1   // 0: lane 0 walks the levels (the literal sequence; measurement aid)
+#endif
+constexpr bool kWaveReplace = OUTFIT_K0_WAVE_REPLACE != 0;
+__device__ __forceinline__ void wave_lds_order() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // LDS instructions of one wave execute in order; this only keeps the COMPILER from moving a lane's loads across the
+  // other lanes' stores (no s_waitcnt, no s_barrier)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+// BinaryHeap::push(new) into slot `slot` (= the heap's length before the push) by the whole wave: sift_up(0, slot, new)
+// along the slot's ancestors A_i = ((slot + 1) >> i) - 1, A_0 = slot, A_m = 0 — lane i reads the i-th, one ballot finds
+// the first that holds the element back (`if (ew <= wp) break`), one store shifts the ones below it down a level.
+// Returns the new top weight (wave-uniform). Any slot < 2^31.
+__device__ __forceinline__ double heap_push_wave(const WaveHeap& h, unsigned slot, double nw, unsigned long long ni,
+                                                 unsigned lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double2 fresh = {nw, __longlong_as_double((long long)ni)};
+  const unsigned m = 31u - (unsigned)__clz((int)(slot + 1u));
+  const bool anc = lane >= 1u && lane <= m;
+  const double2 a = h.e[anc ? ((slot + 1u) >> lane) - 1u : 0u];
+  const unsigned long long halt = __ballot(anc && wt_le(nw, a.x));
+  const unsigned s = halt ? (unsigned)__ffsll((long long)halt) - 1u : m + 1u;
+  if (lane >= 1u && lane < s) h.e[((slot + 1u) >> (lane - 1u)) - 1u] = a;
+  if (lane == 0u) h.e[((slot + 1u) >> (s - 1u)) - 1u] = fresh;
+  wave_lds_order();
+  const double top = h.e[0].x;
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(top)),
+                          __builtin_amdgcn_readfirstlane(__double2loint(top)));
+#else
+  (void)h; (void)slot; (void)ni; (void)lane;
+  return nw;
+#endif
+}
+__device__ __forceinline__ double heap_replace_wave(const WaveHeap& h, unsigned K, double nw, unsigned long long ni,
+                                                    unsigned lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned end = K - 1u;  // the heap's length after pop's --len; slot `end` holds the element pop moves
+  const double2 fresh = {nw, __longlong_as_double((long long)ni)};
+  if (end == 0u) {  // K == 1: pop empties the heap, push refills slot 0
+    if (lane == 0u) h.e[0] = fresh;
+    wave_lds_order();
+    return nw;
+  }
+  const double2 last = h.e[end];
+  // 1. this lane's node
+  const unsigned c1 = 2u * lane + 1u, c2 = c1 + 1u;
+  const bool has2 = c2 < end;
+  const double2 L = h.e[c1 < end ? c1 : 0u];
+  const double2 R = h.e[has2 ? c2 : 0u];
+  const bool right = has2 && wt_le(L.x, R.x);
+  const unsigned nxt = right ? c2 : c1;
+  const double2 cv = right ? R : L;
+  // 2. the path (wave-uniform: scalar registers)
+  unsigned pos = 0u;
+  unsigned long long path = 0ull;
+  while (2u * pos + 2u < end) {  // heap_pop: `child <= end - 2` with child = 2 pos + 1
+    path |= 1ull << pos;
+    pos = (unsigned)__builtin_amdgcn_readlane((int)nxt, (int)pos);
+  }
+  if (2u * pos + 1u == end - 1u) {  // a single child at the very end moves up too
+    path |= 1ull << pos;
+    pos = 2u * pos + 1u;
+  }
+  // 3. sift_up(0, hole, last): `if (ew <= wp) break` from the bottom — the deepest path node that holds it back
+  const bool on_path = (path >> lane) & 1ull;
+  const unsigned long long stop = __ballot(on_path && wt_le(last.x, cv.x));
+  unsigned dest = 0u;
+  unsigned long long shift = 0ull;
+  if (stop) {
+    const int j = 63 - __clzll((long long)stop);
+    dest = (unsigned)__builtin_amdgcn_readlane((int)nxt, j);
+    shift = path & ((2ull << j) - 1ull);
+  }
+  if ((shift >> lane) & 1ull) h.e[lane] = cv;
+  if (lane == 0u) h.e[dest] = last;
+  wave_lds_order();
+  // 4. push
+  return heap_push_wave(h, end, nw, ni, lane);
+#else
+  (void)h; (void)K; (void)ni; (void)lane;
+  return nw;
+#endif
+}
+
 __device__ __forceinline__ unsigned select_triplets_wave(const double* mjd /* this trajectory */, unsigned long long n_obs64,
                                                          const TripletParams& P, double* ep /* LDS [n] */,
                                                          const WaveHeap& h, unsigned long long* out) {
@@ -349,16 +454,25 @@ __device__ __forceinline__ unsigned select_triplets_wave(const double* mjd /* th
       const unsigned long long il = lane_value(id, l);
       K0STAT(5, 1);
       if (len < P.k_cap) {
+        K0STAT(6, 1);
+        if (kWaveReplace) {
+          root_w = heap_push_wave(h, len, wl, il, lane);
+          ++len;
+          continue;
+        }
         if (lane == 0) heap_sift_up(h, 0, len, wl, il);
         ++len;
-        K0STAT(6, 1);
       } else if (wl < root_w) {
+        K0STAT(7, 1);
+        if (kWaveReplace && P.k_cap <= kWaveReplaceMaxK) {  // the whole wave, three LDS round trips (heap_replace_wave)
+          root_w = heap_replace_wave(h, P.k_cap, wl, il, lane);
+          continue;
+        }
         if (lane == 0) {
           unsigned ll = len;
           heap_pop(h, ll);
           heap_sift_up(h, 0, ll, wl, il);
         }
-        K0STAT(7, 1);
       } else {
         K0STAT(8, 1);
         continue;  // the top has dropped below this candidate since the ballot

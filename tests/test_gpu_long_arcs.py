@@ -87,7 +87,11 @@ def _ragged(ephem_d):
 CASES = [
     ("bench cadence: equal weights at the K-th place", lambda e: outfit_amd.ObsBatch.from_dict(synth.make_dataset(1500, seed=11, ephem=e)),
      [synth.bench_params(outfit_amd.IODParams()), outfit_amd.IODParams(n_noise_realizations=0),
-      outfit_amd.IODParams(n_noise_realizations=0, max_triplets=1), outfit_amd.IODParams(n_noise_realizations=0, max_triplets=700)]),
+      outfit_amd.IODParams(n_noise_realizations=0, max_triplets=1), outfit_amd.IODParams(n_noise_realizations=0, max_triplets=700),
+      # the wave-wide pop + push of the wave form (triplets.hpp heap_replace_wave): the smallest heaps, and both sides of
+      # its limit of 128 slots (beyond it lane 0 walks the levels)
+      outfit_amd.IODParams(n_noise_realizations=0, max_triplets=2), outfit_amd.IODParams(n_noise_realizations=0, max_triplets=3),
+      outfit_amd.IODParams(n_noise_realizations=0, max_triplets=128), outfit_amd.IODParams(n_noise_realizations=0, max_triplets=129)]),
     ("ragged and degenerate", _ragged,
      [synth.bench_params(outfit_amd.IODParams()),
       outfit_amd.IODParams(n_noise_realizations=0, max_obs_for_triplets=12, max_triplets=30),
