@@ -1,10 +1,11 @@
 """GPU box: the device in OUTFIT_MATH_GLIBC mode against the oracle in platform-libm mode (= the reference's
 arithmetic on this host's glibc) on a LARGE batch — statistics for DESIGN.md §4.0. Also the default mode against the
 same, and the glibc mode against the oracle's restated mode (must be bit-identical).
-usage: parity_glibc_at_scale.py [n_objects] [seed] [bench|topo|noise|long100|long300]  -> gpurun_out/parity_glibc_<mode>_<n>.json
+usage: parity_glibc_at_scale.py [n_objects] [seed] [bench|topo|noise|long100|long300|long100k100|long300k100]  -> gpurun_out/parity_glibc_<mode>_<n>.json
 (noise: IODParams::default() — 10 triplets x 21 realisations, host-drawn normals, SURVEY 8(d)'s second point;
 long100 / long300: trajectories of 100 / 300 observations (synth.make_long_arc_dataset) under IODParams::default() with
-noise — the wave-per-trajectory K0, down-sampling and quirk Q1, RMS windows over the whole arc)"""
+noise — the wave-per-trajectory K0, down-sampling and quirk Q1, RMS windows over the whole arc; long<N>k100: the same
+trajectories with max_triplets = 100 and no noise — K0's heap of 100 with ~1 300 replacements per trajectory)"""
 import ctypes as C
 import json
 import os
@@ -23,15 +24,17 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 20261005
 mode = sys.argv[3] if len(sys.argv) > 3 else "bench"
 threads = len(os.sched_getaffinity(0))
+k100 = mode.endswith("k100")
 if mode.startswith("long"):
-    ds = synth.make_long_arc_dataset(n, int(mode[4:]), seed=seed)
+    ds = synth.make_long_arc_dataset(n, int(mode[4:-4] if k100 else mode[4:]), seed=seed)
     ed = ds["ephem"]
 else:
     ed = synth.make_ephemeris()
     ds = synth.make_dataset(n, seed=seed, ephem=ed, topocentric=(mode == "topo"))
 batch, ephem = outfit_amd.ObsBatch.from_dict(ds), outfit_amd.Ephemeris.from_dict(ed)
-noisy = mode == "noise" or mode.startswith("long")
-params = outfit_amd.IODParams() if noisy else synth.bench_params(outfit_amd.IODParams())
+noisy = (mode == "noise" or mode.startswith("long")) and not k100
+params = outfit_amd.IODParams() if noisy else \
+    outfit_amd.IODParams(n_noise_realizations=0, max_triplets=100) if k100 else synth.bench_params(outfit_amd.IODParams())
 per_traj = params.max_triplets * params.n_noise_realizations * 6
 if noisy:
     batch.noise_z = np.random.default_rng(seed).standard_normal(n * per_traj)
