@@ -60,6 +60,9 @@ __device__ __forceinline__ double screen_slack_rad(unsigned level) {
 }
 
 // false = Err(RootFindingError), decided by the reference's own iteration
+// kLazyStart: the frame comes from screen_prologue (below), which leaves the Newton start of the reference's iteration
+// (varpi, pi + varpi and its sine / cosine: an atan2 and a sincos) to the rare call that needs it
+template <bool kLazyStart = false>
 __device__ __forceinline__ bool screen_kepler(const Equinoctial& q, const TwoBodyFrame& F, double dt, ScreenKepler& S,
                                               const SinCosConsts& K, const ScreenConsts& C) {
   const double lamu = fma(F.n, dt, q.lambda);
@@ -95,14 +98,95 @@ __device__ __forceinline__ bool screen_kepler(const Equinoctial& q, const TwoBod
   }
   if (full) {
     double lam = principal_angle_fast(lamu);
-    if (lam < F.varpi) lam += kTwoPi;
-    if (!solve_kepler_equation<kFnPlatform>(q, F, lam, S.x, S.sx, S.cx, &K)) return false;
+    if constexpr (kLazyStart) {
+      TwoBodyFrame Fs = F;  // (only the four start fields differ; the rest is not read by the solver)
+      Fs.varpi = 0.0;
+      if (F.e2 > kEps * 1e2) Fs.varpi = principal_angle(atan2_screen(q.h, q.k, C));
+      Fs.x0 = kPi + Fs.varpi;
+      sincos_k(Fs.x0, K, Fs.sx0, Fs.cx0);
+      if (lam < Fs.varpi) lam += kTwoPi;
+      if (!solve_kepler_equation<kFnPlatform>(q, Fs, lam, S.x, S.sx, S.cx, &K)) return false;
+    } else {
+      if (lam < F.varpi) lam += kTwoPi;
+      if (!solve_kepler_equation<kFnPlatform>(q, F, lam, S.x, S.sx, S.cx, &K)) return false;
+    }
     S.dmin = fmin(S.dmin, fma(-q.h, S.sx, fma(-q.k, S.cx, 1.0)));
     S.lam = lam;
     S.off = lam - lamu;
     S.warm = true;
   }
   return true;
+}
+
+// ---- candidate -> equinoctial elements for the SCREEN, straight from the state vector ---------------------------------
+// The reference goes state -> Keplerian elements -> equinoctial elements through the angles (ccek1 orb_elem.rs:58-226,
+// from_kepler equinoctial_element.rs:285-313, then the frame of propagate_twobody): five atan2, six sincos, a tan,
+// eight square roots and fifteen divisions per candidate — 0.55 of K2c's 2.7 ms (measured with a one-observation loop).
+// The exact evaluation (K3b, and this kernel's other modes) has to follow that route rounding by rounding; the screen
+// only needs elements that describe the same orbit to ~1e-15, and the equinoctial set is a rational function of the
+// state: W = r x v / |r x v|, p = Wx / (1 + Wz), q = -Wy / (1 + Wz), f and g from (p, q), (k, h) = the eccentricity
+// vector ((v^2 - mu/r) r - (r.v) v) / mu in that frame, 1/a = 2/r - v^2/mu, and the eccentric longitude F AT THE EPOCH from
+// the position in the frame — the 2 x 2 system xe = a (one_bh2 cos F + bet sin F - k), ye = a (one_bk2 sin F + bet cos F - h)
+// has determinant sqrt(1 - e^2) — one atan2 in all. lambda = F - k sin F + h cos F needs no wrap, and (F, sin F, cos F)
+// is a solved Kepler equation: the loop starts WARM from the epoch (a candidate's first observation is ~10 d away:
+// a rotation by ~0.04 rad) instead of with the reference's iteration from pi + varpi.
+// What the conversion DECIDES must be what the reference's route decides (kind, conversion error, e >= 1): the direct
+// formulas are used where those decisions are far from their thresholds —
+//   kScreenElliptic    1/a > 1e-6 /AU, e^2 < 0.998, 1 + Wz > 1e-4: Keplerian, no conversion error, e < 1;
+//   kScreenHyperbolic  1/a < -1e-6, e^2 > 1 + 1e-6: Cometary with e > 1 (ccek1's third branch, |e - 1| far above 5e-15
+//                      and 1e-12), to_equinoctial succeeds, check_elliptical_orbit fails: flag + Err, no residuals;
+//   kScreenDivert      anything else (2 % of the bench candidates have e >= 0.9 or are hyperbolic; < 0.1 % land here),
+//                      non-finite input included: the candidate takes the reference's route in the slow-list pass.
+constexpr int kScreenElliptic = 0, kScreenHyperbolic = 1, kScreenDivert = 2;
+__device__ __forceinline__ int screen_prologue(const Vec3& pos, const Vec3& vel, double epoch, Equinoctial& q,
+                                               TwoBodyFrame& F, ScreenKepler& S, const ScreenConsts& C) {
+  constexpr double inv_mu = 1.0 / kMu;
+  const Vec3 hv = cross(pos, vel);
+  double hn, inv_hn, r, inv_r;
+  sqrt_rsqrt(dot(hv, hv), hn, inv_hn);
+  sqrt_rsqrt(dot(pos, pos), r, inv_r);
+  const double v2 = dot(vel, vel), rv = dot(pos, vel);
+  const double inv_a = fma(-v2, inv_mu, 2.0 * inv_r);
+  // eccentricity vector
+  const double c_r = fma(v2, inv_mu, -inv_r), c_v = -rv * inv_mu;
+  const Vec3 ev = {fma(c_r, pos.x, c_v * vel.x), fma(c_r, pos.y, c_v * vel.y), fma(c_r, pos.z, c_v * vel.z)};
+  const double e2v = dot(ev, ev);
+  const double wz1 = fma(hv.z, inv_hn, 1.0);  // 1 + Wz
+  if (inv_a < -1e-6 && e2v > 1.0 + 1e-6 && e2v < 1e300 && hn > 0.0) return kScreenHyperbolic;
+  if (!(inv_a > 1e-6 && inv_a < 1e6 && e2v < 0.998 && wz1 > 1e-4 && hn > 0.0)) return kScreenDivert;
+  const double d = rcp_nr2(wz1);
+  const double pp = (hv.x * inv_hn) * d, qq = -(hv.y * inv_hn) * d;
+  const double p2 = pp * pp, q2 = qq * qq;
+  const double inv_u = rcp_nr2(1.0 + p2 + q2);
+  const double cc = 2.0 * pp * qq * inv_u;
+  F.f = {(1.0 - p2 + q2) * inv_u, cc, -2.0 * pp * inv_u};
+  F.g = {cc, (1.0 + p2 - q2) * inv_u, 2.0 * qq * inv_u};
+  const double k = dot(ev, F.f), h = dot(ev, F.g);
+  const double a = rcp_nr2(inv_a);
+  F.e2 = fma(h, h, k * k);
+  double sq, inv_sq;
+  sqrt_rsqrt(1.0 - F.e2, sq, inv_sq);     // sqrt(1 - e^2) > 0.044
+  F.beta = rcp_nr2(1.0 + sq);
+  F.bet = F.beta * h * k;
+  F.one_bh2 = fma(-F.beta, h * h, 1.0);
+  F.one_bk2 = fma(-F.beta, k * k, 1.0);
+  double sa, inv_sa;
+  sqrt_rsqrt(inv_a, sa, inv_sa);
+  F.n = kGaussGrav * inv_a * sa;          // sqrt(mu / a^3)
+  // eccentric longitude at the epoch
+  const double xa = fma(dot(pos, F.f), inv_a, k), ya = fma(dot(pos, F.g), inv_a, h);
+  const double cf = fma(F.one_bk2, xa, -(F.bet * ya)) * inv_sq, sf = fma(F.one_bh2, ya, -(F.bet * xa)) * inv_sq;
+  const double x = atan2_screen(sf, cf, C);
+  q.epoch = epoch; q.a = a; q.h = h; q.k = k; q.p = pp; q.q = qq;
+  q.lambda = fma(h, cf, fma(-k, sf, x));  // the right-hand side (x, sf, cf) solves; no wrap needed (screen_kepler adds S.off)
+  F.varpi = F.x0 = F.sx0 = F.cx0 = 0.0;   // screen_kepler<true> evaluates them when it needs them
+  S.warm = true;
+  S.x = x; S.sx = sf; S.cx = cf;
+  S.lam = q.lambda;
+  S.off = 0.0;
+  S.dmin = fmin(1.0, fma(-h, sf, fma(-k, cf, 1.0)));
+  S.inv_rho_max = 0.0;
+  return kScreenElliptic;
 }
 
 // Candidate-constant part of the screen's residual: the orbital-plane axes in the equatorial frame.

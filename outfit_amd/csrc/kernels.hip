@@ -905,7 +905,14 @@ __device__ __forceinline__ void select_rms_interval(const double* mjd, unsigned 
 // concurrently by the general correction kernel); true handles exactly those.
 // kScreen: the residual loop in the screening arithmetic of device/screen.hpp (glibc-faithful mode: K3b re-evaluates
 // the contenders exactly); the prologue and the failure conditions stay those of the exact evaluation.
-template <bool kSlowList, int kFn, bool kScreen = false>
+// kRedo: an entry of the main pass's redo list, evaluated in the slow-list pass: the screening loop behind the
+// REFERENCE'S route from the state to the elements (the main pass takes screen.hpp's direct route where it may), and
+// the reference's expressions in place when the sum is not finite.
+constexpr unsigned long long kRedoScreenBit = 1ull << 63;
+#ifndef OUTFIT_SCREEN_DIRECT
+#define OUTFIT_SCREEN_DIRECT 1   // 0: the main pass converts through the angles too (measurement / verification aid)
+#endif
+template <bool kSlowList, int kFn, bool kScreen = false, bool kRedo = false>
 __device__ __forceinline__ void rms_candidate(const RmsArgs& a, unsigned long long cid) {
   const unsigned f0 = a.W.flags[cid];
   if ((f0 & kFlagEmpty) || !(f0 & kFlagOk)) return;
@@ -915,6 +922,57 @@ __device__ __forceinline__ void rms_candidate(const RmsArgs& a, unsigned long lo
   const Vec3 r2 = {a.W.state[0 * n + cid], a.W.state[1 * n + cid], a.W.state[2 * n + cid]};
   const Vec3 v2 = {a.W.state[3 * n + cid], a.W.state[4 * n + cid], a.W.state[5 * n + cid]};
   const double epoch = a.W.state[6 * n + cid];
+  if constexpr (kScreen && !kRedo && OUTFIT_SCREEN_DIRECT != 0) {
+    // the screen, both passes: elements straight from the state, the loop warm from the epoch (device/screen.hpp). A
+    // candidate the direct route does not classify, or whose sum is not finite, takes the reference's route: from the
+    // main pass through the redo list (evaluated by the slow-list pass, which keeps the second route out of the main
+    // pass's register budget), in the slow-list pass right below. The screened value of a candidate thus does not depend
+    // on which pass evaluates it (tests/test_gpu_small_batch.py hands candidates over and compares the scratch).
+    const ScreenConsts SCR = screen_consts();
+    Equinoctial eq;
+    TwoBodyFrame F;
+    ScreenKepler S;
+    const int cls = screen_prologue(equ_to_ecl(r2), equ_to_ecl(v2), epoch, eq, F, S, SCR);
+    bool fallback = cls == kScreenDivert;
+    if (!fallback) {
+      unsigned flags = f0 & (kFlagOk | kFlagCorrected | kFlagSlow);
+      unsigned long long i_start, i_end;
+      select_rms_interval(a.I.mjd + c.base, c.n_obs, c.idx[0], c.idx[2], a.extf, a.dtmax, i_start, i_end);
+      if (cls == kScreenHyperbolic) {  // Cometary, converted, e >= 1: check_elliptical_orbit's Err before any residual
+        a.W.n_win[cid] = (unsigned)(i_end - i_start + 1);
+        a.W.sum[cid] = 0.0;
+        a.W.flags[cid] = flags | kFlagCometary | kFlagRmsErr;
+        return;
+      }
+      const ScreenFrame G = screen_frame(eq, F);
+      double acc = 0.0;
+      bool err = false;
+      for (unsigned long long i = i_start; i <= i_end; ++i) {
+        const double2* rec = reinterpret_cast<const double2*>(a.obs_rec + (size_t)kObsRecDoubles * (c.base + i));
+        const double2 r01 = rec[0], r23 = rec[1], r45 = rec[2], r67 = rec[3];
+        if (!screen_kepler<true>(eq, F, r01.x - eq.epoch, S, a.sc, SCR)) {
+          err = true;
+          break;
+        }
+        const Vec3 op = {r45.y, r67.x, r67.y};
+        acc += screen_term(eq, F, G, S.sx, S.cx, r01.y, r23.x, r23.y, r45.x, op, SCR, S.inv_rho_max);
+      }
+      if (err || fabs(acc) < 1e300) {
+        a.W.n_win[cid] = (unsigned)(i_end - i_start + 1);
+        a.W.sum[cid] = acc;
+        a.W.flags[cid] = flags | (screen_level(eq.a, S.inv_rho_max, S.dmin) << kFlagLevelShift) | (err ? kFlagRmsErr : 0u);
+        return;
+      }
+      fallback = true;  // a non-finite sum: not what the shortcuts were made for
+    }
+    if (!kSlowList) {
+      // redo list entry: bit 63 = "not classified" (the screening loop behind the reference's route); clear = a
+      // non-finite sum (the reference's expressions right away, as the loop has already been tried)
+      const unsigned long long at = atomicAdd(a.W.slow_count + 1, 1ull);
+      a.W.slow_list[n - 1 - at] = cid | (cls == kScreenDivert ? kRedoScreenBit : 0ull);
+      return;
+    }
+  }
 
   // build_result -> compute_orbit_from_state -> ccek1 (gauss.rs:906-923,1063-1076)
   // kFn = kFnPlatform (correctly-rounded mode): these elements only feed the candidate's RMS, the selected candidate's
@@ -948,6 +1006,9 @@ __device__ __forceinline__ void rms_candidate(const RmsArgs& a, unsigned long lo
       S.warm = false;
       S.dmin = 1.0;
       S.inv_rho_max = 0.0;
+#ifdef OUTFIT_K2C_PROLOGUE_ONLY  // measurement aid: the loop sees one observation (what the conversion in front of it costs)
+      i_end = i_start;
+#endif
       for (unsigned long long i = i_start; i <= i_end; ++i) {
         // one 64-byte record per observation (kernels.h kObsRecDoubles): four 16-byte loads from one address
         const double2* rec = reinterpret_cast<const double2*>(a.obs_rec + (size_t)kObsRecDoubles * (c.base + i));
@@ -965,7 +1026,7 @@ __device__ __forceinline__ void rms_candidate(const RmsArgs& a, unsigned long lo
       // candidate is on one list at most), which keeps the second loop out of the main pass's register budget
       flags |= screen_level(eq.a, S.inv_rho_max, S.dmin) << kFlagLevelShift;
       if (!err && !(fabs(acc) < 1e300)) {
-        if (!kSlowList) {
+        if (!kSlowList && !kRedo) {
           const unsigned long long at = atomicAdd(a.W.slow_count + 1, 1ull);
           a.W.slow_list[n - 1 - at] = cid;
           return;
@@ -1003,16 +1064,21 @@ constexpr int kRmsExact = 0, kRmsGlibc = 1, kRmsScreen = 2;
 #ifndef OUTFIT_RMS_WAVES
 #define OUTFIT_RMS_WAVES 3
 #endif
+// (the slow-list pass — few lanes, three routes in one kernel, a chain of up to 30 k instructions — is compiled for two
+// waves per SIMD: 256 registers instead of 168 + spills)
 template <bool kSlowList, int kMode = kRmsExact>
-__global__ void __launch_bounds__(256, OUTFIT_RMS_WAVES)
+__global__ void __launch_bounds__(256, kSlowList ? 2 : OUTFIT_RMS_WAVES)
 k_orbit_rms(RmsArgs a) {
   constexpr int kFn = kMode == kRmsGlibc ? kFnGlibc : kFnPlatform;
   const unsigned long long lid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (kSlowList) {
     const unsigned long long n_slow = a.W.slow_count[0];
     if (lid < n_slow) rms_candidate<true, kFn, kMode == kRmsScreen>(a, a.W.slow_list[lid]);
-    else if (kMode == kRmsScreen && lid - n_slow < a.W.slow_count[1])  // the main pass's redo list
-      rms_candidate<false, kFn, false>(a, a.W.slow_list[a.I.n_cand - 1 - (lid - n_slow)]);
+    else if (kMode == kRmsScreen && lid - n_slow < a.W.slow_count[1]) {  // the main pass's redo list
+      const unsigned long long e = a.W.slow_list[a.I.n_cand - 1 - (lid - n_slow)];
+      if (e & kRedoScreenBit) rms_candidate<false, kFn, true, true>(a, e & ~kRedoScreenBit);
+      else rms_candidate<false, kFn, false>(a, e);
+    }
   } else if (lid < a.I.n_cand) {
     rms_candidate<false, kFn, kMode == kRmsScreen>(a, lid);
   }

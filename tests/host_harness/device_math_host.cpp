@@ -7,6 +7,7 @@
 #include "hip/hip_runtime.h"
 #include "device/gauss.hpp"
 #include "device/orbit.hpp"
+#include "device/screen.hpp"
 #include "device/diffcor.hpp"
 extern "C" {
 double g_seed_rel_error = 0.0;
@@ -172,6 +173,53 @@ void rms_chain_glibc(unsigned long long n, unsigned n_obs, const double* state, 
       const bool ok = ephemeris_error<kFnGlibc>(eq, F, b[0], b[1], b[2], glm::cos1(b[2]), b[3], b[4], {b[5], b[6], b[7]}, term);
       o[14 + 2 * j] = ok ? 1.0 : 0.0;
       o[15 + 2 * j] = ok ? term : 0.0;
+    }
+  }
+}
+// The screen's two routes from a state to the loop's inputs (device/screen.hpp): `direct` = screen_prologue, `angles` =
+// the reference's route in the screen's arithmetic (ccek1 / to_equinoctial / twobody_frame with kFnScreen), and the
+// per-observation squared residuals of each (screen_kepler + screen_term), the direct route warm from the epoch.
+// state: 7 per case (equatorial r, v, epoch); obs as in rms_chain_glibc (8 per observation; weights from sra / sdec);
+// out per case: cls, kind, conv, e>=1, then direct (a h k p q lambda n), angles (a h k p q lambda n), kepler residual of
+// the direct start, then n_obs x (ok_direct, term_direct, ok_angles, term_angles).
+void screen_routes(unsigned long long n, unsigned n_obs, const double* state, const double* obs, double* out) {
+  const unsigned stride = 4 + 7 + 7 + 1 + 4 * n_obs;
+  const ScreenConsts C = screen_consts();
+  const SinCosConsts K = sincos_consts();
+  for (unsigned long long i = 0; i < n; ++i) {
+    const double* s = state + 7 * i;
+    double* o = out + stride * i;
+    for (unsigned j = 0; j < stride; ++j) o[j] = 0.0;
+    const Vec3 pe = equ_to_ecl({s[0], s[1], s[2]}), ve = equ_to_ecl({s[3], s[4], s[5]});
+    Equinoctial qd{}, qa{};
+    TwoBodyFrame Fd{}, Fa{};
+    ScreenKepler Sd{}, Sa{};
+    const int cls = screen_prologue(pe, ve, s[6], qd, Fd, Sd, C);
+    const Elements el = ccek1<kFnScreen>(pe, ve, s[6]);
+    const int conv = to_equinoctial<kFnScreen>(el, qa);
+    o[0] = cls; o[1] = el.kind; o[2] = conv;
+    const bool hyper = conv == 0 && sqrt(qa.h * qa.h + qa.k * qa.k) >= 1.0;
+    o[3] = hyper ? 1.0 : 0.0;
+    if (conv == 0 && !hyper) {
+      Fa = twobody_frame<kFnScreen>(qa);
+      o[11] = qa.a; o[12] = qa.h; o[13] = qa.k; o[14] = qa.p; o[15] = qa.q; o[16] = qa.lambda; o[17] = Fa.n;
+    }
+    if (cls == kScreenElliptic) {
+      o[4] = qd.a; o[5] = qd.h; o[6] = qd.k; o[7] = qd.p; o[8] = qd.q; o[9] = qd.lambda; o[10] = Fd.n;
+      o[18] = Sd.x - qd.k * Sd.sx + qd.h * Sd.cx - qd.lambda;
+    }
+    if (cls != kScreenElliptic || conv != 0 || hyper) continue;
+    const ScreenFrame Gd = screen_frame(qd, Fd), Ga = screen_frame(qa, Fa);
+    Sa.warm = false; Sa.dmin = 1.0; Sa.inv_rho_max = 0.0;
+    bool okd = true, oka = true;
+    for (unsigned j = 0; j < n_obs; ++j) {
+      const double* b = obs + 8 * ((unsigned long long)n_obs * i + j);
+      const double w_ra = cos(b[2]) / b[3], w_dec = 1.0 / b[4];
+      double* t = o + 19 + 4 * j;
+      if (okd) okd = screen_kepler<true>(qd, Fd, b[0] - qd.epoch, Sd, K, C);
+      if (okd) { t[0] = 1.0; t[1] = screen_term(qd, Fd, Gd, Sd.sx, Sd.cx, b[1], b[2], w_ra, w_dec, {b[5], b[6], b[7]}, C, Sd.inv_rho_max); }
+      if (oka) oka = screen_kepler<false>(qa, Fa, b[0] - qa.epoch, Sa, K, C);
+      if (oka) { t[2] = 1.0; t[3] = screen_term(qa, Fa, Ga, Sa.sx, Sa.cx, b[1], b[2], w_ra, w_dec, {b[5], b[6], b[7]}, C, Sa.inv_rho_max); }
     }
   }
 }

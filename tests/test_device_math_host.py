@@ -594,3 +594,79 @@ def test_decisions_on_operands_equal_the_literal_expressions(D):
     with np.errstate(invalid="ignore"):
         inside = (np.abs(x) >= 2.0 ** -300) & (np.abs(x) < 2.0 ** 300)
     assert np.array_equal(ok.astype(bool), inside)             # and it passes everything in [2^-300, 2^300)
+
+
+def test_screen_direct_route_agrees_with_the_route_through_the_angles(D):
+    """K2c's main pass takes the equinoctial elements of a candidate straight from its state (device/screen.hpp
+    screen_prologue) where the reference's route through the Keplerian angles decides nothing near a threshold, and starts
+    the loop warm from the epoch. Held here against that route in the same screening arithmetic (what the slow-list pass
+    and the redo list still take): same classification wherever the direct route classifies at all, elements and mean
+    motion to 1e-13, the start (F, sin F, cos F) a solution of Kepler's equation, every observation's residual the same to
+    1e-7 of the normalised unit (7e-9 is what 1e-14 rad on the sky gives at 0.3") + 1e-9 of its size."""
+    from outfit_amd import synth
+    n_obs = 20
+    rng = np.random.default_rng(23)
+    ds = synth.make_dataset(400, seed=43)
+    truth = ds["truth"].copy()
+    pops = {"bench": truth.copy()}
+    hi = truth.copy(); hi[:, 1] = rng.uniform(0.6, 0.999, len(hi))
+    hi[::7, 1] = 1.0 - 10.0 ** rng.uniform(-7, -3.2, len(hi[::7]))   # e^2 >= 0.998: the direct route declines
+    pops["eccentric"] = hi
+    lo = truth.copy(); lo[:, 1] = 10.0 ** rng.uniform(-9, -3, len(lo)); pops["near circular"] = lo
+    eqt = truth.copy(); eqt[:, 2] = 10.0 ** rng.uniform(-12, -4, len(eqt)); pops["near equatorial"] = eqt
+    ret = truth.copy(); ret[:, 2] = np.pi - 10.0 ** rng.uniform(-6, -0.5, len(ret)); pops["retrograde"] = ret
+    L = O.lib()
+    total_elliptic = 0
+    for name, pop in pops.items():
+        n = len(pop)
+        state = np.empty((n, 7))
+        for i in range(n):
+            a, e, inc, node, argp, m0 = pop[i]
+            el = O.Elements(kind=0, epoch=60000.0, e=(C.c_double * 6)(a, e, inc, node, argp, m0))
+            eq = O.Equinoctial()
+            assert L.orc_to_equinoctial(C.byref(el), C.byref(eq)) == 0
+            r, v = O.D3(), O.D3()
+            t_mid = float(ds["mjd_tt"][n_obs * i + n_obs // 2])
+            assert L.orc_propagate_twobody(C.byref(eq), 60000.0, t_mid, r, v) == 0
+            c, s_ = 9.174820620691818e-1, 3.977771559319137e-1
+            rq = np.array([r[0], c * r[1] - s_ * r[2], s_ * r[1] + c * r[2]]) * (1 + 1e-4 * rng.normal(size=3))
+            vq = np.array([v[0], c * v[1] - s_ * v[2], s_ * v[1] + c * v[2]]) * (1 + 1e-4 * rng.normal(size=3))
+            if name == "eccentric" and i % 3 == 0 and i % 7 != 0:
+                vq *= rng.uniform(1.0, 1.6)     # towards and beyond the parabola: divert / hyperbolic
+            state[i] = [*rq, *vq, t_mid]
+        obs = np.empty((n, n_obs, 8))
+        for i in range(n):
+            sl = slice(n_obs * i, n_obs * (i + 1))
+            obs[i, :, 0] = ds["mjd_tt"][sl]; obs[i, :, 1] = ds["ra"][sl]; obs[i, :, 2] = ds["dec"][sl]
+            obs[i, :, 3] = ds["sigma_ra"][sl]; obs[i, :, 4] = ds["sigma_dec"][sl]
+            obs[i, :, 5:] = ds["obs_helio_equ"].reshape(-1, 3)[sl]
+        state, obs = np.ascontiguousarray(state), np.ascontiguousarray(obs)
+        stride = 19 + 4 * n_obs
+        out = np.empty(n * stride)
+        D.screen_routes(C.c_uint64(n), C.c_uint(n_obs), _p(state), _p(obs), _p(out))
+        out = out.reshape(n, stride)
+        cls, kind, conv, hyper = (out[:, k].astype(int) for k in range(4))
+        ell, hyp = cls == 0, cls == 1
+        assert (kind[ell] == 0).all() and (conv[ell] == 0).all() and (hyper[ell] == 0).all(), name
+        assert (kind[hyp] == 1).all() and (conv[hyp] == 0).all() and (hyper[hyp] == 1).all(), name
+        if name in ("bench", "near circular", "near equatorial"):
+            assert ell.all(), name
+        if name == "eccentric":
+            assert hyp.any() and (cls == 2).any() and ell.any()
+        d, a = out[ell, 4:11], out[ell, 11:18]
+        assert (np.abs(d[:, 0] - a[:, 0]) <= 1e-13 * a[:, 0]).all(), name                # a
+        assert (np.abs(d[:, 1:3] - a[:, 1:3]) <= 1e-13).all(), (name, np.abs(d[:, 1:3] - a[:, 1:3]).max())   # h, k
+        # p, q = tan(i/2) (sin, cos)(node): towards i = 180 deg both routes lose digits (1 + cos i cancels in one, tan runs
+        # into its pole in the other); what the frame needs is their error over u = 1 + p^2 + q^2
+        u = 1.0 + a[:, 3] ** 2 + a[:, 4] ** 2
+        assert (np.abs(d[:, 3:5] - a[:, 3:5]) <= 1e-13 * u[:, None]).all(), (name, (np.abs(d[:, 3:5] - a[:, 3:5]) / u[:, None]).max())
+        dl = np.abs((d[:, 5] - a[:, 5] + np.pi) % (2 * np.pi) - np.pi)
+        assert (dl <= 2e-13).all(), (name, dl.max())                                          # lambda, modulo 2 pi
+        assert (np.abs(d[:, 6] - a[:, 6]) <= 1e-13 * a[:, 6]).all(), name                   # n
+        assert (np.abs(out[ell, 18]) <= 1e-15).all(), name                                    # Kepler's equation at the epoch
+        t = out[ell, 19:].reshape(-1, n_obs, 4)
+        assert (t[:, :, 0] == 1.0).all() and (t[:, :, 2] == 1.0).all(), name
+        dr = np.abs(np.sqrt(t[:, :, 1]) - np.sqrt(t[:, :, 3]))
+        assert (dr <= 1e-7 + 1e-9 * np.sqrt(t[:, :, 3])).all(), (name, dr.max())
+        total_elliptic += int(ell.sum())
+    assert total_elliptic > 1400
