@@ -939,8 +939,13 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
     const bool glibc_mode = s->math_mode == OUTFIT_MATH_GLIBC;
     const int rms_mode = exact_all ? 1 : (no_screen_env || (!glibc_mode && exact_all_env)) ? 0 : 2;
     const bool refine = glibc_mode ? !exact_all : rms_mode == 2;
+    // the screen's direct state -> elements route pays on short trajectories (the conversion is a fifth of a 20-observation
+    // candidate's evaluation) and costs on long ones (kernels.hip rms_candidate): up to 64 observations per trajectory on
+    // average. OUTFIT_SCREEN_DIRECT = 0 / 1 forces either (measurement / verification aid).
+    static const char* direct_env = std::getenv("OUTFIT_SCREEN_DIRECT");
+    const int screen_direct = direct_env ? (std::atoi(direct_env) != 0) : (s->n_obs <= 64ull * s->n_traj);
     const outfit::RmsArgs rm{ci, w, obs_pos, s->cos_dec.p, s->obs_rec.p, s->params.extf, s->params.dtmax, outfit::sincos_consts(),
-                             rms_mode};
+                             screen_direct, rms_mode};
     HIP_TRY(hipStreamWaitEvent(st, s->ev_prepass, 0));
     {
       Stamp stamp(s, st, K_RMS);

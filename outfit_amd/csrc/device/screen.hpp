@@ -16,12 +16,17 @@
 //     observation, a jump of more than 0.5 rad, and any step that does not shrink as expected go through the
 //     reference's own iteration (solve_kepler_equation), which is also what decides Err(RootFindingError).
 //   * atan2 (twice per observation): one division, an odd polynomial of degree 21 on |t| <= tan(pi/8) (1.4e-16
-//     relative), constants in scalar registers — 45 instructions against the platform's 105.
+//     relative), constants in scalar registers — 45 instructions against the platform's 105. Round 5: the residual is
+//     the DIFFERENCE of two angles, and K1 stores the sine and cosine of the observed ones with each observation: the
+//     difference comes from one small-argument arctangent per coordinate (screen_term_fast: no octant logic, a short
+//     series), the generic form remains for directions more than 22.5 degrees apart.
+//   * the elements: straight from the state vector for short trajectories (screen_prologue), the loop warm from the epoch.
 //   * sqrt and the divisions: v_rsq_f64 / v_rcp_f64 with Newton refinements, no scaling for subnormals.
 //   * explicit fma() throughout (the exact paths are compiled with contraction off and spell out every rounding).
 //   * the constants are compile-time literals: passed as kernel arguments (50 doubles) they overflowed the scalar
 //     register file and every use became two v_readlane (690 per loop body; K2c 3.95 ms instead of 2.99).
-// Result: 877 -> ~300 VALU instructions per (candidate, observation); K2c 5.66 -> 2.99 ms per 10^7 candidates.
+// Result: 877 -> ~300 VALU instructions per (candidate, observation); K2c 5.66 -> 2.99 ms per 10^7 candidates (round 3),
+// 2.69 -> 2.06 ms with the direct conversion and the difference form of the residual (round 5).
 #pragma once
 #include "orbit.hpp"   // (brings screen_math.hpp: ScreenConsts, rcp / rsqrt, atan2_screen)
 
@@ -60,11 +65,10 @@ __device__ __forceinline__ double screen_slack_rad(unsigned level) {
 }
 
 // false = Err(RootFindingError), decided by the reference's own iteration
-// kLazyStart: the frame comes from screen_prologue (below), which leaves the Newton start of the reference's iteration
+// lazy_start: the frame comes from screen_prologue (below), which leaves the Newton start of the reference's iteration
 // (varpi, pi + varpi and its sine / cosine: an atan2 and a sincos) to the rare call that needs it
-template <bool kLazyStart = false>
 __device__ __forceinline__ bool screen_kepler(const Equinoctial& q, const TwoBodyFrame& F, double dt, ScreenKepler& S,
-                                              const SinCosConsts& K, const ScreenConsts& C) {
+                                              const SinCosConsts& K, const ScreenConsts& C, bool lazy_start = false) {
   const double lamu = fma(F.n, dt, q.lambda);
   bool full = !S.warm;
   if (S.warm) {
@@ -98,18 +102,15 @@ __device__ __forceinline__ bool screen_kepler(const Equinoctial& q, const TwoBod
   }
   if (full) {
     double lam = principal_angle_fast(lamu);
-    if constexpr (kLazyStart) {
-      TwoBodyFrame Fs = F;  // (only the four start fields differ; the rest is not read by the solver)
+    TwoBodyFrame Fs = F;  // (only the four start fields may differ; the rest is not read by the solver)
+    if (lazy_start) {
       Fs.varpi = 0.0;
       if (F.e2 > kEps * 1e2) Fs.varpi = principal_angle(atan2_screen(q.h, q.k, C));
       Fs.x0 = kPi + Fs.varpi;
       sincos_k(Fs.x0, K, Fs.sx0, Fs.cx0);
-      if (lam < Fs.varpi) lam += kTwoPi;
-      if (!solve_kepler_equation<kFnPlatform>(q, Fs, lam, S.x, S.sx, S.cx, &K)) return false;
-    } else {
-      if (lam < F.varpi) lam += kTwoPi;
-      if (!solve_kepler_equation<kFnPlatform>(q, F, lam, S.x, S.sx, S.cx, &K)) return false;
     }
+    if (lam < Fs.varpi) lam += kTwoPi;
+    if (!solve_kepler_equation<kFnPlatform>(q, Fs, lam, S.x, S.sx, S.cx, &K)) return false;
     S.dmin = fmin(S.dmin, fma(-q.h, S.sx, fma(-q.k, S.cx, 1.0)));
     S.lam = lam;
     S.off = lam - lamu;
@@ -198,11 +199,34 @@ __device__ __forceinline__ ScreenFrame screen_frame(const Equinoctial& q, const 
   return {ecl_to_equ_finite(F.f), ecl_to_equ_finite(F.g), F.n * (q.a * q.a)};
 }
 
+// One observation as the screening loop reads it: K1 packs it once per observation (kernels.h kObsRecDoubles = 12: six
+// 16-byte loads from one address) — w_ra = cos(dec_obs) / sigma_ra and w_dec = 1 / sigma_dec, and the sines and cosines of
+// the observed angles, all of which depend on the observation only, instead of being evaluated per (candidate, observation).
+struct ScreenObs {
+  double mjd, ra, cra, sra, cdec, sdec, w_ra, w_dec;
+  Vec3 pos;     // observer, equatorial
+  double dec;
+};
+// cra = NaN marks an observation whose angles are outside 0 <= ra < 2 pi, |dec| <= pi / 2 (or not finite): the residual of
+// such an observation takes the generic expressions (the reference subtracts the angles as they are given)
+__device__ __forceinline__ void pack_screen_obs(double* rec, double mjd, double ra, double dec, double w_ra, double w_dec) {
+  double sr, cr, sd, cd;
+  ::sincos(ra, &sr, &cr);
+  ::sincos(dec, &sd, &cd);
+  const bool regular = ra >= 0.0 && ra < kTwoPi && fabs(dec) <= 0.5 * kPi;
+  rec[0] = mjd; rec[1] = ra; rec[2] = regular ? cr : nan(""); rec[3] = sr; rec[4] = cd; rec[5] = sd;
+  rec[6] = w_ra; rec[7] = w_dec; rec[11] = dec;   // [8..10]: the observer's position, written by its own stage
+}
+__device__ __forceinline__ ScreenObs load_screen_obs(const double* rec) {
+  const double2* r = reinterpret_cast<const double2*>(rec);
+  const double2 a = r[0], b = r[1], c = r[2], d = r[3], e = r[4], f = r[5];
+  return {a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y, {e.x, e.y, f.x}, f.y};
+}
+
 // The squared normalised residual of one observation from (sin F, cos F): equinoctial_element.rs:850-867,
-// observation_ephemeris.rs:222-275,388-416 (incl. the sign-keeping `%` of quirk Q6), in the screen's arithmetic.
-// w_ra = cos(dec_obs) / sigma_ra and w_dec = 1 / sigma_dec depend on the observation only: K1 evaluates them once per
-// observation (kernels.h kObsRecDoubles) instead of the loop once per (candidate, observation).
-__device__ __forceinline__ double screen_term(const Equinoctial& q, const TwoBodyFrame& F, const ScreenFrame& G,
+// observation_ephemeris.rs:222-275,388-416 (incl. the sign-keeping `%` of quirk Q6), in the screen's arithmetic —
+// the generic form: both angles of the computed direction by atan2, then the reference's subtractions.
+__device__ __forceinline__ double screen_term_generic(const Equinoctial& q, const TwoBodyFrame& F, const ScreenFrame& G,
                                               double sx, double cx, double ra, double dec, double w_ra, double w_dec,
                                               const Vec3& obs_pos_equ, const ScreenConsts& C, double& inv_rho_max) {
   const double xe = q.a * fma(F.one_bh2, cx, fma(F.bet, sx, -q.k));
@@ -231,6 +255,90 @@ __device__ __forceinline__ double screen_term(const Equinoctial& q, const TwoBod
   const double t1 = da * w_ra;
   const double t2 = (dec - delta) * w_dec;
   return fma(t1, t1, t2 * t2);
+}
+
+// atan(num / den) for den > 0, |num| <= tan(pi/8) den: the kernel of atan2_screen without its octant logic.
+// kShortSeries: four terms of the series for |num / den| < 1e-2 (z^4 / 9 < 1.2e-17), and three of sqrt(1 + z) in
+// screen_term_fast — every residual of a candidate worth its name is that small, and the bench workload's K2c takes
+// 2.05 instead of 2.19 ms; but the candidates of long noisy arcs (residuals of degrees) make their waves run both forms,
+// so the callers enable it for short trajectories only (kernels.hip rms_candidate, kDirect).
+template <bool kShortSeries>
+__device__ __forceinline__ double atan_small(double num, double den, const ScreenConsts& C, double& z) {
+  const double rd = rcp_nr1(den);                 // 2^-46; the correction below squares that
+  double t = num * rd;
+  t = fma(fma(-den, t, num), rd, t);
+  z = t * t;
+  if (kShortSeries && z < 1e-4) return fma(t * z, fma(z, fma(z, -1.0 / 7.0, 0.2), -1.0 / 3.0), t);
+  double p = C.at[9];
+#pragma unroll
+  for (int j = 8; j >= 0; --j) p = fma(p, z, C.at[j]);
+  return fma(t * z, p, t);
+}
+
+// The same residual where the observation is regular (ScreenObs) and the computed direction lies within 22.5 degrees of
+// the observed one in both coordinates — anything else goes through screen_term_generic. The differences of the angles
+// are evaluated directly: rotating the computed direction by -ra_obs about z gives rho (cos D, sin D), D = alpha - ra_obs,
+// and (dec_obs - delta) is the angle of (cos dec rho + sin dec z, sin dec rho - cos dec z); each is ONE small-argument
+// arctangent (no octant logic, a four-term series) instead of a full atan2 followed by a subtraction, rho comes from
+// the first as u sqrt(1 + tan^2 D). The reference's wrap of ra_obs - alpha (alpha in [0, 2 pi), `%` keeping the sign, then
+// - 2 pi above pi: quirk Q6) reduces to: -D, minus 2 pi when ra_obs + D < 0.
+// Also cheaper than the generic form, to the accuracy the light-time correction needs (1e-12 relative): r = a (1 - k cos F
+// - h sin F) instead of a square root, one Newton round for |rel|.
+// `applies` = false: not within 22.5 degrees in ra (or an irregular observation): nothing but inv_rho_max has been touched,
+// the caller takes screen_term_generic for this observation (the main pass leaves its hot loop for a generic one then).
+template <bool kShortSeries>
+__device__ __forceinline__ double screen_term_fast(const Equinoctial& q, const TwoBodyFrame& F, const ScreenFrame& G,
+                                                   double sx, double cx, const ScreenObs& ob, const ScreenConsts& C,
+                                                   double& inv_rho_max, bool& applies) {
+  const double xe = q.a * fma(F.one_bh2, cx, fma(F.bet, sx, -q.k));
+  const double ye = q.a * fma(F.one_bk2, sx, fma(F.bet, cx, -q.h));
+  const double vc = G.na2 * rcp_nr1(q.a * fma(-q.h, sx, fma(-q.k, cx, 1.0)));
+  const double vxe = vc * fma(F.bet, cx, -(F.one_bh2 * sx));
+  const double vye = vc * fma(F.one_bk2, cx, -(F.bet * sx));
+  const Vec3 rel = {fma(xe, G.f.x, fma(ye, G.g.x, -ob.pos.x)), fma(xe, G.f.y, fma(ye, G.g.y, -ob.pos.y)),
+                    fma(xe, G.f.z, fma(ye, G.g.z, -ob.pos.z))};
+  const Vec3 vq = {fma(vxe, G.f.x, vye * G.g.x), fma(vxe, G.f.y, vye * G.g.y), fma(vxe, G.f.z, vye * G.g.z)};
+  const double d2 = fma(rel.x, rel.x, fma(rel.y, rel.y, rel.z * rel.z));
+  double dist, inv_dist;
+  {  // one coupled Newton round on v_rsq_f64: 2^-46
+    const double y = __builtin_amdgcn_rsq(d2);
+    double g = d2 * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    dist = g;
+    inv_dist = 2.0 * h;
+  }
+  inv_rho_max = fmax(inv_rho_max, inv_dist);
+  const double lt = dist * C.inv_vlight;
+  const Vec3 cor = {fma(-lt, vq.x, rel.x), fma(-lt, vq.y, rel.y), fma(-lt, vq.z, rel.z)};
+  const double u = fma(cor.x, ob.cra, cor.y * ob.sra), v = fma(cor.y, ob.cra, -(cor.x * ob.sra));
+  applies = u > 0.0 && fabs(v) <= C.tan_pi_8 * u;   // (false also for cra = NaN, d2 = 0 or not finite)
+  if (!applies) return 0.0;
+  double z;
+  const double dal = atan_small<kShortSeries>(v, u, C, z);       // alpha - ra_obs
+  double s1;                                       // sqrt(1 + z)
+  if (kShortSeries && z < 1e-4) s1 = fma(z, fma(z, fma(z, 0.0625, -0.125), 0.5), 1.0);
+  else { double inv; sqrt_rsqrt(1.0 + z, s1, inv); }
+  const double rho = u * s1;
+  const double p = fma(ob.sdec, rho, -(ob.cdec * cor.z)), qq = fma(ob.cdec, rho, ob.sdec * cor.z);
+  double dd;                                       // dec_obs - delta
+  if (qq > 0.0 && fabs(p) <= C.tan_pi_8 * qq) { double z2; dd = atan_small<kShortSeries>(p, qq, C, z2); }
+  else dd = ob.dec - atan2_screen(cor.z, rho, C);
+  double da = -dal;
+  if (ob.ra + dal < 0.0) da -= C.two_pi;
+  const double t1 = da * ob.w_ra;
+  const double t2 = dd * ob.w_dec;
+  return fma(t1, t1, t2 * t2);
+}
+template <bool kShortSeries = false>
+__device__ __forceinline__ double screen_term(const Equinoctial& q, const TwoBodyFrame& F, const ScreenFrame& G,
+                                              double sx, double cx, const ScreenObs& ob, const ScreenConsts& C,
+                                              double& inv_rho_max) {
+  bool applies;
+  const double t = screen_term_fast<kShortSeries>(q, F, G, sx, cx, ob, C, inv_rho_max, applies);
+  if (applies) return t;
+  return screen_term_generic(q, F, G, sx, cx, ob.ra, ob.dec, ob.w_ra, ob.w_dec, ob.pos, C, inv_rho_max);
 }
 
 }  // namespace outfit

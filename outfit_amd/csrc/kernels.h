@@ -145,11 +145,13 @@ struct CorrectArgs {
                               // saw an operand outside its window" — for every (candidate + iteration) divisible by m
 };
 
-// What the screening loop of K2c reads per (candidate, observation), packed by K1 into ONE 64-byte record per
-// observation: (mjd_tt, ra, dec, cos(dec) / sigma_ra, 1 / sigma_dec, observer x, y, z). Nine separate arrays cost nine
-// 64-bit address computations and nine loads per pass and two reciprocals of values that depend on the observation only;
-// the record is one address, four 16-byte loads and no reciprocal. The exact loops keep the reference's operands.
-constexpr unsigned kObsRecDoubles = 8;
+// What the screening loop of K2c reads per (candidate, observation), packed by K1 into ONE 96-byte record per
+// observation (device/screen.hpp ScreenObs): mjd_tt, ra, cos ra, sin ra, cos dec, sin dec, cos(dec) / sigma_ra,
+// 1 / sigma_dec, observer x, y, z, dec. Nine separate arrays cost nine 64-bit address computations and nine loads per
+// pass and two reciprocals of values that depend on the observation only; the record is one address, six 16-byte loads,
+// no reciprocal — and with the sines and cosines of the observed angles the residual needs no full atan2 (screen_term).
+// The exact loops keep the reference's operands.
+constexpr unsigned kObsRecDoubles = 12;
 
 struct RmsArgs {
   CandidateIndex I;
@@ -159,6 +161,8 @@ struct RmsArgs {
   const double* obs_rec;
   double extf, dtmax;
   SinCosConsts sc;  // polynomial constants as kernel arguments = scalar registers (device/orbit.hpp)
+  int screen_direct;  // rms_mode 2 only: 1 = the screen takes the elements straight from the state (device/screen.hpp
+                      // screen_prologue; short trajectories — the host decides, kernels.hip rms_candidate says why)
   int rms_mode;     // 0 exact with the platform functions (correctly-rounded mode) | 1 every candidate with the
                     // glibc-faithful functions (OUTFIT_RMS_EXACT_ALL=1) | 2 screening arithmetic, after which
                     // k_refine_best re-evaluates the contenders exactly (the glibc-faithful mode's default)

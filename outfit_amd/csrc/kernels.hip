@@ -124,9 +124,8 @@ k_observer_prepass(PrepassArgs a) {
     a.cos_dec[o] = cd;
     // the screen's record (a zero uncertainty gives Inf / NaN weights: a non-finite sum, i.e. the exact loop)
     double* rec = a.obs_rec + (size_t)kObsRecDoubles * o;
-    rec[0] = a.mjd[o]; rec[1] = a.ra[o]; rec[2] = a.dec[o];
-    rec[3] = cd / a.sra[o]; rec[4] = 1.0 / a.sdec[o];
-    if (!a.has_table) { rec[5] = a.helio[3 * o]; rec[6] = a.helio[3 * o + 1]; rec[7] = a.helio[3 * o + 2]; }
+    pack_screen_obs(rec, a.mjd[o], a.ra[o], a.dec[o], cd / a.sra[o], 1.0 / a.sdec[o]);
+    if (!a.has_table) { rec[8] = a.helio[3 * o]; rec[9] = a.helio[3 * o + 1]; rec[10] = a.helio[3 * o + 2]; }
   }
   if (!a.has_table) return;
   if (threadIdx.x == 0) { s_min = ~0ull; s_max = 0ull; s_bad = 0; }
@@ -161,7 +160,7 @@ k_observer_prepass(PrepassArgs a) {
   a.obs_pos[3 * o + 1] = out.y;
   a.obs_pos[3 * o + 2] = out.z;
   double* rec = a.obs_rec + (size_t)kObsRecDoubles * o;
-  rec[5] = out.x; rec[6] = out.y; rec[7] = out.z;
+  rec[8] = out.x; rec[9] = out.y; rec[10] = out.z;
 }
 
 // ------------------------------------------------------------------------------
@@ -904,15 +903,20 @@ __device__ __forceinline__ void select_rms_interval(const double* mjd, unsigned 
 // One candidate of K2c. kSlowList = false skips the candidates marked kFlagSlow (their state is being produced
 // concurrently by the general correction kernel); true handles exactly those.
 // kScreen: the residual loop in the screening arithmetic of device/screen.hpp (glibc-faithful mode: K3b re-evaluates
-// the contenders exactly); the prologue and the failure conditions stay those of the exact evaluation.
-// kRedo: an entry of the main pass's redo list, evaluated in the slow-list pass: the screening loop behind the
-// REFERENCE'S route from the state to the elements (the main pass takes screen.hpp's direct route where it may), and
-// the reference's expressions in place when the sum is not finite.
+// the contenders exactly).
+// kDirect (short trajectories, the launcher's choice): the elements come straight from the state (screen_prologue) and
+//   the loop starts warm from the epoch; the < 0.1 % of candidates that route declines go to the redo list — the tail of
+//   slow_list, evaluated by the slow-list pass (kRedo) — with bit 63 set: "the screening loop behind the reference's
+//   route". In place they cost the main pass its registers (the reference's route inlined: 26 spilled VGPRs, 2.08 ->
+//   2.35 ms; as a call: 52, 2.31 ms). On LONG trajectories the redo list backfires — a near-parabolic candidate runs the
+//   reference's Kepler iteration at every one of its 100 - 300 observations, and a pass of a few hundred lanes lasts as
+//   long as its longest chain (10 000 x 300 observations: slow-list pass 0.8 -> 1.5 ms) while the conversion is a
+//   small part of such a candidate — so those batches run with kDirect = false: every candidate through the angles.
+// A sum that is not finite (absurd inputs: overflow, 0 / 0, a zero uncertainty) takes the reference's expressions: in
+// the slow-list pass in place, from the main pass through the redo list (bit 63 clear; a candidate is on one list at
+// most), which keeps that second loop out of the main pass's register budget.
 constexpr unsigned long long kRedoScreenBit = 1ull << 63;
-#ifndef OUTFIT_SCREEN_DIRECT
-#define OUTFIT_SCREEN_DIRECT 1   // 0: the main pass converts through the angles too (measurement / verification aid)
-#endif
-template <bool kSlowList, int kFn, bool kScreen = false, bool kRedo = false>
+template <bool kSlowList, int kFn, bool kScreen = false, bool kDirect = false, bool kRedo = false>
 __device__ __forceinline__ void rms_candidate(const RmsArgs& a, unsigned long long cid) {
   const unsigned f0 = a.W.flags[cid];
   if ((f0 & kFlagEmpty) || !(f0 & kFlagOk)) return;
@@ -922,12 +926,8 @@ __device__ __forceinline__ void rms_candidate(const RmsArgs& a, unsigned long lo
   const Vec3 r2 = {a.W.state[0 * n + cid], a.W.state[1 * n + cid], a.W.state[2 * n + cid]};
   const Vec3 v2 = {a.W.state[3 * n + cid], a.W.state[4 * n + cid], a.W.state[5 * n + cid]};
   const double epoch = a.W.state[6 * n + cid];
-  if constexpr (kScreen && !kRedo && OUTFIT_SCREEN_DIRECT != 0) {
-    // the screen, both passes: elements straight from the state, the loop warm from the epoch (device/screen.hpp). A
-    // candidate the direct route does not classify, or whose sum is not finite, takes the reference's route: from the
-    // main pass through the redo list (evaluated by the slow-list pass, which keeps the second route out of the main
-    // pass's register budget), in the slow-list pass right below. The screened value of a candidate thus does not depend
-    // on which pass evaluates it (tests/test_gpu_small_batch.py hands candidates over and compares the scratch).
+  constexpr bool kInPlace = kSlowList || kRedo;  // evaluated by the slow-list pass: no list to hand a candidate to
+  if constexpr (kScreen && kDirect) {
     const ScreenConsts SCR = screen_consts();
     Equinoctial eq;
     TwoBodyFrame F;
@@ -947,15 +947,19 @@ __device__ __forceinline__ void rms_candidate(const RmsArgs& a, unsigned long lo
       const ScreenFrame G = screen_frame(eq, F);
       double acc = 0.0;
       bool err = false;
+#ifdef OUTFIT_K2C_PROLOGUE_ONLY  // measurement aid: the loop sees one observation (what the conversion in front of it costs)
+      i_end = i_start;
+#endif
       for (unsigned long long i = i_start; i <= i_end; ++i) {
-        const double2* rec = reinterpret_cast<const double2*>(a.obs_rec + (size_t)kObsRecDoubles * (c.base + i));
-        const double2 r01 = rec[0], r23 = rec[1], r45 = rec[2], r67 = rec[3];
-        if (!screen_kepler<true>(eq, F, r01.x - eq.epoch, S, a.sc, SCR)) {
+        // one record per observation (kernels.h kObsRecDoubles): 16-byte loads from one address
+        const ScreenObs ob = load_screen_obs(a.obs_rec + (size_t)kObsRecDoubles * (c.base + i));
+        if (!screen_kepler(eq, F, ob.mjd - eq.epoch, S, a.sc, SCR, true)) {
           err = true;
           break;
         }
-        const Vec3 op = {r45.y, r67.x, r67.y};
-        acc += screen_term(eq, F, G, S.sx, S.cx, r01.y, r23.x, r23.y, r45.x, op, SCR, S.inv_rho_max);
+        // (the generic residual stays inline behind its test: a second, generic loop for the rest of the window was
+        // measured — 2.23 instead of 2.08 ms, the register allocator spills more with two loops)
+        acc += screen_term<true>(eq, F, G, S.sx, S.cx, ob, SCR, S.inv_rho_max);
       }
       if (err || fabs(acc) < 1e300) {
         a.W.n_win[cid] = (unsigned)(i_end - i_start + 1);
@@ -963,15 +967,13 @@ __device__ __forceinline__ void rms_candidate(const RmsArgs& a, unsigned long lo
         a.W.flags[cid] = flags | (screen_level(eq.a, S.inv_rho_max, S.dmin) << kFlagLevelShift) | (err ? kFlagRmsErr : 0u);
         return;
       }
-      fallback = true;  // a non-finite sum: not what the shortcuts were made for
     }
-    if (!kSlowList) {
-      // redo list entry: bit 63 = "not classified" (the screening loop behind the reference's route); clear = a
-      // non-finite sum (the reference's expressions right away, as the loop has already been tried)
+    if (!kInPlace) {
       const unsigned long long at = atomicAdd(a.W.slow_count + 1, 1ull);
-      a.W.slow_list[n - 1 - at] = cid | (cls == kScreenDivert ? kRedoScreenBit : 0ull);
+      a.W.slow_list[n - 1 - at] = cid | (fallback ? kRedoScreenBit : 0ull);
       return;
     }
+    // slow-list pass: the reference's route below, in place (its screened value is what the redo list would give)
   }
 
   // build_result -> compute_orbit_from_state -> ccek1 (gauss.rs:906-923,1063-1076)
@@ -1006,27 +1008,20 @@ __device__ __forceinline__ void rms_candidate(const RmsArgs& a, unsigned long lo
       S.warm = false;
       S.dmin = 1.0;
       S.inv_rho_max = 0.0;
-#ifdef OUTFIT_K2C_PROLOGUE_ONLY  // measurement aid: the loop sees one observation (what the conversion in front of it costs)
+#ifdef OUTFIT_K2C_PROLOGUE_ONLY
       i_end = i_start;
 #endif
       for (unsigned long long i = i_start; i <= i_end; ++i) {
-        // one 64-byte record per observation (kernels.h kObsRecDoubles): four 16-byte loads from one address
-        const double2* rec = reinterpret_cast<const double2*>(a.obs_rec + (size_t)kObsRecDoubles * (c.base + i));
-        const double2 r01 = rec[0], r23 = rec[1], r45 = rec[2], r67 = rec[3];
-        if (!screen_kepler(eq, F, r01.x - eq.epoch, S, a.sc, SCR)) {
+        const ScreenObs ob = load_screen_obs(a.obs_rec + (size_t)kObsRecDoubles * (c.base + i));
+        if (!screen_kepler(eq, F, ob.mjd - eq.epoch, S, a.sc, SCR)) {
           err = true;
           break;
         }
-        const Vec3 op = {r45.y, r67.x, r67.y};
-        acc += screen_term(eq, F, G, S.sx, S.cx, r01.y, r23.x, r23.y, r45.x, op, SCR, S.inv_rho_max);
+        acc += screen_term(eq, F, G, S.sx, S.cx, ob, SCR, S.inv_rho_max);
       }
-      // anything the screen's shortcuts were not made for (non-finite or absurd inputs: overflow, 0 / 0, a zero
-      // uncertainty) shows up as a non-finite sum: such a candidate takes the reference's expressions instead — here
-      // in the slow-list pass; the main pass hands it to that pass through the redo list (the tail of slow_list: a
-      // candidate is on one list at most), which keeps the second loop out of the main pass's register budget
       flags |= screen_level(eq.a, S.inv_rho_max, S.dmin) << kFlagLevelShift;
       if (!err && !(fabs(acc) < 1e300)) {
-        if (!kSlowList && !kRedo) {
+        if (!kInPlace) {
           const unsigned long long at = atomicAdd(a.W.slow_count + 1, 1ull);
           a.W.slow_list[n - 1 - at] = cid;
           return;
@@ -1066,21 +1061,24 @@ constexpr int kRmsExact = 0, kRmsGlibc = 1, kRmsScreen = 2;
 #endif
 // (the slow-list pass — few lanes, three routes in one kernel, a chain of up to 30 k instructions — is compiled for two
 // waves per SIMD: 256 registers instead of 168 + spills)
-template <bool kSlowList, int kMode = kRmsExact>
+// kDirect (kRmsScreen only): the screen's direct route from the state to the elements (rms_candidate; RmsArgs::screen_direct)
+template <bool kSlowList, int kMode = kRmsExact, bool kDirect = false>
 __global__ void __launch_bounds__(256, kSlowList ? 2 : OUTFIT_RMS_WAVES)
 k_orbit_rms(RmsArgs a) {
   constexpr int kFn = kMode == kRmsGlibc ? kFnGlibc : kFnPlatform;
+  constexpr bool kScr = kMode == kRmsScreen;
   const unsigned long long lid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (kSlowList) {
     const unsigned long long n_slow = a.W.slow_count[0];
-    if (lid < n_slow) rms_candidate<true, kFn, kMode == kRmsScreen>(a, a.W.slow_list[lid]);
-    else if (kMode == kRmsScreen && lid - n_slow < a.W.slow_count[1]) {  // the main pass's redo list
+    if (lid < n_slow) {
+      rms_candidate<true, kFn, kScr, kDirect>(a, a.W.slow_list[lid]);
+    } else if (kScr && lid - n_slow < a.W.slow_count[1]) {  // the main pass's redo list
       const unsigned long long e = a.W.slow_list[a.I.n_cand - 1 - (lid - n_slow)];
-      if (e & kRedoScreenBit) rms_candidate<false, kFn, true, true>(a, e & ~kRedoScreenBit);
-      else rms_candidate<false, kFn, false>(a, e);
+      if (kDirect && (e & kRedoScreenBit)) rms_candidate<false, kFn, true, false, true>(a, e & ~kRedoScreenBit);
+      else rms_candidate<false, kFn, false>(a, e & ~kRedoScreenBit);
     }
   } else if (lid < a.I.n_cand) {
-    rms_candidate<false, kFn, kMode == kRmsScreen>(a, lid);
+    rms_candidate<false, kFn, kScr, kDirect>(a, lid);
   }
 }
 
@@ -2064,9 +2062,14 @@ hipError_t launch_gauss_correct(const CorrectArgs& a, unsigned n_cu, hipStream_t
 }
 hipError_t launch_orbit_rms(const RmsArgs& a, bool slow_list, hipStream_t s) {
   if (a.I.n_cand == 0) return hipSuccess;
+  // the direct route shortens the main pass and lengthens the slow-list pass (the redo list's chains): a small batch —
+  // the chunks that run the latency forms of the correction kernels — is the sum of its chains (1 000 objects: 0.95 ->
+  // 1.00 ms per step with it), so it keeps the one route
+  const bool direct = a.screen_direct != 0 && !use_pair_form(a.I.n_cand);
   if (slow_list) {
     const unsigned grid = (unsigned)((a.I.n_cand + 255) / 256);  // the list length lives on the device
     if (a.rms_mode == kRmsGlibc) hipLaunchKernelGGL((k_orbit_rms<true, kRmsGlibc>), dim3(grid), dim3(256), 0, s, a);
+    else if (a.rms_mode == kRmsScreen && direct) hipLaunchKernelGGL((k_orbit_rms<true, kRmsScreen, true>), dim3(grid), dim3(256), 0, s, a);
     else if (a.rms_mode == kRmsScreen) hipLaunchKernelGGL((k_orbit_rms<true, kRmsScreen>), dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((k_orbit_rms<true, kRmsExact>), dim3(grid), dim3(256), 0, s, a);
   } else {
@@ -2077,6 +2080,7 @@ hipError_t launch_orbit_rms(const RmsArgs& a, bool slow_list, hipStream_t s) {
     }
     const unsigned grid = (unsigned)((a.I.n_cand + 255) / 256);
     if (a.rms_mode == kRmsGlibc) hipLaunchKernelGGL((k_orbit_rms<false, kRmsGlibc>), dim3(grid), dim3(256), 0, s, a);
+    else if (a.rms_mode == kRmsScreen && direct) hipLaunchKernelGGL((k_orbit_rms<false, kRmsScreen, true>), dim3(grid), dim3(256), 0, s, a);
     else if (a.rms_mode == kRmsScreen) hipLaunchKernelGGL((k_orbit_rms<false, kRmsScreen>), dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((k_orbit_rms<false, kRmsExact>), dim3(grid), dim3(256), 0, s, a);
   }

@@ -215,11 +215,16 @@ void screen_routes(unsigned long long n, unsigned n_obs, const double* state, co
     for (unsigned j = 0; j < n_obs; ++j) {
       const double* b = obs + 8 * ((unsigned long long)n_obs * i + j);
       const double w_ra = cos(b[2]) / b[3], w_dec = 1.0 / b[4];
+      double rec[12];
+      pack_screen_obs(rec, b[0], b[1], b[2], w_ra, w_dec);
+      rec[8] = b[5]; rec[9] = b[6]; rec[10] = b[7];
+      const ScreenObs ob = load_screen_obs(rec);
       double* t = o + 19 + 4 * j;
-      if (okd) okd = screen_kepler<true>(qd, Fd, b[0] - qd.epoch, Sd, K, C);
-      if (okd) { t[0] = 1.0; t[1] = screen_term(qd, Fd, Gd, Sd.sx, Sd.cx, b[1], b[2], w_ra, w_dec, {b[5], b[6], b[7]}, C, Sd.inv_rho_max); }
-      if (oka) oka = screen_kepler<false>(qa, Fa, b[0] - qa.epoch, Sa, K, C);
-      if (oka) { t[2] = 1.0; t[3] = screen_term(qa, Fa, Ga, Sa.sx, Sa.cx, b[1], b[2], w_ra, w_dec, {b[5], b[6], b[7]}, C, Sa.inv_rho_max); }
+      if (okd) okd = screen_kepler(qd, Fd, b[0] - qd.epoch, Sd, K, C, true);
+      if (okd) { t[0] = 1.0; t[1] = (j & 1) ? screen_term<true>(qd, Fd, Gd, Sd.sx, Sd.cx, ob, C, Sd.inv_rho_max) : screen_term<false>(qd, Fd, Gd, Sd.sx, Sd.cx, ob, C, Sd.inv_rho_max); }
+      // the route through the angles with the GENERIC residual (two atan2, the reference's subtractions)
+      if (oka) oka = screen_kepler(qa, Fa, b[0] - qa.epoch, Sa, K, C, false);
+      if (oka) { t[2] = 1.0; t[3] = screen_term_generic(qa, Fa, Ga, Sa.sx, Sa.cx, b[1], b[2], w_ra, w_dec, {b[5], b[6], b[7]}, C, Sa.inv_rho_max); }
     }
   }
 }

@@ -615,6 +615,8 @@ def test_screen_direct_route_agrees_with_the_route_through_the_angles(D):
     lo = truth.copy(); lo[:, 1] = 10.0 ** rng.uniform(-9, -3, len(lo)); pops["near circular"] = lo
     eqt = truth.copy(); eqt[:, 2] = 10.0 ** rng.uniform(-12, -4, len(eqt)); pops["near equatorial"] = eqt
     ret = truth.copy(); ret[:, 2] = np.pi - 10.0 ** rng.uniform(-6, -0.5, len(ret)); pops["retrograde"] = ret
+    pops["across ra = 0"] = truth.copy()   # the whole geometry turned about the pole: observed ra straddles 0 / 2 pi (quirk Q6)
+    pops["irregular angles"] = truth.copy()  # ra given outside [0, 2 pi): the generic residual on both sides
     L = O.lib()
     total_elliptic = 0
     for name, pop in pops.items():
@@ -640,6 +642,18 @@ def test_screen_direct_route_agrees_with_the_route_through_the_angles(D):
             obs[i, :, 0] = ds["mjd_tt"][sl]; obs[i, :, 1] = ds["ra"][sl]; obs[i, :, 2] = ds["dec"][sl]
             obs[i, :, 3] = ds["sigma_ra"][sl]; obs[i, :, 4] = ds["sigma_dec"][sl]
             obs[i, :, 5:] = ds["obs_helio_equ"].reshape(-1, 3)[sl]
+        if name == "across ra = 0":
+            for i in range(n):
+                phi = obs[i, n_obs // 2, 1] - (1e-7 if i % 2 else -1e-7) * (i % 5)   # middle observation lands at ra ~ 0 +- k 1e-7
+                c_, s__ = np.cos(phi), np.sin(phi)
+                rot = np.array([[c_, s__, 0.0], [-s__, c_, 0.0], [0.0, 0.0, 1.0]])
+                state[i, :3] = rot @ state[i, :3]
+                state[i, 3:6] = rot @ state[i, 3:6]
+                obs[i, :, 5:] = obs[i, :, 5:] @ rot.T
+                obs[i, :, 1] = np.mod(obs[i, :, 1] - phi, 2 * np.pi)
+        if name == "irregular angles":
+            obs[::2, :, 1] -= 2 * np.pi
+            obs[1::2, :, 1] += 2 * np.pi
         state, obs = np.ascontiguousarray(state), np.ascontiguousarray(obs)
         stride = 19 + 4 * n_obs
         out = np.empty(n * stride)
@@ -649,7 +663,10 @@ def test_screen_direct_route_agrees_with_the_route_through_the_angles(D):
         ell, hyp = cls == 0, cls == 1
         assert (kind[ell] == 0).all() and (conv[ell] == 0).all() and (hyper[ell] == 0).all(), name
         assert (kind[hyp] == 1).all() and (conv[hyp] == 0).all() and (hyper[hyp] == 1).all(), name
-        if name in ("bench", "near circular", "near equatorial"):
+        if name == "across ra = 0":   # the reference's wrap leaves ra_obs - alpha below -pi alone: residuals of ~2 pi / sigma
+            big = np.sqrt(out[:, 19:].reshape(n, n_obs, 4)[:, :, 3]).max(1) > 1e6
+            assert big.any() and not big.all()
+        if name in ("bench", "near circular", "near equatorial", "across ra = 0", "irregular angles"):
             assert ell.all(), name
         if name == "eccentric":
             assert hyp.any() and (cls == 2).any() and ell.any()
