@@ -201,6 +201,11 @@ def test_contender_refinement_equals_the_exhaustive_exact_evaluation(tmp_path, m
     # round 4: K3b's first round reads the contender list K3 collected against its running bound; OUTFIT_REFINE_SCAN_ALL=1
     # makes it sweep every candidate as before — the same records either way
     assert _digests({"OUTFIT_REFINE_SCAN_ALL": "1"}, None, mode) == refined
+    # round 5: the screen takes a candidate's elements straight from its state on short trajectories (device/screen.hpp
+    # screen_prologue; the flags of every candidate are held against the exact evaluation's below); OUTFIT_SCREEN_DIRECT=0
+    # sends every candidate through the angles as on long ones — the same records either way
+    if mode == "glibc":
+        assert _digests({"OUTFIT_SCREEN_DIRECT": "0"}, None, mode) == refined
     assert all(int(d.split(":")[1]) > 14000 for d in refined)
     report = []
     for i in range(3):

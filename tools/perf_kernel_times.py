@@ -1,5 +1,8 @@
+"""GPU box: kernel times (HIP events, summed over three back-to-back runs) of the bench workload for one build of the
+library — the A/B tool of the K2c work (profiles/round05_k2c_screen.log).
+    python tools/perf_kernel_times.py [path of liboutfit_hip.so]"""
 import os, sys
-ROOT = "/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT]
 import outfit_amd._lib as L
 if len(sys.argv) > 1: L.LIB_PATH = sys.argv[1]
