@@ -2065,7 +2065,8 @@ hipError_t launch_orbit_rms(const RmsArgs& a, bool slow_list, hipStream_t s) {
   // the direct route shortens the main pass and lengthens the slow-list pass (the redo list's chains): a small batch —
   // the chunks that run the latency forms of the correction kernels — is the sum of its chains (1 000 objects: 0.95 ->
   // 1.00 ms per step with it), so it keeps the one route
-  const bool direct = a.screen_direct != 0 && !use_pair_form(a.I.n_cand);
+  // (the size alone decides, not OUTFIT_PAIR_MODE: the test aid that forces a form must not change the screen with it)
+  const bool direct = a.screen_direct != 0 && a.I.n_cand > kPairMaxCandidates;
   if (slow_list) {
     const unsigned grid = (unsigned)((a.I.n_cand + 255) / 256);  // the list length lives on the device
     if (a.rms_mode == kRmsGlibc) hipLaunchKernelGGL((k_orbit_rms<true, kRmsGlibc>), dim3(grid), dim3(256), 0, s, a);
