@@ -341,6 +341,7 @@ struct outfit_hip_session {
   unsigned wave_min_obs = 0;
   size_t wave_lds = 0;
   std::vector<unsigned> wave_list_host;
+  uint64_t max_traj_len = 0;   // observations of the longest trajectory (chooses the screen's route, session_run)
   DevBuf<unsigned> wave_list;
   DevBuf<outfit::GaussResultRec> results;
   DevBuf<int> error_flag;
@@ -738,6 +739,7 @@ int session_build(outfit_hip_session* s, const outfit_iod_params_t* params, cons
   {
     uint64_t max_len = 0;
     for (uint64_t t = 0; t < s->n_traj; ++t) max_len = std::max<uint64_t>(max_len, off[t + 1] - off[t]);
+    s->max_traj_len = max_len;
     const uint64_t reduced = std::min<uint64_t>(max_len, std::max<uint64_t>(params->max_obs_for_triplets, 3));
     s->triplet_lds = reduced <= 1024 && (uint64_t)s->k_cap * 64 * 12 <= 160 * 1024 - 1024 && s->k_cap > 0;
     // Long trajectories go to the wave-per-trajectory form of K0 (device/triplets.hpp): from 48 reduced epochs on
@@ -940,10 +942,11 @@ int session_run(outfit_hip_session* s, hipStream_t st, outfit::GaussResultRec* d
     const int rms_mode = exact_all ? 1 : (no_screen_env || (!glibc_mode && exact_all_env)) ? 0 : 2;
     const bool refine = glibc_mode ? !exact_all : rms_mode == 2;
     // the screen's direct state -> elements route pays on short trajectories (the conversion is a fifth of a 20-observation
-    // candidate's evaluation) and costs on long ones (kernels.hip rms_candidate): up to 64 observations per trajectory on
-    // average. OUTFIT_SCREEN_DIRECT = 0 / 1 forces either (measurement / verification aid).
+    // candidate's evaluation) and costs on long ones (kernels.hip rms_candidate): batches whose LONGEST trajectory has up
+    // to 64 observations (one long trajectory's declined candidates would be the slow-list pass's chain).
+    // OUTFIT_SCREEN_DIRECT = 0 / 1 forces either (measurement / verification aid).
     static const char* direct_env = std::getenv("OUTFIT_SCREEN_DIRECT");
-    const int screen_direct = direct_env ? (std::atoi(direct_env) != 0) : (s->n_obs <= 64ull * s->n_traj);
+    const int screen_direct = direct_env ? (std::atoi(direct_env) != 0) : (s->max_traj_len <= 64);
     const outfit::RmsArgs rm{ci, w, obs_pos, s->cos_dec.p, s->obs_rec.p, s->params.extf, s->params.dtmax, outfit::sincos_consts(),
                              screen_direct, rms_mode};
     HIP_TRY(hipStreamWaitEvent(st, s->ev_prepass, 0));
